@@ -1,0 +1,300 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+A straight-line float32 numpy restatement of the reference's per-frame forward
+pass `UVLTrack.forward_test` (reference lib/models/uvltrack/uvltrack.py:41-45).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the shipped path (uvltrack_amd / lib.models) never does and fails
+loudly when the HIP library is missing.
+
+Parity pin: the reference holds NO test, golden vector or fixture for this path
+(SURVEY.md §8c "parity unpinned by the reference"), so this oracle is pinned
+against outputs of the reference itself, run in the build container by
+oracle/make_golden.py (imports /root/reference with stub packages) and committed
+as tests/golden/*.npz.  tests/test_oracle_golden.py checks every fixture to
+atol 2e-4 (fp32 re-association only).
+
+Every function cites the reference file:line it restates.  Weights are a dict
+name -> float32 ndarray in the reference's state_dict schema.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.special import erf as _erf
+
+f32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def linear(x, w, b=None):
+    """nn.Linear: y = x W^T + b, W is [out, in]."""
+    y = x @ w.T
+    if b is not None:
+        y = y + b
+    return y.astype(f32, copy=False)
+
+
+def layer_norm(x, w, b, eps):
+    """nn.LayerNorm / BertLayerNorm (bert_backbone.py:231-244): biased variance, eps inside sqrt."""
+    u = x.mean(-1, keepdims=True, dtype=f32)
+    d = x - u
+    s = (d * d).mean(-1, keepdims=True, dtype=f32)
+    return (d / np.sqrt(s + f32(eps)) * w + b).astype(f32, copy=False)
+
+
+def gelu(x):
+    """exact erf GELU: nn.GELU() (backbones/utils.py:57) and bert gelu (bert_backbone.py:118-124)."""
+    return (x * f32(0.5) * (f32(1.0) + _erf(x / f32(np.sqrt(2.0))))).astype(f32, copy=False)
+
+
+def softmax(x, axis=-1):
+    m = x.max(axis=axis, keepdims=True)
+    e = np.exp(x - m, dtype=f32)
+    return (e / e.sum(axis=axis, keepdims=True, dtype=f32)).astype(f32, copy=False)
+
+
+def sigmoid(x):
+    return (f32(1.0) / (f32(1.0) + np.exp(-x, dtype=f32))).astype(f32, copy=False)
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, dim=-1): x / max(||x||_2, eps)."""
+    n = np.sqrt((x * x).sum(-1, keepdims=True, dtype=f32))
+    return (x / np.maximum(n, f32(eps))).astype(f32, copy=False)
+
+
+# --------------------------------------------------------------------------
+# backbone pieces
+# --------------------------------------------------------------------------
+def patch_embed(img, w, b):
+    """PatchEmbed.forward (mae_vit.py:94-100): Conv2d(3,D,k16,s16) == GEMM over
+    (c,kh,kw)-ordered patch vectors; output [B, G*G, D], token s = i*G + j."""
+    B, C, H, W = img.shape
+    G = H // 16
+    p = img.reshape(B, C, G, 16, G, 16).transpose(0, 2, 4, 1, 3, 5).reshape(B, G * G, C * 256)
+    return linear(p, w.reshape(w.shape[0], -1), b)
+
+
+def patchify(sd, z, x):
+    """MaskedAutoencoderViT.patchify (mae_vit.py:203-215)."""
+    v = "backbone.vit."
+    pw, pb = sd[v + "patch_embed.proj.weight"], sd[v + "patch_embed.proj.bias"]
+    zt = patch_embed(z, pw, pb) + sd[v + "pos_embed_z"]
+    xt = patch_embed(x, pw, pb) + sd[v + "pos_embed_x"]
+    cls = np.broadcast_to(sd[v + "cls_token"], (x.shape[0], 1, pw.shape[0]))
+    return np.concatenate([cls, zt, xt], axis=1).astype(f32)
+
+
+def bert_embedding(sd, ids, tmask):
+    """BertModel.embedding (bert_backbone.py:740-750) + BertEmbeddings.forward (:260-274), eval mode."""
+    e = "backbone.bert.embeddings."
+    T = ids.shape[1]
+    emb = sd[e + "word_embeddings.weight"][ids] + sd[e + "position_embeddings.weight"][:T][None] \
+        + sd[e + "token_type_embeddings.weight"][0][None, None]
+    emb = layer_norm(emb.astype(f32), sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], 1e-12)
+    bert_mask = ((f32(1.0) - tmask.astype(f32)) * f32(-10000.0))[:, None, None, :]
+    return emb, bert_mask
+
+
+def cat_mask(tmask, flag, nz, nx):
+    """ModalityUnifiedFeatureExtractor.cat_mask (extractor.py:43-50). True = key is ignored."""
+    B = flag.shape[0]
+    fl = flag.reshape(B, 1)
+    x_m = np.ones((B, nx), f32)
+    z_m = np.ones((B, nz), f32) * (fl != 1)
+    c_m = np.ones((B, 1), f32) * (fl != 1)
+    t_m = tmask.astype(f32) * (fl != 0)
+    mask = ~np.concatenate([c_m, z_m, x_m, t_m], axis=1).astype(bool)
+    vmask = ~np.concatenate([c_m, z_m, x_m], axis=1).astype(bool)
+    return mask, vmask
+
+
+def vit_attention(sd, pre, x, key_mask, heads):
+    """Attention.forward (block.py:47-61)."""
+    B, N, C = x.shape
+    hd = C // heads
+    qkv = linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(B, N, 3, heads, hd).transpose(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(0, 1, 3, 2)) * f32(hd ** -0.5)
+    if key_mask is not None:
+        attn = np.where(key_mask[:, None, None, :], f32(-1e10), attn)
+    attn = softmax(attn.astype(f32), -1)
+    o = (attn @ v).transpose(0, 2, 1, 3).reshape(B, N, C)
+    return linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+
+
+def vit_block(sd, i, x, key_mask, heads):
+    """Block.forward (block.py:29-32); LayerNorm eps 1e-6 (mae_vit.py:221); DropPath/LayerScale are Identity."""
+    p = "backbone.vit.blocks.%d." % i
+    x = x + vit_attention(sd, p + "attn.", layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6), key_mask, heads)
+    h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
+    h = gelu(linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))     # Mlp.forward (backbones/utils.py:63-69)
+    return (x + linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])).astype(f32)
+
+
+def bert_layer(sd, i, y, bert_mask, heads):
+    """BertLayer.forward (bert_backbone.py:390-394) = BertSelfAttention (:299-325) + BertSelfOutput (:335-339)
+    + BertIntermediate (:363-366) + BertOutput (:376-380); post-LN, eps 1e-12, eval mode."""
+    p = "backbone.bert.encoder.layer.%d." % i
+    B, T, C = y.shape
+    hd = C // heads
+
+    def split(t):
+        return t.reshape(B, T, heads, hd).transpose(0, 2, 1, 3)
+    q = split(linear(y, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"]))
+    k = split(linear(y, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"]))
+    v = split(linear(y, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"]))
+    s = (q @ k.transpose(0, 1, 3, 2)) / f32(np.sqrt(hd))
+    s = s + bert_mask
+    pr = softmax(s.astype(f32), -1)
+    ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, T, C)
+    a = linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+    a = layer_norm(a + y, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], 1e-12)
+    h = gelu(linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+    o = linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    return layer_norm(o + a, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
+
+
+def txt_token_of(txt, tmask, mode):
+    """generate_txt_token (extractor.py:79-83)."""
+    if mode == "mean":
+        m = tmask.astype(f32)[..., None]
+        return ((txt * m).sum(1, keepdims=True) / m.sum(1, keepdims=True)).astype(f32)
+    return txt[:, :1]
+
+
+def backbone_contrast(sd, img, txt, tmask, flag, nz, mode):
+    """ModalityUnifiedFeatureExtractor.contractive_learning (extractor.py:85-93) -> [B, nx, 1]."""
+    vis_token, x = img[:, :1], img[:, 1 + nz:]
+    tt = txt_token_of(txt, tmask, mode)
+    tau = np.exp(sd["backbone.logit_scale"]).astype(f32)
+    xn = l2_normalize(x)
+    lv = tau * (xn @ l2_normalize(vis_token).transpose(0, 2, 1))
+    lt = tau * (xn @ l2_normalize(tt).transpose(0, 2, 1))
+    grp = np.stack([lv, lt, (lv + lt) / f32(2.0)], axis=1)
+    return grp[np.arange(flag.shape[0]), flag.reshape(-1)].astype(f32)
+
+
+def backbone_forward(sd, spec, template, search, ids, tmask, flag, taps=None):
+    """ModalityUnifiedFeatureExtractor.forward (extractor.py:52-77)."""
+    img = patchify(sd, template, search)
+    txt, bert_mask = bert_embedding(sd, ids, tmask)
+    mask, vmask = cat_mask(tmask, flag, spec.nz, spec.nx)
+    me = sd["backbone.vit.modal_embed"]
+    logits = []
+    if taps is not None:
+        taps["embed_img"], taps["embed_txt"] = img.copy(), txt.copy()
+    for i in range(spec.depth):
+        if i in spec.fusion_layers:
+            # MaskedAutoencoderViT.forward_joint (mae_vit.py:193-200): the modal shift is permanent
+            emb = np.concatenate([img + me[0], txt + me[1]], axis=1).astype(f32)
+            emb = vit_block(sd, i, emb, mask, spec.heads)
+            img, txt = emb[:, :spec.nv], emb[:, spec.nv:]
+        else:
+            img = vit_block(sd, i, img, vmask, spec.heads)
+            txt = bert_layer(sd, i, txt, bert_mask, spec.heads)
+        if i in spec.cont_layers:
+            logits.append(backbone_contrast(sd, img, txt, tmask, flag, spec.nz, spec.txt_token_mode))
+        if taps is not None:
+            taps["img_%d" % i], taps["txt_%d" % i] = img.copy(), txt.copy()
+    B = img.shape[0]
+    F = spec.feat_sz
+    return {
+        "search": img[:, 1 + spec.nz:], "template": img[:, 1:1 + spec.nz], "text": txt,
+        "vis_token": img[:, :1], "txt_token": txt_token_of(txt, tmask, spec.txt_token_mode),
+        "flag": flag.reshape(-1),
+        "logits": np.stack(logits, axis=1).reshape(B, -1, F, F),
+    }
+
+
+# --------------------------------------------------------------------------
+# head
+# --------------------------------------------------------------------------
+def conv3x3_bn_relu(sd, pre, x):
+    """heads/utils.py:126-131 in eval mode: Conv2d(3x3, pad 1, bias) + BatchNorm2d(running stats, eps 1e-5) + ReLU.
+    x is NCHW."""
+    w, b = sd[pre + "0.weight"], sd[pre + "0.bias"]
+    B, C, H, W = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    cols = np.empty((B, H, W, C, 3, 3), f32)
+    for kh in range(3):
+        for kw in range(3):
+            cols[:, :, :, :, kh, kw] = xp[:, :, kh:kh + H, kw:kw + W].transpose(0, 2, 3, 1)
+    y = cols.reshape(B * H * W, C * 9) @ w.reshape(w.shape[0], -1).T + b
+    y = (y - sd[pre + "1.running_mean"]) / np.sqrt(sd[pre + "1.running_var"] + f32(1e-5)) * sd[pre + "1.weight"] + sd[pre + "1.bias"]
+    y = np.maximum(y, f32(0.0)).astype(f32)
+    return y.reshape(B, H, W, -1).transpose(0, 3, 1, 2)
+
+
+def tower(sd, name, x):
+    """One of the four nn.Sequential towers (head:28-50)."""
+    for l in range(4):
+        x = conv3x3_bn_relu(sd, "box_head.%s.%d." % (name, l), x)
+    w, b = sd["box_head.%s.4.weight" % name], sd["box_head.%s.4.bias" % name]
+    B, C, H, W = x.shape
+    y = x.transpose(0, 2, 3, 1).reshape(-1, C) @ w.reshape(w.shape[0], C).T + b
+    return y.reshape(B, H, W, -1).transpose(0, 3, 1, 2).astype(f32)
+
+
+def head_contrast(sd, spec, search, prompt):
+    """ModalityAdaptiveBoxHead.contractive_learning, test branch (head:140-148)."""
+    tau = np.exp(sd["box_head.logit_scale"]).astype(f32)
+    cs = tau * (l2_normalize(search) @ l2_normalize(prompt).transpose(0, 2, 1))
+    zero = np.zeros_like(cs[:, :, :1])
+    if spec.softmax_one:
+        mid = np.concatenate([cs[:, :, 1:], zero], axis=-1).max(-1, keepdims=True)
+        return np.concatenate([cs[:, :, :1], mid, zero], axis=-1).astype(f32)
+    return np.concatenate([cs[:, :, :1], cs[:, :, 1:].max(-1, keepdims=True)], axis=-1).astype(f32)
+
+
+def head_forward(sd, spec, out, prompt):
+    """ModalityAdaptiveBoxHead.forward (head:62-94) + convert2bbox (head:108-119)."""
+    flag = out["flag"]
+    B = flag.shape[0]
+    F = spec.feat_sz
+    bid = np.arange(B)
+    cont = head_contrast(sd, spec, out["search"], prompt)
+    x = out["search"].transpose(0, 2, 1).reshape(B, -1, F, F)
+    if spec.cls_tokenize:
+        vt, tt = out["vis_token"], out["txt_token"]
+        grp = np.concatenate([vt, tt, (vt + tt) / f32(2.0)], axis=1)
+        token = grp[bid, flag][:, :, None, None]
+        cls_map = sigmoid(tower(sd, "conv_cls", x * token))[:, 0]
+    else:
+        cls_map = sigmoid(tower(sd, "conv_cls", x))[:, 0]
+    off = tower(sd, "conv_offset", x)
+    if spec.offset_sigmoid:
+        off = sigmoid(off)
+    tr = sigmoid(tower(sd, "conv_bbox", x))
+    gr = sigmoid(tower(sd, "conv_bbox_grounding", x))
+    size = np.stack([tr, gr, tr], axis=1)[bid, flag]
+    # convert2bbox
+    p0 = softmax(cont, -1)[:, :, 0]
+    score = cls_map.reshape(B, -1) * p0
+    s_idx = score.argmax(-1)
+    ctr = (sd["box_head.coodinate"] + off.reshape(B, 2, -1)) / f32(F)
+    bbox_map = np.concatenate([ctr, size.reshape(B, 2, -1)], axis=1).transpose(0, 2, 1).astype(f32)
+    res = dict(out)
+    res.update({
+        "cls_score": (cls_map * p0.reshape(B, F, F)) if spec.joint_cls else cls_map,
+        "bbox_map": bbox_map,
+        "pred_boxes": bbox_map[bid, s_idx][:, None],
+        "cont_score": cont,
+        "prompts": prompt, "prompt": prompt,
+        "cls_score_test": cls_map,
+        "score": score.astype(f32),          # not in the reference dict: kept for tie-aware argmax checks
+    })
+    return res
+
+
+def forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps=None):
+    """UVLTrack.forward_test (uvltrack.py:41-45), eval semantics."""
+    sd = {k: (np.asarray(v, dtype=f32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in sd.items()}
+    out = backbone_forward(sd, spec, template.astype(f32), search.astype(f32), np.asarray(ids), np.asarray(tmask),
+                           np.asarray(flag).reshape(-1, 1), taps)
+    return head_forward(sd, spec, out, prompt.astype(f32))
+
+
+OUTPUT_KEYS = ("search", "template", "text", "vis_token", "txt_token", "logits", "cls_score",
+               "cls_score_test", "bbox_map", "pred_boxes", "cont_score")

@@ -1,0 +1,66 @@
+"""Pin the numpy oracle against the committed reference outputs (CPU only)."""
+import numpy as np
+import pytest
+
+from oracle import uvl_oracle as O
+from tests.golden_util import list_cases, load_case, rebuild_inputs, rebuild_weights
+
+ATOL = 2e-4     # fp32 re-association only; measured deviation is <= 1.5e-5 (see fixture meta)
+
+SMALL = [c for c in list_cases() if c.startswith("tiny")]
+BIG = [c for c in list_cases() if not c.startswith("tiny")]
+
+
+def _check(name):
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    sd = rebuild_weights(meta, spec)
+    out = O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"])
+    for k, v in ref.items():
+        if k == "flag":
+            assert (out["flag"] == v).all()
+            continue
+        if k.endswith(".slice"):
+            got = out[k[:-6]][:, :8, :32]
+        else:
+            got = out[k]
+        assert got.shape == v.shape, k
+        np.testing.assert_allclose(got, v, atol=ATOL, rtol=0, err_msg="%s/%s" % (name, k))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_matches_reference_tiny(name):
+    _check(name)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", [c for c in BIG if c.startswith("b_")])
+def test_oracle_matches_reference_base(name):
+    _check(name)
+
+
+def test_mask_semantics_text_never_leaks_in_bbox_mode():
+    """flag 0 masks every text key (extractor.py:43-50): visual outputs must not depend on the text ids."""
+    meta, spec, _ = load_case("tiny_mixed")
+    inp = rebuild_inputs(meta, spec)
+    sd = rebuild_weights(meta, spec)
+    flag = np.zeros_like(inp["flag"])
+    a = O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], flag)
+    ids2 = (inp["ids"] + 7) % spec.vocab
+    b = O.forward_test(sd, spec, inp["template"], inp["search"], ids2, inp["mask"], inp["prompt"], flag)
+    for k in ("search", "bbox_map", "cls_score_test", "cont_score", "logits"):
+        np.testing.assert_array_equal(a[k], b[k])
+    assert np.abs(a["text"] - b["text"]).max() > 1e-3
+
+
+def test_batch_independence():
+    """Each sequence is independent in eval mode: batch of 3 == 3 single runs."""
+    meta, spec, _ = load_case("tiny_mixed")
+    inp = rebuild_inputs(meta, spec)
+    sd = rebuild_weights(meta, spec)
+    full = O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"])
+    for b in range(meta["batch"]):
+        one = O.forward_test(sd, spec, inp["template"][b:b + 1], inp["search"][b:b + 1], inp["ids"][b:b + 1],
+                             inp["mask"][b:b + 1], inp["prompt"][b:b + 1], inp["flag"][b:b + 1])
+        for k in ("bbox_map", "cls_score_test", "cont_score", "logits", "search"):
+            np.testing.assert_allclose(one[k][0], full[k][b], atol=1e-5, rtol=0)
