@@ -1,0 +1,174 @@
+/*
+ * uvltrack_hip.h -- C ABI of the MI355X (gfx950) implementation of UVLTrack's per-frame
+ * forward pass, `UVLTrack.forward_test` (reference lib/models/uvltrack/uvltrack.py:41-45).
+ *
+ * The reference has no FFI: its hot path is eager PyTorch.  This header is the boundary a
+ * maintainer binds instead of `self.backbone(...)` + `self.box_head(...)`; each entry point
+ * cites the reference interface it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer into caller-owned memory (e.g. tensor.data_ptr())
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream)
+ *   - all calls are asynchronous on `stream`; nothing here synchronises the device except
+ *     uvl_create / uvl_finalize_weights / uvl_destroy / uvl_graph_capture
+ *   - return 0 on success, negative UVL_E* on error; uvl_last_error() gives a thread-local message
+ *   - no call allocates device memory per frame: activations live in a caller-provided workspace
+ *     of uvl_workspace_bytes() bytes; weights are packed once into library-owned memory
+ *   - one handle per device per process; calls on one handle must be serialised by the caller
+ */
+#ifndef UVLTRACK_HIP_H
+#define UVLTRACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVL_OK            0
+#define UVL_EINVAL       -1   /* bad argument / unsupported geometry */
+#define UVL_ESTATE       -2   /* call order violated (e.g. forward before finalize) */
+#define UVL_EHIP         -3   /* a HIP runtime call failed */
+#define UVL_ENOTFOUND    -4   /* unknown tensor name */
+
+#define UVL_MAX_LAYERS   64
+
+/* Geometry of the model; mirrors uvltrack_amd.spec.ModelSpec, i.e. the yaml keys the reference
+ * reads in ModalityUnifiedFeatureExtractor.__init__ (extractor.py:12-41) and
+ * build_modality_adaptive_box_head (heads/__init__.py:4-13). */
+typedef struct uvl_config {
+    int32_t dim;              /* MODEL.HIDDEN_DIM: 768 (B) / 1024 (L); multiple of 64 */
+    int32_t heads;            /* 12 / 16; dim/heads must be 64 */
+    int32_t depth;            /* 12 / 24 */
+    int32_t n_fusion_start;   /* min(FUSION_LAYER); layers [n_fusion_start, depth) are joint */
+    int32_t n_cont;           /* len(CONT_LOSS_LAYER) */
+    int32_t cont_layers[UVL_MAX_LAYERS];
+    int32_t template_size;    /* DATA.TEMPLATE.SIZE (pixels, multiple of 16) */
+    int32_t search_size;      /* DATA.SEARCH.SIZE */
+    int32_t text_len;         /* BERT.MAX_QUERY_LEN (<= 64) */
+    int32_t head_dim;         /* MODEL.HEAD.HEAD_DIM (multiple of 256) */
+    int32_t vocab;
+    int32_t max_pos;
+    int32_t txt_token_mean;   /* TXT_TOKEN_MODE == 'mean' */
+    int32_t cls_tokenize;     /* MODEL.HEAD.CLS_TOKENIZE */
+    int32_t offset_sigmoid;   /* MODEL.HEAD.OFFSET_SIGMOID */
+    int32_t joint_cls;        /* MODEL.HEAD.JOINT_CLS */
+    int32_t softmax_one;      /* MODEL.HEAD.SOFTMAX_ONE */
+    int32_t max_batch;        /* largest batch a forward call may carry */
+} uvl_config;
+
+/* Inputs of forward_test (uvltrack.py:41): device tensors, contiguous. */
+typedef struct uvl_inputs {
+    int32_t batch;
+    const float*   d_template;   /* [B,3,Hz,Hz] f32 NCHW, already mean/std normalised */
+    const float*   d_search;     /* [B,3,Hx,Hx] f32 */
+    const int64_t* d_text_ids;   /* [B,T] i64   (NestedTensor.tensors) */
+    const uint8_t* d_text_mask;  /* [B,T] u8/bool, 1 = real token (NestedTensor.mask) */
+    const float*   d_prompt;     /* [B,3,D] f32 */
+    const int64_t* d_flag;       /* [B] i64 in {0 BBOX, 1 NL, 2 NLBBOX} */
+    int32_t skip_text;           /* 1: all flags are 0 and the caller does not need `text`/`txt_token`:
+                                    run the visual stream only (exact for every box output) */
+} uvl_inputs;
+
+/* Output dict of forward_test: caller-allocated f32 device tensors.
+ * Any pointer may be NULL to skip that output. */
+typedef struct uvl_outputs {
+    float* d_search;        /* [B,S,D]   */
+    float* d_template;      /* [B,nz,D]  */
+    float* d_text;          /* [B,T,D]   */
+    float* d_vis_token;     /* [B,1,D]   */
+    float* d_txt_token;     /* [B,1,D]   */
+    float* d_logits;        /* [B,n_cont,F,F] */
+    float* d_cls_score;     /* [B,F,F]  (== cls_score_test unless joint_cls) */
+    float* d_cls_score_test;/* [B,F,F]   */
+    float* d_bbox_map;      /* [B,S,4]   */
+    float* d_pred_boxes;    /* [B,1,4]   */
+    float* d_cont_score;    /* [B,S,3] (softmax_one) or [B,S,2] */
+    int64_t* d_argmax;      /* [B] index of pred_boxes in bbox_map (extra, for tie-aware checks) */
+} uvl_outputs;
+
+typedef struct uvl_model uvl_model_t;
+
+const char* uvl_last_error(void);
+int  uvl_version(void);
+
+/* build_model(cfg) (uvltrack.py:47-57): create an empty model for a geometry. */
+uvl_model_t* uvl_create(const uvl_config* cfg);
+void uvl_destroy(uvl_model_t* m);
+
+/* load_state_dict (SURVEY.md 8b weight contract): hand one f32 tensor of the reference's state_dict
+ * to the library by its reference name.  `d_data` is a device pointer, dims are the tensor's shape.
+ * Tensors forward_test never reads (prompter.*, pooler.*, vit.norm.*, num_batches_tracked) are
+ * accepted and ignored (return 1).  Unknown names return UVL_ENOTFOUND (strict=False callers ignore it). */
+int uvl_load_tensor(uvl_model_t* m, const char* name, const float* d_data, int ndim, const int64_t* dims, void* stream);
+
+/* Pack everything for the kernels: bf16 GEMM weights, BERT q/k/v concatenation, BatchNorm folded into
+ * the conv towers (eval semantics, eps 1e-5), conv weights re-laid to [Cout][tap][Cin].
+ * Fails with UVL_ESTATE listing the first missing tensor. */
+int uvl_finalize_weights(uvl_model_t* m, void* stream);
+
+size_t uvl_workspace_bytes(const uvl_model_t* m, int batch);
+
+/* UVLTrack.forward_test (uvltrack.py:41-45).  Enqueues the whole frame on `stream`. */
+int uvl_forward_test(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out,
+                     void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* hipGraph replay of the same call: capture once for fixed pointers/batch, then launch per frame. */
+int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out,
+                      void* d_workspace, size_t workspace_bytes);
+int uvl_graph_launch(uvl_model_t* m, void* stream);
+int uvl_graph_release(uvl_model_t* m);
+
+/* Per-kernel timing of the last eager uvl_forward_test_profiled call: runs the frame with a HIP event
+ * pair around every launch (on the launching stream) and returns accumulated milliseconds per kernel
+ * family.  Families: 0 gemm, 1 attention, 2 layernorm, 3 conv, 4 other. */
+#define UVL_NFAM 5
+int uvl_forward_test_profiled(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out,
+                              void* d_workspace, size_t workspace_bytes, void* stream,
+                              float ms_per_family[UVL_NFAM], int launches_per_family[UVL_NFAM]);
+
+/* Per-launch-site breakdown of the last uvl_forward_test_profiled call: `name` = launch site
+ * ("gemm.fc1", "attention", ...), `kernel` = the kernel instantiation that ran, `flops`/`bytes` =
+ * algorithmic work summed over the site's launches. */
+int uvl_profile_count(const uvl_model_t* m);
+int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int name_cap,
+                      double* ms, double* flops, double* bytes, int* launches);
+
+/* Test hook.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
+ * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs. */
+int uvl_debug_set(uvl_model_t* m, const char* key, int value);
+
+/* ---- per-kernel entry points (used by the parity tests; same kernels the forward uses) ---------- */
+
+/* y = act(x W^T + b): nn.Linear (block.py:42,44; backbones/utils.py:58,61; bert_backbone.py:289-291,338,366,379).
+ * d_x [M,K] bf16 row-major, d_w [N,K] bf16 (nn.Linear layout), d_bias [N] f32 or NULL.
+ * act: 0 none, 1 erf-GELU, 2 ReLU.  out_f32 != 0: d_y is f32 [M,N] and `accumulate` adds into it
+ * (the residual add of block.py:30-31); otherwise d_y is bf16 [M,N].  K % 64 == 0, N % 64 == 0. */
+int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
+               int M, int N, int K, int act, int out_f32, int accumulate, void* stream);
+
+/* Fused multi-head self-attention core of Attention.forward (block.py:50-58) and BertSelfAttention
+ * (bert_backbone.py:311-324): softmax(q k^T / sqrt(64) + key_add) v.
+ * d_q, d_k: [B,H,Npad,64] bf16; d_vt: [B,H,64,Npad] bf16 (V transposed); d_key_add: [B,Npad] f32 additive
+ * per-key term (-1e10 reproduces masked_fill for |score| < 512, -10000 is BERT's mask); d_o: [B*N, H*64] bf16. */
+int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o,
+                  int B, int H, int N, int Npad, void* stream);
+
+/* QKV projection with the scatter epilogue the attention kernel consumes (block.py:49-50):
+ * d_x [B*N, D] bf16, d_w [3D, D] bf16, d_bias [3D] f32 -> q,k [B,H,Npad,64], vt [B,H,64,Npad]. */
+int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
+                    int B, int N, int Npad, int D, void* stream);
+
+/* nn.LayerNorm / BertLayerNorm over the last dim (block.py:30-31 eps 1e-6; bert_backbone.py:231-244 eps 1e-12).
+ * d_x [M,D] f32 -> d_y_bf16 [M,D] bf16 (may be NULL) and d_y_f32 [M,D] f32 (may be NULL, may alias d_x). */
+int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
+                  void* d_y_bf16, float* d_y_f32, int M, int D, void* stream);
+
+/* f32 -> bf16 (round to nearest even) helper for tests. */
+int uvl_f32_to_bf16(const float* d_in, void* d_out, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVLTRACK_HIP_H */

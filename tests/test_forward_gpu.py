@@ -1,0 +1,93 @@
+"""GPU parity of the whole HIP forward pass (through the C ABI) against the committed reference outputs
+and against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import list_cases, load_case, rebuild_inputs, rebuild_weights
+from tests.parity_util import compare_outputs, fmt_report
+
+pytestmark = pytest.mark.gpu
+
+_engines = {}
+
+
+def _engine(meta, spec):
+    from uvltrack_amd.engine import HipEngine
+    key = (meta["name"].split("_")[0], tuple(sorted(spec.to_dict().items(), key=str).__repr__()), meta["weight_seed"])
+    if key not in _engines:
+        _engines.clear()                       # one big model resident at a time
+        eng = HipEngine(spec, torch.device("cuda:0"), max_batch=8)
+        eng.load_state_dict(rebuild_weights(meta, spec))
+        _engines[key] = eng
+    return _engines[key]
+
+
+def _run(eng, inp, **kw):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]), **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
+
+
+@pytest.mark.parametrize("name", list_cases())
+def test_forward_matches_reference_fixture(name):
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    got = _run(_engine(meta, spec), inp)
+    ok, rep = compare_outputs(got, ref)
+    assert ok, "\n" + fmt_report(rep)
+
+
+def test_forward_matches_oracle_per_sample_batch1():
+    """Batch-1 calls (the tracker's shape) agree with the batched fixture run."""
+    meta, spec, ref = load_case("tiny_mixed")
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    for b in range(meta["batch"]):
+        one = {k: v[b:b + 1] for k, v in inp.items()}
+        got = _run(eng, one)
+        refb = {k: v[b:b + 1] for k, v in ref.items()}
+        ok, rep = compare_outputs(got, refb)
+        assert ok, "sample %d\n%s" % (b, fmt_report(rep))
+
+
+def test_graph_replay_equals_eager():
+    meta, spec, ref = load_case("tiny_mixed")
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    eager = _run(eng, inp)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    st, outs = eng.capture(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
+    for _ in range(3):
+        eng.replay()
+    torch.cuda.synchronize()
+    for k in ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "text"):
+        np.testing.assert_array_equal(outs[k].cpu().numpy(), eager[k])
+    # new inputs through the static buffers
+    st["search"].mul_(0.5)
+    eng.replay()
+    torch.cuda.synchronize()
+    assert np.abs(outs["bbox_map"].cpu().numpy() - eager["bbox_map"]).max() > 1e-4
+
+
+def test_skip_text_is_exact_for_box_outputs():
+    """BBOX-only mode may drop the text branch: every box output is bit-identical."""
+    meta, spec, _ = load_case("tiny_mixed")
+    inp = rebuild_inputs(meta, spec)
+    inp["flag"][:] = 0
+    eng = _engine(meta, spec)
+    full = _run(eng, inp)
+    skip = _run(eng, inp, skip_text=True)
+    for k in ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "template", "vis_token", "pred_boxes"):
+        np.testing.assert_array_equal(full[k], skip[k], err_msg=k)
+
+
+def test_cpu_tensors_fail_loudly():
+    from uvltrack_amd import _native
+    meta, spec, _ = load_case("tiny_mixed")
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    with pytest.raises(_native.NativeLibraryError):
+        eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))

@@ -1,0 +1,153 @@
+"""GPU parity of the individual HIP kernels against plain PyTorch fp32 references (through the C ABI)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from uvltrack_amd import _native
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _native.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda()
+
+
+def _chk(rc, lib):
+    assert rc == 0, lib.uvl_last_error().decode()
+
+
+@pytest.mark.parametrize("M,N,K", [(553, 2304, 768), (513, 768, 768), (40, 3072, 768), (321, 768, 3072),
+                                   (1, 64, 64), (65, 128, 128), (873, 1024, 4096), (4424, 3072, 768), (256, 32, 576)])
+@pytest.mark.parametrize("mode", ["bf16", "gelu", "relu", "f32", "f32_acc"])
+def test_linear(lib, M, N, K, mode):
+    x = _rand((M, K), 1).bfloat16()
+    # asymmetric weights: a transposed / permuted fragment layout cannot pass
+    w = (_rand((N, K), 2, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
+    b = _rand((N,), 3, 0.5)
+    ref = x.float() @ w.float().t() + b
+    if mode in ("bf16", "gelu", "relu"):
+        act = {"bf16": 0, "gelu": 1, "relu": 2}[mode]
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if act == 2:
+            ref = torch.relu(ref)
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, _stream()), lib)
+        torch.cuda.synchronize()
+        err = (y.float() - ref).abs()
+        tol = 1e-2 * ref.abs() + 2e-2
+        assert bool((err <= tol).all()), "max err %g" % float(err.max())
+    else:
+        acc = mode == "f32_acc"
+        y0 = _rand((M, N), 4) if acc else torch.full((M, N), float("nan"), device="cuda")
+        y = y0.clone()
+        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, 0, 1, int(acc), _stream()), lib)
+        torch.cuda.synchronize()
+        if acc:
+            ref = ref + y0
+        err = (y - ref).abs().max().item()
+        assert err < 2e-3, err
+
+
+@pytest.mark.parametrize("M,D", [(553, 768), (40, 768), (7, 128), (873, 1024), (1, 256)])
+def test_layernorm(lib, M, D):
+    x = _rand((M, D), 5, 3.0) + 1.5
+    g = _rand((D,), 6) * 0.2 + 1.0
+    b = _rand((D,), 7) * 0.1
+    for eps in (1e-6, 1e-12):
+        ref = torch.nn.functional.layer_norm(x, (D,), g, b, eps)
+        yb = torch.empty((M, D), dtype=torch.bfloat16, device="cuda")
+        yf = torch.empty((M, D), device="cuda")
+        _chk(lib.uvl_layernorm(_p(x), _p(g), _p(b), C.c_float(eps), _p(yb), _p(yf), M, D, _stream()), lib)
+        torch.cuda.synchronize()
+        assert (yf - ref).abs().max().item() < 2e-5
+        assert (yb.float() - ref).abs().max().item() < 3e-2
+
+
+def _attention_case(lib, B, H, N, mode, seed):
+    D = H * 64
+    Npad = (N + 63) // 64 * 64
+    x = _rand((B * N, D), seed).bfloat16()
+    w = _rand((3 * D, D), seed + 1, 1.0 / math.sqrt(D)).bfloat16()
+    bias = _rand((3 * D,), seed + 2, 0.2)
+    # poison the padded workspace: nothing beyond N may leak into the result
+    q = torch.full((B, H, Npad, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    k = torch.full_like(q, float("nan"))
+    vt = torch.full((B, H, 64, Npad), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _chk(lib.uvl_qkv_project(_p(x), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, N, Npad, D, _stream()), lib)
+    qkv = (x.float() @ w.float().t() + bias).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    torch.cuda.synchronize()
+    for got, ref in ((q[:, :, :N], qkv[0]), (k[:, :, :N], qkv[1]), (vt[:, :, :, :N].transpose(2, 3), qkv[2])):
+        err = (got.float() - ref).abs()
+        assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "qkv scatter max err %g" % float(err.max())
+    g = torch.Generator(device="cpu").manual_seed(seed + 3)
+    masked = (torch.rand((B, N), generator=g) < 0.3).cuda()
+    masked[:, N // 2] = False
+    add = torch.zeros((B, Npad), device="cuda")
+    if mode == "fill":
+        add[:, :N] = masked.float() * -1e10
+    elif mode == "bert":
+        add[:, :N] = masked.float() * -10000.0
+    elif mode == "bert_all":            # every key masked: BERT's additive mask keeps the score differences
+        add[:, :N] = -10000.0
+    add[:, N:] = float("nan")           # must be ignored
+    o = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, _stream()), lib)
+    torch.cuda.synchronize()
+    qf, kf, vf = q[:, :, :N].float(), k[:, :, :N].float(), vt[:, :, :, :N].transpose(2, 3).float()
+    s = (qf @ kf.transpose(-1, -2)) * 0.125
+    if mode == "fill":
+        s = s.masked_fill(masked[:, None, None, :], -1e10)
+    else:
+        s = s + add[:, None, None, :N]
+    ref = (s.softmax(-1) @ vf).transpose(1, 2).reshape(B * N, D)
+    err = (o.float() - ref).abs().max().item()
+    assert err < 3e-2, "attention max err %g (B=%d H=%d N=%d %s)" % (err, B, H, N, mode)
+
+
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 40, 64, 65, 321, 361, 513, 553, 681, 873])
+def test_attention_token_counts(lib, N):
+    _attention_case(lib, 1, 2, N, "fill", 10 + N)
+
+
+@pytest.mark.parametrize("mode", ["none", "fill", "bert", "bert_all"])
+@pytest.mark.parametrize("B,H,N", [(1, 12, 553), (3, 12, 40), (8, 16, 681), (2, 12, 321)])
+def test_attention_modes(lib, B, H, N, mode):
+    _attention_case(lib, B, H, N, mode, 77)
+
+
+def test_attention_spike_forces_rescale(lib):
+    """A late key with a huge score forces the online-softmax rescale branch (rare on random data)."""
+    B, H, N = 1, 1, 200
+    Npad = 256
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.zeros((B, H, Npad, 64), dtype=torch.bfloat16, device="cuda")
+    k = torch.zeros_like(q)
+    vt = torch.zeros((B, H, 64, Npad), dtype=torch.bfloat16, device="cuda")
+    q[:, :, :N] = torch.randn((B, H, N, 64), generator=g).cuda().bfloat16()
+    k[:, :, :N] = torch.randn((B, H, N, 64), generator=g).cuda().bfloat16()
+    vt[:, :, :, :N] = torch.randn((B, H, 64, N), generator=g).cuda().bfloat16()
+    k[0, 0, 150] = q[0, 0, 7] * 4.0            # key 150 (third tile) dominates query 7
+    add = torch.zeros((B, Npad), device="cuda")
+    o = torch.empty((B * N, 64), dtype=torch.bfloat16, device="cuda")
+    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, _stream()), lib)
+    torch.cuda.synchronize()
+    s = (q[:, :, :N].float() @ k[:, :, :N].float().transpose(-1, -2)) * 0.125
+    ref = (s.softmax(-1) @ vt[:, :, :, :N].transpose(2, 3).float()).reshape(N, 64)
+    assert (o.float() - ref).abs().max().item() < 3e-2

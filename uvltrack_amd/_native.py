@@ -1,0 +1,116 @@
+"""ctypes binding of include/uvltrack_hip.h (the C ABI of the gfx950 library).
+
+There is deliberately NO fallback: if the shared library is missing or a HIP device is absent the
+product path raises -- it never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libuvltrack_hip.so")
+
+UVL_MAX_LAYERS = 64
+UVL_NFAM = 5
+
+# every symbol include/uvltrack_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = [
+    "uvl_last_error", "uvl_version", "uvl_create", "uvl_destroy", "uvl_load_tensor", "uvl_finalize_weights",
+    "uvl_workspace_bytes", "uvl_forward_test", "uvl_graph_capture", "uvl_graph_launch", "uvl_graph_release",
+    "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_debug_set",
+    "uvl_linear", "uvl_attention", "uvl_qkv_project", "uvl_layernorm", "uvl_f32_to_bf16",
+]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class UvlConfig(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("heads", C.c_int32), ("depth", C.c_int32), ("n_fusion_start", C.c_int32),
+        ("n_cont", C.c_int32), ("cont_layers", C.c_int32 * UVL_MAX_LAYERS),
+        ("template_size", C.c_int32), ("search_size", C.c_int32), ("text_len", C.c_int32), ("head_dim", C.c_int32),
+        ("vocab", C.c_int32), ("max_pos", C.c_int32), ("txt_token_mean", C.c_int32), ("cls_tokenize", C.c_int32),
+        ("offset_sigmoid", C.c_int32), ("joint_cls", C.c_int32), ("softmax_one", C.c_int32), ("max_batch", C.c_int32),
+    ]
+
+
+class UvlInputs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32),
+        ("d_template", C.c_void_p), ("d_search", C.c_void_p), ("d_text_ids", C.c_void_p), ("d_text_mask", C.c_void_p),
+        ("d_prompt", C.c_void_p), ("d_flag", C.c_void_p), ("skip_text", C.c_int32),
+    ]
+
+
+class UvlOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "d_search", "d_template", "d_text", "d_vis_token", "d_txt_token", "d_logits", "d_cls_score", "d_cls_score_test",
+        "d_bbox_map", "d_pred_boxes", "d_cont_score", "d_argmax")]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (building is the job of uvltrack_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "HIP library %s is missing -- run `python -m uvltrack_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the product path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64p, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    lib.uvl_last_error.restype = C.c_char_p
+    lib.uvl_version.restype = C.c_int
+    lib.uvl_create.restype = vp
+    lib.uvl_create.argtypes = [C.POINTER(UvlConfig)]
+    lib.uvl_destroy.argtypes = [vp]
+    lib.uvl_destroy.restype = None
+    lib.uvl_load_tensor.argtypes = [vp, C.c_char_p, vp, i32, i64p, vp]
+    lib.uvl_finalize_weights.argtypes = [vp, vp]
+    lib.uvl_workspace_bytes.argtypes = [vp, i32]
+    lib.uvl_workspace_bytes.restype = C.c_size_t
+    lib.uvl_forward_test.argtypes = [vp, C.POINTER(UvlInputs), C.POINTER(UvlOutputs), vp, C.c_size_t, vp]
+    lib.uvl_graph_capture.argtypes = [vp, C.POINTER(UvlInputs), C.POINTER(UvlOutputs), vp, C.c_size_t]
+    lib.uvl_graph_launch.argtypes = [vp, vp]
+    lib.uvl_graph_release.argtypes = [vp]
+    lib.uvl_forward_test_profiled.argtypes = [vp, C.POINTER(UvlInputs), C.POINTER(UvlOutputs), vp, C.c_size_t, vp, f32p, C.POINTER(C.c_int)]
+    lib.uvl_profile_count.argtypes = [vp]
+    lib.uvl_profile_entry.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.uvl_debug_set.argtypes = [vp, C.c_char_p, i32]
+    lib.uvl_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.uvl_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.uvl_qkv_project.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.uvl_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, vp]
+    lib.uvl_f32_to_bf16.argtypes = [vp, vp, C.c_size_t, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "uvl call"):
+    if rc < 0:
+        raise NativeLibraryError("%s failed (%d): %s" % (what, rc, load().uvl_last_error().decode()))
+    return rc
+
+
+def config_from_spec(spec, max_batch: int = 64) -> UvlConfig:
+    c = UvlConfig()
+    c.dim, c.heads, c.depth = spec.dim, spec.heads, spec.depth
+    c.n_fusion_start = spec.n_bert
+    c.n_cont = len(spec.cont_layers)
+    for i, l in enumerate(spec.cont_layers):
+        c.cont_layers[i] = l
+    c.template_size, c.search_size = spec.template_size, spec.search_size
+    c.text_len, c.head_dim = spec.text_len, spec.head_dim
+    c.vocab, c.max_pos = spec.vocab, spec.max_pos
+    c.txt_token_mean = 1 if spec.txt_token_mode == "mean" else 0
+    c.cls_tokenize, c.offset_sigmoid = int(spec.cls_tokenize), int(spec.offset_sigmoid)
+    c.joint_cls, c.softmax_one = int(spec.joint_cls), int(spec.softmax_one)
+    c.max_batch = max_batch
+    return c

@@ -1,0 +1,62 @@
+"""Build the gfx950 shared library in-tree: uvltrack_amd/libuvltrack_hip.so.
+
+    python -m uvltrack_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the .so is git-ignored but travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libuvltrack_hip.so")
+SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "uvl_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "uvltrack_hip.h")]
+    return _newest(deps) > os.path.getmtime(LIB)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,50 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // 16-byte staging register (native vector: stays in VGPRs)
+
+#define WAVE 64
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)f; }          // RNE (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)h; }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    union { bf16_t h[2]; uint32_t u; } v;
+    v.h[0] = (bf16_t)lo;
+    v.h[1] = (bf16_t)hi;
+    return v.u;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact erf GELU: 0.5 x (1 + erf(x / sqrt(2)))  (nn.GELU default; bert_backbone.py:118-124)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// MFMA 32x32x16 bf16 C/D fragment: register r of lane l holds
+//   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// LDS tile of [rows][64] bf16 (128-byte rows) read by ds_read_b128 with lane = row: XOR the 16-byte
+// chunk index with (row>>1)&7 so the 16 lanes of one ds_read_b128 service group hit 16 distinct slots.
+__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Same tile read by ds_read_b64 with lane = row (32-lane service groups, 64 banks): XOR the 8-byte
+// chunk index (0..15) with (row>>1)&15.
+__device__ __forceinline__ int swz64(int row, int chunk8) { return row * 128 + ((chunk8 ^ ((row >> 1) & 15)) << 3); }

@@ -1,0 +1,98 @@
+// Host-visible launchers of the gfx950 kernels (internal to the library; the public ABI is include/uvltrack_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace uvl {
+
+// name of the kernel instantiation the last launcher picked (for per-kernel profiles)
+extern thread_local const char* g_last_kernel;
+
+struct GemmParams {
+    const bf16_t* A = nullptr; int lda = 0;      // [M,K] bf16 (plain) or NHWC activations (conv)
+    const bf16_t* W = nullptr; int ldw = 0;      // [groups*N, K] bf16, K-contiguous
+    const float* bias = nullptr;                 // [groups*N] or null
+    int M = 0, N = 0, K = 0;                     // per group
+    int epi = 0;                                 // EPI_BF16 / EPI_F32 / EPI_QKV
+    void* C = nullptr; int ldc = 0;              // output (bf16 or f32)
+    int act = 0;                                 // 0 none, 1 erf-GELU, 2 ReLU       (EPI_BF16)
+    int accumulate = 0;                          // C += ...                         (EPI_F32)
+    int rpb = 1 << 30, obs = 0, oro = 0;         // row m -> (b = m / rpb, t = m % rpb) -> output row b*obs + oro + t
+    const float* addtab = nullptr;               // [rpb, N] f32 added by t            (EPI_F32; pos-embed)
+    bf16_t *q = nullptr, *k = nullptr, *vt = nullptr; int H = 0, Npad = 0, D = 0;   // EPI_QKV
+    int groups = 1;
+    int conv_F = 0, cin_g = 0;                   // conv mode: feature-map side, input channels per group
+    int a_goff[4] = {0, 0, 0, 0};                // conv mode: channel offset of each group's input inside a row
+};
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+
+struct AttnParams {
+    const bf16_t *q = nullptr, *k = nullptr, *vt = nullptr;   // [B,H,Npad,64], [B,H,Npad,64], [B,H,64,Npad]
+    const float* key_add = nullptr; int key_add_stride = 0;   // [B, stride] additive per-key score term
+    bf16_t* o = nullptr;                                      // [B*N, H*64]
+    int B = 0, H = 0, N = 0, Npad = 0;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+
+struct LnParams {
+    const float* x = nullptr;                    // input rows, f32
+    int M = 0, D = 0;                            // compact row count
+    int rpb = 1 << 30, xbs = 0, xro = 0;         // compact row m -> x row (m/rpb)*xbs + xro + m%rpb
+    const float* pre_add0 = nullptr;             // optional vector added to rows with t <  split (then written back to x)
+    const float* pre_add1 = nullptr;             //                          rows with t >= split
+    int split = 0;
+    const float *gamma = nullptr, *beta = nullptr; float eps = 1e-6f;
+    bf16_t* y_bf16 = nullptr;                    // [M,D] compact, optional
+    float* y_f32 = nullptr; int y_remap = 0;     // optional f32 output; y_remap: same row map as x (in-place LN) else compact
+};
+hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
+
+// images -> bf16 patch rows [(b, z tokens..., x tokens...), 768] in (c,kh,kw) order (mae_vit.py:94-100)
+hipError_t launch_im2row(const float* z, const float* x, bf16_t* out, int B, int Hz, int Hx, hipStream_t s);
+
+// BertEmbeddings.forward + BertModel.embedding mask (bert_backbone.py:260-274,740-750)
+hipError_t launch_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                             const float* gamma, const float* beta, float* x, int xbs, int xro, bf16_t* y_bf16,
+                             int B, int T, int D, int vocab, hipStream_t s);
+
+// cat_mask (extractor.py:43-50) + cls-token rows: per-key additive terms and the [cls] row of the residual stream.
+hipError_t launch_setup(const uint8_t* text_mask, const int64_t* flag, const float* cls_token, float* x,
+                        float* key_add, float* bert_add, int B, int nz, int nv, int nj, int npad, int T, int D,
+                        int skip_text, hipStream_t s);
+
+// ModalityUnifiedFeatureExtractor.contractive_learning (extractor.py:85-93) for one layer.
+hipError_t launch_contrast(const float* x, int nj, int nz, int nx, int nv, int D, const uint8_t* text_mask, int T,
+                           int mean_mode, const int64_t* flag, const float* logit_scale, float* logits,
+                           int layer_slot, int n_cont, int B, int skip_text, hipStream_t s);
+
+// Head prologue: copy residual rows to the output dict, emit the bf16 NHWC conv input and cont_score (head:140-148).
+struct HeadPrepParams {
+    const float* x = nullptr; int nj = 0, nv = 0, nz = 0, nx = 0, T = 0, D = 0, B = 0;
+    const float* prompt = nullptr; const float* logit_scale = nullptr;
+    const uint8_t* text_mask = nullptr; const int64_t* flag = nullptr;
+    int softmax_one = 1, mean_mode = 0, cls_tokenize = 0, skip_text = 0;
+    bf16_t* g0 = nullptr; int g0_ld = 0;
+    float *o_search = nullptr, *o_template = nullptr, *o_text = nullptr, *o_vis = nullptr, *o_txt = nullptr, *o_cont = nullptr;
+};
+hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s);
+
+// Head tail: the four 1x1 convs + sigmoid + size select + convert2bbox + argmax (head:74-94,108-119).
+struct HeadTailParams {
+    const bf16_t* g4 = nullptr; int ld = 0, c8 = 0;          // [B*S, 4*c8] bf16 (towers cls, offset, bbox, bbox_grounding)
+    const float* w1 = nullptr; const float* b1 = nullptr;    // packed 1x1 weights [7, c8], bias [7]
+    const float* cont = nullptr; int cont_ch = 3;            // cont_score [B,S,cont_ch]
+    const int64_t* flag = nullptr; const float* coord = nullptr;   // coodinate buffer [2,S]
+    int B = 0, S = 0, F = 0, offset_sigmoid = 1, joint_cls = 0;
+    float *o_cls = nullptr, *o_cls_test = nullptr, *o_bbox_map = nullptr, *o_pred = nullptr; int64_t* o_argmax = nullptr;
+};
+hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s);
+
+// weight packing
+hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+// conv [Co,Ci,3,3] f32 + BN(eval) -> bf16 [Co][tap][Ci] and folded bias f32 [Co]
+hipError_t launch_fold_conv_bn(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
+                               const float* bn_var, bf16_t* w_out, float* b_out, int Co, int Ci, hipStream_t s);
+hipError_t launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s);
+
+}  // namespace uvl

@@ -1,0 +1,549 @@
+// Row-wise (HBM/L2-bound) kernels of the frame: LayerNorm, patch gather, BERT embedding, mask setup,
+// contrastive logits, head prologue/epilogue and the weight packers.  One wave64 per token row,
+// 16-byte vector loads, wave shuffles for the reductions.
+#include "common.h"
+#include "kernels.h"
+
+namespace uvl {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (block.py:30-31 with eps 1e-6; BertLayerNorm bert_backbone.py:231-244 with eps 1e-12).
+// Optionally adds a per-row-type vector first and writes it back: that is the permanent
+// `img_feat + modal_embed[0]`, `txt_feat + modal_embed[1]` of forward_joint (mae_vit.py:196).
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= p.M) return;
+    const int b = m / p.rpb, t = m - b * p.rpb;
+    const size_t xrow = (size_t)b * p.xbs + p.xro + t;
+    float* xr = const_cast<float*>(p.x) + xrow * p.D;
+    const float* padd = (t < p.split) ? p.pre_add0 : p.pre_add1;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < p.D) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            if (padd) {
+                const float4 a = *reinterpret_cast<const float4*>(padd + c);
+                v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+                *reinterpret_cast<float4*>(xr + c) = v[i];
+            }
+            sum += v[i].x + v[i].y + v[i].z + v[i].w;
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < p.D) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            sq += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    const size_t yrow = p.y_remap ? xrow : (size_t)m;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < p.D) {
+            const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+            const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * g.x + be.x;
+            y.y = (v[i].y - mean) * rstd * g.y + be.y;
+            y.z = (v[i].z - mean) * rstd * g.z + be.z;
+            y.w = (v[i].w - mean) * rstd * g.w + be.w;
+            if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + yrow * p.D + c) = y;
+            if (p.y_bf16) {
+                uint2 w;
+                w.x = pack_bf16x2(y.x, y.y);
+                w.y = pack_bf16x2(y.z, y.w);
+                *reinterpret_cast<uint2*>(p.y_bf16 + (size_t)m * p.D + c) = w;
+            }
+        }
+    }
+}
+
+hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
+    if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0) return hipErrorInvalidValue;
+    const int grid = (p.M + 3) / 4;
+    if (p.D <= 256) hipLaunchKernelGGL(ln_kernel<1>, dim3(grid), dim3(256), 0, s, p);
+    else if (p.D <= 768) hipLaunchKernelGGL(ln_kernel<3>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(ln_kernel<4>, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2row for PatchEmbed (mae_vit.py:94-100): Conv2d(3, D, k16, s16) == GEMM over (c,kh,kw) patch vectors.
+// One thread moves one 16-pixel patch line: 64 B of f32 in, 32 B of bf16 out.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2row_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                                                     bf16_t* __restrict__ out, int B, int Hz, int Hx) {
+    const int gz = Hz / 16, gx = Hx / 16, nz = gz * gz, nx = gx * gx, per = nz + nx;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * per * 48;
+    if (gid >= total) return;
+    const int line = gid % 48;                  // c*16 + kh
+    const long row = gid / 48;
+    const int c = line >> 4, kh = line & 15;
+    const int b = row / per, t = row - (long)b * per;
+    const float* src;
+    if (t < nz) {
+        const int i = t / gz, j = t - i * gz;
+        src = z + (((size_t)b * 3 + c) * Hz + i * 16 + kh) * Hz + j * 16;
+    } else {
+        const int tt = t - nz, i = tt / gx, j = tt - i * gx;
+        src = x + (((size_t)b * 3 + c) * Hx + i * 16 + kh) * Hx + j * 16;
+    }
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 f = *reinterpret_cast<const float4*>(src + 4 * q);
+        w[2 * q] = pack_bf16x2(f.x, f.y);
+        w[2 * q + 1] = pack_bf16x2(f.z, f.w);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)row * 768 + line * 16);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+hipError_t launch_im2row(const float* z, const float* x, bf16_t* out, int B, int Hz, int Hx, hipStream_t s) {
+    const long total = (long)B * ((Hz / 16) * (Hz / 16) + (Hx / 16) * (Hx / 16)) * 48;
+    hipLaunchKernelGGL(im2row_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, x, out, B, Hz, Hx);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// BERT embedding: word[ids] + position[t] + token_type[0] -> LayerNorm(eps 1e-12)
+// (bert_backbone.py:260-274).  Writes the f32 residual row and the bf16 GEMM operand.
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                         const float* __restrict__ pos, const float* __restrict__ type0,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ x, int xbs, int xro, bf16_t* __restrict__ y,
+                                                         int B, int T, int D, int vocab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= B * T) return;
+    const int b = m / T, t = m - b * T;
+    long id = ids[m];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* wr = word + (size_t)id * D;
+    const float* pr = pos + (size_t)t * D;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const float4 a = *reinterpret_cast<const float4*>(wr + c);
+            const float4 q = *reinterpret_cast<const float4*>(pr + c);
+            const float4 ty = *reinterpret_cast<const float4*>(type0 + c);
+            v[i] = make_float4(a.x + q.x + ty.x, a.y + q.y + ty.y, a.z + q.z + ty.z, a.w + q.w + ty.w);
+            sum += v[i].x + v[i].y + v[i].z + v[i].w;
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            sq += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-12f);
+    float* xr = x + ((size_t)b * xbs + xro + t) * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 be = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + be.x;
+            o.y = (v[i].y - mean) * rstd * g.y + be.y;
+            o.z = (v[i].z - mean) * rstd * g.z + be.z;
+            o.w = (v[i].w - mean) * rstd * g.w + be.w;
+            *reinterpret_cast<float4*>(xr + c) = o;
+            uint2 w;
+            w.x = pack_bf16x2(o.x, o.y);
+            w.y = pack_bf16x2(o.z, o.w);
+            *reinterpret_cast<uint2*>(y + (size_t)m * D + c) = w;
+        }
+    }
+}
+
+hipError_t launch_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                             const float* gamma, const float* beta, float* x, int xbs, int xro, bf16_t* y_bf16,
+                             int B, int T, int D, int vocab, hipStream_t s) {
+    if (D % 4 != 0 || D > 1024) return hipErrorInvalidValue;
+    const int grid = (B * T + 3) / 4;
+    if (D <= 256) hipLaunchKernelGGL(bert_embed_kernel<1>, dim3(grid), dim3(256), 0, s, ids, word, pos, type0, gamma, beta, x, xbs, xro, y_bf16, B, T, D, vocab);
+    else if (D <= 768) hipLaunchKernelGGL(bert_embed_kernel<3>, dim3(grid), dim3(256), 0, s, ids, word, pos, type0, gamma, beta, x, xbs, xro, y_bf16, B, T, D, vocab);
+    else hipLaunchKernelGGL(bert_embed_kernel<4>, dim3(grid), dim3(256), 0, s, ids, word, pos, type0, gamma, beta, x, xbs, xro, y_bf16, B, T, D, vocab);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// cat_mask (extractor.py:43-50) as additive per-key terms, BERT's extended mask (bert_backbone.py:745-747),
+// and the [cls] row of the residual stream (mae_vit.py:212-214).
+//   key i: 0 = cls, [1,1+nz) template, [1+nz,nv) search, [nv,nj) text
+//   flag==1 masks cls+template; search never; text where mask==0 or flag==0
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ tmask, const int64_t* __restrict__ flag,
+                                                    const float* __restrict__ cls_token, float* __restrict__ x,
+                                                    float* __restrict__ key_add, float* __restrict__ bert_add,
+                                                    int nz, int nv, int nj, int npad, int T, int D, int skip_text) {
+    const int b = blockIdx.x;
+    const int fl = (int)flag[b];
+    for (int i = threadIdx.x; i < npad; i += 256) {
+        float a;
+        if (i < 1 + nz) a = (fl == 1) ? -1e10f : 0.f;                 // cls + template keys
+        else if (i < nv) a = 0.f;                                     // search keys are never masked
+        else if (i < nj) a = (skip_text || fl == 0 || tmask[(size_t)b * T + (i - nv)] == 0) ? -1e10f : 0.f;
+        else a = -INFINITY;
+        key_add[(size_t)b * npad + i] = a;
+    }
+    if (!skip_text)
+        for (int t = threadIdx.x; t < 64; t += 256)
+            bert_add[(size_t)b * 64 + t] = (t < T) ? (tmask[(size_t)b * T + t] ? 0.f : -10000.f) : -INFINITY;
+    for (int c = threadIdx.x; c < D; c += 256) x[(size_t)b * nj * D + c] = cls_token[c];
+}
+
+hipError_t launch_setup(const uint8_t* text_mask, const int64_t* flag, const float* cls_token, float* x,
+                        float* key_add, float* bert_add, int B, int nz, int nv, int nj, int npad, int T, int D,
+                        int skip_text, hipStream_t s) {
+    hipLaunchKernelGGL(setup_kernel, dim3(B), dim3(256), 0, s, text_mask, flag, cls_token, x, key_add, bert_add, nz, nv, nj, npad, T, D, skip_text);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers: per-wave dot products over a D-vector
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_dot(const float* a, const float* b, int D, int lane) {
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(a + c);
+        const float4 y = *reinterpret_cast<const float4*>(b + c);
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    return wave_sum(s);
+}
+
+// txt token (generate_txt_token, extractor.py:79-83) into LDS: 'cls' = first text row, 'mean' = masked mean
+__device__ __forceinline__ void block_txt_token(float* dst, const float* xtext, const uint8_t* tm, int T, int D, int mean_mode) {
+    if (!mean_mode) {
+        for (int c = threadIdx.x; c < D; c += blockDim.x) dst[c] = xtext[c];
+    } else {
+        float cnt = 0.f;
+        for (int t = 0; t < T; ++t) cnt += tm[t] ? 1.f : 0.f;
+        for (int c = threadIdx.x; c < D; c += blockDim.x) {
+            float s = 0.f;
+            for (int t = 0; t < T; ++t) s += tm[t] ? xtext[(size_t)t * D + c] : 0.f;
+            dst[c] = s / cnt;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backbone contrastive logits for one layer (extractor.py:85-93):
+//   tau * normalize(x) . normalize(tok) for tok in {vis_token, txt_token}; select [vis, txt, mean][flag].
+// grid (ceil(nx/4), B), one wave per search token.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void contrast_kernel(const float* __restrict__ x, int nj, int nz, int nx, int nv, int D,
+                                                       const uint8_t* __restrict__ tmask, int T, int mean_mode,
+                                                       const int64_t* __restrict__ flag, const float* __restrict__ logit_scale,
+                                                       float* __restrict__ logits, int slot, int n_cont, int skip_text) {
+    extern __shared__ float sh[];              // [D] txt token
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xb = x + (size_t)b * nj * D;
+    const int fl = (int)flag[b];
+    if (!skip_text) block_txt_token(sh, xb + (size_t)nv * D, tmask + (size_t)b * T, T, D, mean_mode);
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= nx) return;
+    const float* xr = xb + (size_t)(1 + nz + s) * D;
+    const float* vt = xb;                      // vis token = row 0
+    const float tau = __expf(logit_scale[0]);
+    const float xx = fmaxf(sqrtf(wave_dot(xr, xr, D, lane)), 1e-12f);
+    float lt = 0.f;
+    const float vv = fmaxf(sqrtf(wave_dot(vt, vt, D, lane)), 1e-12f);
+    const float lv = tau * wave_dot(xr, vt, D, lane) / (xx * vv);
+    if (!skip_text) {
+        float tt = 0.f, xt = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + c);
+            const float4 q = *reinterpret_cast<const float4*>(sh + c);
+            tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+            xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+        }
+        tt = fmaxf(sqrtf(wave_sum(tt)), 1e-12f);
+        lt = tau * wave_sum(xt) / (xx * tt);
+    }
+    const float out = fl == 0 ? lv : (fl == 1 ? lt : 0.5f * (lv + lt));
+    if (lane == 0) logits[((size_t)b * n_cont + slot) * nx + s] = out;
+}
+
+hipError_t launch_contrast(const float* x, int nj, int nz, int nx, int nv, int D, const uint8_t* text_mask, int T,
+                           int mean_mode, const int64_t* flag, const float* logit_scale, float* logits,
+                           int layer_slot, int n_cont, int B, int skip_text, hipStream_t s) {
+    hipLaunchKernelGGL(contrast_kernel, dim3((nx + 3) / 4, B), dim3(256), D * sizeof(float), s, x, nj, nz, nx, nv, D,
+                       text_mask, T, mean_mode, flag, logit_scale, logits, layer_slot, n_cont, skip_text);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head prologue.  grid (ceil(nj/4), B): one wave per residual row.
+//   * copies the row into the output dict entry it belongs to (extractor.py:66-76)
+//   * search rows: bf16 NHWC conv input (the transpose/reshape of head:73 is free: tokens ARE NHWC),
+//     optionally a second copy scaled by the flag-selected token (CLS_TOKENIZE, head:64-69,74)
+//   * search rows: cont_score = tau * normalize(x) . normalize(prompt_k) with the SOFTMAX_ONE fold (head:140-148)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) {
+    extern __shared__ float sh[];              // [D] txt token, [D] cls-tokenize token
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = p.D;
+    const float* xb = p.x + (size_t)b * p.nj * D;
+    const int fl = (int)p.flag[b];
+    float* txt_tok = sh;
+    float* tok = sh + D;
+    const bool have_text = !p.skip_text;
+    if (have_text) block_txt_token(txt_tok, xb + (size_t)p.nv * D, p.text_mask + (size_t)b * p.T, p.T, D, p.mean_mode);
+    if (p.cls_tokenize) {
+        for (int c = threadIdx.x; c < D; c += 256) {
+            const float v = xb[c], t = have_text ? txt_tok[c] : 0.f;
+            tok[c] = fl == 0 ? v : (fl == 1 ? t : 0.5f * (v + t));
+        }
+        __syncthreads();
+    }
+    const int rows = have_text ? p.nj : p.nv;
+    const int r = blockIdx.x * 4 + wave;
+    if (r == 0 && have_text && p.o_txt && wave == 0) {
+        // txt_token output row (written by the wave that also owns the cls row of this batch)
+        for (int c = lane * 4; c < D; c += 256)
+            *reinterpret_cast<float4*>(p.o_txt + (size_t)b * D + c) = *reinterpret_cast<const float4*>(txt_tok + c);
+    }
+    if (r >= rows) return;
+    const float* xr = xb + (size_t)r * D;
+    float* dst = nullptr;
+    if (r == 0) dst = p.o_vis ? p.o_vis + (size_t)b * D : nullptr;
+    else if (r < 1 + p.nz) dst = p.o_template ? p.o_template + ((size_t)b * p.nz + (r - 1)) * D : nullptr;
+    else if (r < p.nv) dst = p.o_search ? p.o_search + ((size_t)b * p.nx + (r - 1 - p.nz)) * D : nullptr;
+    else dst = p.o_text ? p.o_text + ((size_t)b * p.T + (r - p.nv)) * D : nullptr;
+    const bool is_search = r >= 1 + p.nz && r < p.nv;
+    const int s = r - 1 - p.nz;
+    float xx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    const float* pr = p.prompt + (size_t)b * 3 * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + c);
+        if (dst) *reinterpret_cast<float4*>(dst + c) = a;
+        if (is_search) {
+            bf16_t* g = p.g0 + ((size_t)b * p.nx + s) * p.g0_ld;
+            uint2 w;
+            w.x = pack_bf16x2(a.x, a.y);
+            w.y = pack_bf16x2(a.z, a.w);
+            *reinterpret_cast<uint2*>(g + c) = w;
+            if (p.cls_tokenize) {
+                const float4 t = *reinterpret_cast<const float4*>(tok + c);
+                w.x = pack_bf16x2(a.x * t.x, a.y * t.y);
+                w.y = pack_bf16x2(a.z * t.z, a.w * t.w);
+                *reinterpret_cast<uint2*>(g + D + c) = w;
+            }
+            const float4 p0 = *reinterpret_cast<const float4*>(pr + c);
+            const float4 p1 = *reinterpret_cast<const float4*>(pr + D + c);
+            const float4 p2 = *reinterpret_cast<const float4*>(pr + 2 * D + c);
+            xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            d0 += a.x * p0.x + a.y * p0.y + a.z * p0.z + a.w * p0.w;
+            d1 += a.x * p1.x + a.y * p1.y + a.z * p1.z + a.w * p1.w;
+            d2 += a.x * p2.x + a.y * p2.y + a.z * p2.z + a.w * p2.w;
+            n0 += p0.x * p0.x + p0.y * p0.y + p0.z * p0.z + p0.w * p0.w;
+            n1 += p1.x * p1.x + p1.y * p1.y + p1.z * p1.z + p1.w * p1.w;
+            n2 += p2.x * p2.x + p2.y * p2.y + p2.z * p2.z + p2.w * p2.w;
+        }
+    }
+    if (is_search && p.o_cont) {
+        xx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
+        n0 = fmaxf(sqrtf(wave_sum(n0)), 1e-12f);
+        n1 = fmaxf(sqrtf(wave_sum(n1)), 1e-12f);
+        n2 = fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+        const float tau = __expf(p.logit_scale[0]);
+        const float c0 = tau * wave_sum(d0) / (xx * n0);
+        const float c1 = tau * wave_sum(d1) / (xx * n1);
+        const float c2 = tau * wave_sum(d2) / (xx * n2);
+        if (lane == 0) {
+            if (p.softmax_one) {
+                float* o = p.o_cont + ((size_t)b * p.nx + s) * 3;
+                o[0] = c0;
+                o[1] = fmaxf(fmaxf(c1, c2), 0.f);
+                o[2] = 0.f;
+            } else {
+                float* o = p.o_cont + ((size_t)b * p.nx + s) * 2;
+                o[0] = c0;
+                o[1] = fmaxf(c1, c2);
+            }
+        }
+    }
+}
+
+hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s) {
+    const int rows = p.skip_text ? p.nv : p.nj;
+    hipLaunchKernelGGL(head_prep_kernel, dim3((rows + 3) / 4, p.B), dim3(256), 2 * p.D * sizeof(float), s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head tail.  One workgroup per sample: the four 1x1 convs on the 32-channel tower outputs, sigmoids,
+// size-map select by flag (head:80-82), convert2bbox (head:108-119) and the argmax over S.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) {
+    extern __shared__ float shw[];              // [7*c8] weights, [8] bias
+    __shared__ float red_v[256];
+    __shared__ int red_i[256];
+    const int b = blockIdx.x, c8 = p.c8;
+    for (int i = threadIdx.x; i < 7 * c8; i += 256) shw[i] = p.w1[i];
+    if (threadIdx.x < 7) shw[7 * c8 + threadIdx.x] = p.b1[threadIdx.x];
+    __syncthreads();
+    const float* bias = shw + 7 * c8;
+    const int fl = (int)p.flag[b];
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int s = threadIdx.x; s < p.S; s += 256) {
+        const bf16_t* g = p.g4 + ((size_t)b * p.S + s) * p.ld;
+        float o[7];
+        // tower t reads channels [t*c8, (t+1)*c8); outputs: 0 cls | 1,2 offset | 3,4 bbox | 5,6 bbox_grounding
+        const int tower_of[7] = {0, 1, 1, 2, 2, 3, 3};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            float acc = bias[k];
+            const bf16_t* gt = g + tower_of[k] * c8;
+            for (int c = 0; c < c8; ++c) acc += bf2f(gt[c]) * shw[k * c8 + c];
+            o[k] = acc;
+        }
+        const float cls = sigmoidf_(o[0]);
+        const float ox = p.offset_sigmoid ? sigmoidf_(o[1]) : o[1];
+        const float oy = p.offset_sigmoid ? sigmoidf_(o[2]) : o[2];
+        const float w = fl == 1 ? sigmoidf_(o[5]) : sigmoidf_(o[3]);
+        const float h = fl == 1 ? sigmoidf_(o[6]) : sigmoidf_(o[4]);
+        const float* cs = p.cont + ((size_t)b * p.S + s) * p.cont_ch;
+        float mx = cs[0];
+        for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k]);
+        float den = 0.f;
+        for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k] - mx);
+        const float p0 = __expf(cs[0] - mx) / den;
+        const float score = cls * p0;
+        const size_t bs = (size_t)b * p.S + s;
+        if (p.o_cls_test) p.o_cls_test[bs] = cls;
+        if (p.o_cls) p.o_cls[bs] = p.joint_cls ? score : cls;
+        if (p.o_bbox_map) {
+            float4 bb;
+            bb.x = (p.coord[s] + ox) / (float)p.F;
+            bb.y = (p.coord[p.S + s] + oy) / (float)p.F;
+            bb.z = w;
+            bb.w = h;
+            *reinterpret_cast<float4*>(p.o_bbox_map + bs * 4) = bb;
+        }
+        if (score > best) { best = score; best_i = s; }
+    }
+    red_v[threadIdx.x] = best;
+    red_i[threadIdx.x] = best_i;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const float ov = red_v[threadIdx.x + st];
+            const int oi = red_i[threadIdx.x + st];
+            if (ov > red_v[threadIdx.x] || (ov == red_v[threadIdx.x] && oi < red_i[threadIdx.x])) {
+                red_v[threadIdx.x] = ov;
+                red_i[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    const int win = red_i[0] < p.S ? red_i[0] : 0;
+    if (threadIdx.x < 4 && p.o_pred && p.o_bbox_map) p.o_pred[(size_t)b * 4 + threadIdx.x] = p.o_bbox_map[((size_t)b * p.S + win) * 4 + threadIdx.x];
+    if (threadIdx.x == 0 && p.o_argmax) p.o_argmax[b] = win;
+}
+
+hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(head_tail_kernel, dim3(p.B), dim3(256), (7 * p.c8 + 8) * sizeof(float), s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        const float4 f = *reinterpret_cast<const float4*>(in + i);
+        uint2 w;
+        w.x = pack_bf16x2(f.x, f.y);
+        w.y = pack_bf16x2(f.z, f.w);
+        *reinterpret_cast<uint2*>(out + i) = w;
+    }
+    // tail (n % 4) handled by the first threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n & ~(size_t)3) + threadIdx.x] = f2bf(in[(n & ~(size_t)3) + threadIdx.x]);
+}
+hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void copy_f32_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+hipError_t launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+// conv3x3 [Co,Ci,3,3] + BatchNorm2d(eval, eps 1e-5) -> bf16 [Co][tap][Ci], bias' = (b - mean) * scale + beta
+// (heads/utils.py:126-131; eval semantics = running statistics).
+__global__ __launch_bounds__(256) void fold_conv_bn_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                           const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                           const float* __restrict__ bn_mean, const float* __restrict__ bn_var,
+                                                           bf16_t* __restrict__ w_out, float* __restrict__ b_out, int Co, int Ci) {
+    const size_t total = (size_t)Co * 9 * Ci;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < total; i += stride) {
+        const int ci = i % Ci;
+        const int tap = (i / Ci) % 9;
+        const int co = i / ((size_t)9 * Ci);
+        const float scale = bn_w[co] / sqrtf(bn_var[co] + 1e-5f);
+        w_out[i] = f2bf(w[((size_t)co * Ci + ci) * 9 + tap] * scale);
+        if (ci == 0 && tap == 0) b_out[co] = (b[co] - bn_mean[co]) * scale + bn_b[co];
+    }
+}
+hipError_t launch_fold_conv_bn(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
+                               const float* bn_var, bf16_t* w_out, float* b_out, int Co, int Ci, hipStream_t s) {
+    size_t blocks = ((size_t)Co * 9 * Ci + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fold_conv_bn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, b, bn_w, bn_b, bn_mean, bn_var, w_out, b_out, Co, Ci);
+    return hipGetLastError();
+}
+
+}  // namespace uvl

@@ -1,0 +1,733 @@
+// C ABI + host-side frame scheduler of the gfx950 UVLTrack forward pass (see include/uvltrack_hip.h).
+//
+// The frame is a fixed DAG of ~150 launches on two HIP streams (the BERT text branch runs beside the
+// visual ViT branch until the first fusion layer: extractor.py:57-65), with no host sync and no
+// allocation; uvl_graph_capture() records the same DAG into a hipGraph for replay.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/uvltrack_hip.h"
+#include "kernels.h"
+
+using namespace uvl;
+
+namespace uvl { thread_local const char* g_last_kernel = "?"; }
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return fail(UVL_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct RawTensor {
+    float* d = nullptr;
+    std::vector<int64_t> shape;
+    size_t numel = 0;
+};
+
+struct VitBlockW {
+    const float *ln1g, *ln1b, *ln2g, *ln2b, *bqkv, *bproj, *bfc1, *bfc2;
+    bf16_t *wqkv, *wproj, *wfc1, *wfc2;
+};
+struct BertLayerW {
+    const float *bao, *bi, *bo, *ln1g, *ln1b, *ln2g, *ln2b;
+    float* bqkv;
+    bf16_t *wqkv, *wao, *wi, *wo;
+};
+struct ConvLayerW {
+    bf16_t* w;      // [4][Cout][9*Cin]
+    float* b;       // [4*Cout]
+    int cin, cout;
+};
+
+struct ProfEntry {
+    std::string name, kernel;
+    double ms = 0, flops = 0, bytes = 0;
+    int launches = 0;
+};
+struct Profiler {
+    struct Rec { hipEvent_t a, b; const char* name; const char* kernel; double flops, bytes; };
+    std::vector<Rec> recs;
+};
+
+struct uvl_model {
+    uvl_config cfg;
+    int D, H, depth, nf, nz, nx, nv, nj, npad, T, F, S, C, ffn;
+    std::map<std::string, RawTensor> raw;
+    std::vector<void*> owned;           // packed allocations
+    bool finalized = false;
+    // packed
+    bf16_t* w_patch = nullptr; const float* b_patch = nullptr; float* pos_tab = nullptr;
+    const float *cls_token = nullptr, *modal = nullptr, *logit_scale_bb = nullptr, *logit_scale_head = nullptr, *coord = nullptr;
+    const float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    std::vector<VitBlockW> vit;
+    std::vector<BertLayerW> bert;
+    ConvLayerW conv[4];
+    float *w1 = nullptr, *b1 = nullptr;
+    // streams / events
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_bert;
+    // graph
+    hipStream_t cap_stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    // profile of the last profiled call
+    std::vector<ProfEntry> prof;
+    int debug_stop_layer = -1;          // >= 0: leave the layer loop after this layer (tests localise errors with it)
+};
+
+extern "C" const char* uvl_last_error(void) { return g_err; }
+extern "C" int uvl_version(void) { return 1; }
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
+    if (!c) { fail(UVL_EINVAL, "null config"); return nullptr; }
+    if (c->dim <= 0 || c->dim % 64 != 0 || c->dim > 1024) { fail(UVL_EINVAL, "dim %d must be a multiple of 64 and <= 1024", c->dim); return nullptr; }
+    if (c->heads <= 0 || c->dim != c->heads * 64) { fail(UVL_EINVAL, "dim/heads must be 64 (got %d/%d)", c->dim, c->heads); return nullptr; }
+    if (c->depth <= 0 || c->depth > UVL_MAX_LAYERS || c->n_fusion_start < 0 || c->n_fusion_start > c->depth) { fail(UVL_EINVAL, "bad depth/fusion"); return nullptr; }
+    if (c->template_size % 16 || c->search_size % 16 || c->template_size <= 0 || c->search_size <= 0) { fail(UVL_EINVAL, "image sizes must be multiples of 16"); return nullptr; }
+    if (c->text_len <= 0 || c->text_len > 64 || c->text_len > c->max_pos) { fail(UVL_EINVAL, "text_len must be in [1,64]"); return nullptr; }
+    if (c->head_dim <= 0 || c->head_dim % 256 != 0) { fail(UVL_EINVAL, "head_dim must be a multiple of 256"); return nullptr; }
+    if (c->n_cont < 0 || c->n_cont > UVL_MAX_LAYERS) { fail(UVL_EINVAL, "bad n_cont"); return nullptr; }
+    uvl_model* m = new uvl_model();
+    m->cfg = *c;
+    m->D = c->dim; m->H = c->heads; m->depth = c->depth; m->nf = c->n_fusion_start;
+    m->nz = (c->template_size / 16) * (c->template_size / 16);
+    m->F = c->search_size / 16;
+    m->nx = m->F * m->F; m->S = m->nx;
+    m->nv = 1 + m->nz + m->nx; m->T = c->text_len; m->nj = m->nv + m->T;
+    m->npad = (int)align_up(m->nj, 64);
+    m->C = c->head_dim; m->ffn = 4 * c->dim;
+    if (hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+        fail(UVL_EHIP, "stream/event creation failed (is a HIP device present?)");
+        delete m;
+        return nullptr;
+    }
+    m->ev_bert.resize(c->depth);
+    for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    return m;
+}
+
+extern "C" void uvl_destroy(uvl_model_t* m) {
+    if (!m) return;
+    hipDeviceSynchronize();
+    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) hipGraphDestroy(m->graph);
+    if (m->cap_stream) hipStreamDestroy(m->cap_stream);
+    for (auto& kv : m->raw) if (kv.second.d) hipFree(kv.second.d);
+    for (void* p : m->owned) hipFree(p);
+    for (auto& e : m->ev_bert) hipEventDestroy(e);
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
+    if (m->ev_join) hipEventDestroy(m->ev_join);
+    if (m->aux) hipStreamDestroy(m->aux);
+    delete m;
+}
+
+static bool name_is_ignored(const std::string& n) {
+    return n.find("box_head.prompter.") == 0 || n.find("backbone.bert.pooler.") == 0 || n.find("backbone.vit.norm.") == 0 ||
+           n.find("num_batches_tracked") != std::string::npos;
+}
+
+static bool name_is_known(const uvl_model* m, const std::string& n) {
+    static const char* fixed[] = {"backbone.logit_scale", "backbone.vit.cls_token", "backbone.vit.pos_embed_z", "backbone.vit.pos_embed_x",
+                                  "backbone.vit.modal_embed", "backbone.vit.patch_embed.proj.weight", "backbone.vit.patch_embed.proj.bias",
+                                  "backbone.bert.embeddings.word_embeddings.weight", "backbone.bert.embeddings.position_embeddings.weight",
+                                  "backbone.bert.embeddings.token_type_embeddings.weight", "backbone.bert.embeddings.LayerNorm.weight",
+                                  "backbone.bert.embeddings.LayerNorm.bias", "box_head.logit_scale", "box_head.coodinate"};
+    for (const char* f : fixed) if (n == f) return true;
+    if (n.find("backbone.vit.blocks.") == 0 || n.find("backbone.bert.encoder.layer.") == 0 || n.find("box_head.conv_") == 0) return true;
+    (void)m;
+    return false;
+}
+
+extern "C" int uvl_load_tensor(uvl_model_t* m, const char* name, const float* d_data, int ndim, const int64_t* dims, void* stream) {
+    if (!m || !name || !d_data || ndim < 0 || ndim > 8) return fail(UVL_EINVAL, "uvl_load_tensor: bad argument");
+    const std::string n(name);
+    if (name_is_ignored(n)) return 1;
+    if (!name_is_known(m, n)) return fail(UVL_ENOTFOUND, "unknown tensor '%s'", name);
+    // BERT layers beyond the ones that run are accepted and dropped (extractor.py:28 truncates the encoder)
+    if (n.find("backbone.bert.encoder.layer.") == 0) {
+        const int li = atoi(n.c_str() + strlen("backbone.bert.encoder.layer."));
+        if (li >= m->nf) return 1;
+    }
+    RawTensor& t = m->raw[n];
+    size_t numel = 1;
+    std::vector<int64_t> shape;
+    for (int i = 0; i < ndim; ++i) { numel *= (size_t)dims[i]; shape.push_back(dims[i]); }
+    if (t.d && t.numel != numel) { hipFree(t.d); t.d = nullptr; }
+    if (!t.d) HIPCHK(hipMalloc(&t.d, numel * sizeof(float) + 16));
+    t.shape = shape; t.numel = numel;
+    HIPCHK(hipMemcpyAsync(t.d, d_data, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    m->finalized = false;
+    return UVL_OK;
+}
+
+// ---- finalize helpers ---------------------------------------------------------------------------
+struct Packer {
+    uvl_model* m;
+    hipStream_t s;
+    int err = 0;
+    const RawTensor* get(const std::string& n, size_t numel) {
+        auto it = m->raw.find(n);
+        if (it == m->raw.end()) { if (!err) err = fail(UVL_ESTATE, "missing tensor '%s'", n.c_str()); return nullptr; }
+        if (it->second.numel != numel) { if (!err) err = fail(UVL_EINVAL, "tensor '%s' has %zu elements, expected %zu", n.c_str(), it->second.numel, numel); return nullptr; }
+        return &it->second;
+    }
+    const float* f32(const std::string& n, size_t numel) { const RawTensor* t = get(n, numel); return t ? t->d : nullptr; }
+    template <class T> T* alloc(size_t count) {
+        void* p = nullptr;
+        if (hipMalloc(&p, count * sizeof(T) + 256) != hipSuccess) { if (!err) err = fail(UVL_EHIP, "hipMalloc of %zu bytes failed", count * sizeof(T)); return nullptr; }
+        m->owned.push_back(p);
+        return (T*)p;
+    }
+    bf16_t* bf16(const std::string& n, size_t numel, bf16_t* dst = nullptr) {
+        const RawTensor* t = get(n, numel);
+        if (!t) return nullptr;
+        if (!dst) dst = alloc<bf16_t>(numel);
+        if (!dst) return nullptr;
+        if (launch_f32_to_bf16(t->d, dst, numel, s) != hipSuccess && !err) err = fail(UVL_EHIP, "f32->bf16 launch failed");
+        return dst;
+    }
+    void drop(const std::string& n) {   // free the f32 copy of a tensor that now lives packed
+        auto it = m->raw.find(n);
+        if (it != m->raw.end() && it->second.d) { hipFree(it->second.d); it->second.d = nullptr; m->raw.erase(it); }
+    }
+};
+
+extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
+    if (!m) return fail(UVL_EINVAL, "null model");
+    if (m->finalized) return UVL_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));
+    for (void* p : m->owned) hipFree(p);
+    m->owned.clear();
+    m->vit.clear(); m->bert.clear();
+    Packer P{m, s};
+    const size_t D = m->D, Fn = m->ffn;
+    const std::string v = "backbone.vit.";
+    m->logit_scale_bb = P.f32("backbone.logit_scale", 1);
+    m->cls_token = P.f32(v + "cls_token", D);
+    m->modal = P.f32(v + "modal_embed", 2 * D);
+    m->w_patch = P.bf16(v + "patch_embed.proj.weight", D * 768);
+    m->b_patch = P.f32(v + "patch_embed.proj.bias", D);
+    m->pos_tab = P.alloc<float>((size_t)(m->nz + m->nx) * D);
+    {
+        const float* pz = P.f32(v + "pos_embed_z", (size_t)m->nz * D);
+        const float* px = P.f32(v + "pos_embed_x", (size_t)m->nx * D);
+        if (pz && px && m->pos_tab) {
+            launch_copy_f32(pz, m->pos_tab, (size_t)m->nz * D, s);
+            launch_copy_f32(px, m->pos_tab + (size_t)m->nz * D, (size_t)m->nx * D, s);
+        }
+    }
+    for (int i = 0; i < m->depth; ++i) {
+        const std::string b = v + "blocks." + std::to_string(i) + ".";
+        VitBlockW w{};
+        w.ln1g = P.f32(b + "norm1.weight", D); w.ln1b = P.f32(b + "norm1.bias", D);
+        w.ln2g = P.f32(b + "norm2.weight", D); w.ln2b = P.f32(b + "norm2.bias", D);
+        w.wqkv = P.bf16(b + "attn.qkv.weight", 3 * D * D); w.bqkv = P.f32(b + "attn.qkv.bias", 3 * D);
+        w.wproj = P.bf16(b + "attn.proj.weight", D * D); w.bproj = P.f32(b + "attn.proj.bias", D);
+        w.wfc1 = P.bf16(b + "mlp.fc1.weight", Fn * D); w.bfc1 = P.f32(b + "mlp.fc1.bias", Fn);
+        w.wfc2 = P.bf16(b + "mlp.fc2.weight", D * Fn); w.bfc2 = P.f32(b + "mlp.fc2.bias", D);
+        m->vit.push_back(w);
+    }
+    const std::string e = "backbone.bert.embeddings.";
+    m->word = P.f32(e + "word_embeddings.weight", (size_t)m->cfg.vocab * D);
+    m->pos = P.f32(e + "position_embeddings.weight", (size_t)m->cfg.max_pos * D);
+    m->type0 = P.f32(e + "token_type_embeddings.weight", 2 * D);
+    m->emb_g = P.f32(e + "LayerNorm.weight", D); m->emb_b = P.f32(e + "LayerNorm.bias", D);
+    for (int i = 0; i < m->nf; ++i) {
+        const std::string b = "backbone.bert.encoder.layer." + std::to_string(i) + ".";
+        BertLayerW w{};
+        w.wqkv = P.alloc<bf16_t>(3 * D * D);
+        w.bqkv = P.alloc<float>(3 * D);
+        const char* nm[3] = {"query", "key", "value"};
+        for (int k = 0; k < 3; ++k) {
+            if (w.wqkv) P.bf16(b + "attention.self." + nm[k] + ".weight", D * D, w.wqkv + (size_t)k * D * D);
+            const float* bb = P.f32(b + "attention.self." + nm[k] + ".bias", D);
+            if (bb && w.bqkv) launch_copy_f32(bb, w.bqkv + (size_t)k * D, D, s);
+        }
+        w.wao = P.bf16(b + "attention.output.dense.weight", D * D); w.bao = P.f32(b + "attention.output.dense.bias", D);
+        w.ln1g = P.f32(b + "attention.output.LayerNorm.weight", D); w.ln1b = P.f32(b + "attention.output.LayerNorm.bias", D);
+        w.wi = P.bf16(b + "intermediate.dense.weight", Fn * D); w.bi = P.f32(b + "intermediate.dense.bias", Fn);
+        w.wo = P.bf16(b + "output.dense.weight", D * Fn); w.bo = P.f32(b + "output.dense.bias", D);
+        w.ln2g = P.f32(b + "output.LayerNorm.weight", D); w.ln2b = P.f32(b + "output.LayerNorm.bias", D);
+        m->bert.push_back(w);
+    }
+    // head: fold BN into the conv towers, tower-major packing
+    const char* towers[4] = {"conv_cls", "conv_offset", "conv_bbox", "conv_bbox_grounding"};
+    const int chans[5] = {m->D, m->C, m->C / 2, m->C / 4, m->C / 8};
+    for (int l = 0; l < 4; ++l) {
+        const int ci = chans[l], co = chans[l + 1];
+        ConvLayerW& cw = m->conv[l];
+        cw.cin = ci; cw.cout = co;
+        cw.w = P.alloc<bf16_t>((size_t)4 * co * 9 * ci);
+        cw.b = P.alloc<float>((size_t)4 * co);
+        for (int t = 0; t < 4; ++t) {
+            const std::string p = std::string("box_head.") + towers[t] + "." + std::to_string(l) + ".";
+            const float* w = P.f32(p + "0.weight", (size_t)co * ci * 9);
+            const float* b = P.f32(p + "0.bias", co);
+            const float* g = P.f32(p + "1.weight", co);
+            const float* be = P.f32(p + "1.bias", co);
+            const float* mu = P.f32(p + "1.running_mean", co);
+            const float* var = P.f32(p + "1.running_var", co);
+            if (w && b && g && be && mu && var && cw.w && cw.b)
+                launch_fold_conv_bn(w, b, g, be, mu, var, cw.w + (size_t)t * co * 9 * ci, cw.b + (size_t)t * co, co, ci, s);
+        }
+    }
+    const int c8 = m->C / 8;
+    m->w1 = P.alloc<float>(7 * c8);
+    m->b1 = P.alloc<float>(8);
+    {
+        const int rows[4] = {1, 2, 2, 2};
+        int off = 0;
+        for (int t = 0; t < 4; ++t) {
+            const std::string p = std::string("box_head.") + towers[t] + ".4.";
+            const float* w = P.f32(p + "weight", (size_t)rows[t] * c8);
+            const float* b = P.f32(p + "bias", rows[t]);
+            if (w && b && m->w1 && m->b1) {
+                launch_copy_f32(w, m->w1 + (size_t)off * c8, (size_t)rows[t] * c8, s);
+                launch_copy_f32(b, m->b1 + off, rows[t], s);
+            }
+            off += rows[t];
+        }
+    }
+    m->logit_scale_head = P.f32("box_head.logit_scale", 1);
+    m->coord = P.f32("box_head.coodinate", 2 * (size_t)m->S);
+    if (P.err) return P.err;
+    HIPCHK(hipStreamSynchronize(s));
+    // the f32 copies of the GEMM / conv weights are no longer needed
+    P.drop(v + "patch_embed.proj.weight");
+    for (int i = 0; i < m->depth; ++i) {
+        const std::string b = v + "blocks." + std::to_string(i) + ".";
+        P.drop(b + "attn.qkv.weight"); P.drop(b + "attn.proj.weight"); P.drop(b + "mlp.fc1.weight"); P.drop(b + "mlp.fc2.weight");
+    }
+    for (int i = 0; i < m->nf; ++i) {
+        const std::string b = "backbone.bert.encoder.layer." + std::to_string(i) + ".";
+        P.drop(b + "attention.self.query.weight"); P.drop(b + "attention.self.key.weight"); P.drop(b + "attention.self.value.weight");
+        P.drop(b + "attention.output.dense.weight"); P.drop(b + "intermediate.dense.weight"); P.drop(b + "output.dense.weight");
+    }
+    for (int l = 0; l < 4; ++l)
+        for (int t = 0; t < 4; ++t) P.drop(std::string("box_head.") + towers[t] + "." + std::to_string(l) + ".0.weight");
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    m->finalized = true;
+    return UVL_OK;
+}
+
+// ---- workspace ------------------------------------------------------------------------------------
+struct Workspace {
+    float* X; bf16_t *Xn, *Q, *K, *Vt, *O, *Hb, *P;
+    bf16_t *Tn, *Tq, *Tk, *Tvt, *To, *Th;
+    float *key_add, *bert_add, *cont, *bbox;
+    bf16_t *G0, *G1, *G2, *G3, *G4;
+    size_t total;
+};
+static Workspace carve(const uvl_model* m, int B, char* base) {
+    Workspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    const size_t D = m->D, nj = m->nj, H = m->H, npad = m->npad, T = m->T, S = m->S, C = m->C;
+    w.X = (float*)take(B * nj * D * 4);
+    w.Xn = (bf16_t*)take(B * nj * D * 2);
+    w.Q = (bf16_t*)take(B * H * npad * 64 * 2);
+    w.K = (bf16_t*)take(B * H * npad * 64 * 2);
+    w.Vt = (bf16_t*)take(B * H * npad * 64 * 2);
+    w.O = (bf16_t*)take(B * nj * D * 2);
+    w.Hb = (bf16_t*)take(B * nj * 4 * D * 2);
+    w.P = (bf16_t*)take(B * (size_t)(m->nz + m->nx) * 768 * 2);
+    w.Tn = (bf16_t*)take(B * T * D * 2);
+    w.Tq = (bf16_t*)take(B * H * 64 * 64 * 2);
+    w.Tk = (bf16_t*)take(B * H * 64 * 64 * 2);
+    w.Tvt = (bf16_t*)take(B * H * 64 * 64 * 2);
+    w.To = (bf16_t*)take(B * T * D * 2);
+    w.Th = (bf16_t*)take(B * T * 4 * D * 2);
+    w.key_add = (float*)take(B * npad * 4);
+    w.bert_add = (float*)take(B * 64 * 4);
+    w.cont = (float*)take(B * S * 3 * 4);
+    w.bbox = (float*)take(B * S * 4 * 4);
+    w.G0 = (bf16_t*)take(B * S * 2 * D * 2);
+    w.G1 = (bf16_t*)take(B * S * 4 * C * 2);
+    w.G2 = (bf16_t*)take(B * S * 2 * C * 2);
+    w.G3 = (bf16_t*)take(B * S * C * 2);
+    w.G4 = (bf16_t*)take(B * S * (C / 2) * 2);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t uvl_workspace_bytes(const uvl_model_t* m, int batch) {
+    if (!m || batch <= 0) return 0;
+    return carve(m, batch, nullptr).total;
+}
+
+// ---- the frame -----------------------------------------------------------------------------------
+struct Launcher {
+    Profiler* prof;
+    int err = 0;
+    void run(hipStream_t s, const char* what, double flops, double bytes, hipError_t (*fn)(void*, hipStream_t), void* ctx) {
+        if (err) return;
+        Profiler::Rec r{};
+        if (prof) {
+            hipEventCreate(&r.a); hipEventCreate(&r.b);
+            hipEventRecord(r.a, s);
+        }
+        g_last_kernel = what;
+        hipError_t e = fn(ctx, s);
+        if (e != hipSuccess) { err = fail(UVL_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e)); return; }
+        if (prof) {
+            hipEventRecord(r.b, s);
+            r.name = what; r.kernel = g_last_kernel; r.flops = flops; r.bytes = bytes;
+            prof->recs.push_back(r);
+        }
+    }
+};
+template <class P_, hipError_t (*F)(const P_&, hipStream_t)>
+static hipError_t tramp(void* ctx, hipStream_t s) { return F(*(const P_*)ctx, s); }
+
+#define RUN_GEMM(L, s, p, what) (L).run((s), (what), 2.0 * (p).M * (p).N * (p).K * ((p).groups > 0 ? (p).groups : 1), \
+    2.0 * ((double)(p).M * (p).K + (double)(p).N * (p).K * ((p).groups > 0 ? (p).groups : 1)), tramp<GemmParams, launch_gemm>, &(p))
+
+static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, hipStream_t s, Profiler* prof) {
+    if (!m || !in || !out) return fail(UVL_EINVAL, "null argument");
+    if (!m->finalized) return fail(UVL_ESTATE, "uvl_finalize_weights has not been called");
+    const int B = in->batch;
+    if (B <= 0 || B > m->cfg.max_batch) return fail(UVL_EINVAL, "batch %d outside [1, %d]", B, m->cfg.max_batch);
+    if (!in->d_template || !in->d_search || !in->d_prompt || !in->d_flag) return fail(UVL_EINVAL, "missing input pointer");
+    const int skip = in->skip_text ? 1 : 0;
+    if (!skip && (!in->d_text_ids || !in->d_text_mask)) return fail(UVL_EINVAL, "text inputs required unless skip_text");
+    const Workspace w = carve(m, B, (char*)d_ws);
+    if (!d_ws || ws_bytes < w.total) return fail(UVL_EINVAL, "workspace too small: %zu < %zu", ws_bytes, w.total);
+    if ((uintptr_t)d_ws % 256) return fail(UVL_EINVAL, "workspace must be 256-byte aligned");
+
+    const int D = m->D, H = m->H, nz = m->nz, nx = m->nx, nv = m->nv, nj = m->nj, npad = m->npad, T = m->T, Fn = m->ffn;
+    Launcher L{prof};
+    const bool fork = !skip && !prof && m->nf > 0;
+    hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
+
+    // -- setup: masks, cls rows
+    struct SetupCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B, skip; } sc{m, in, w, B, skip};
+    L.run(s, "setup", 0, 0, [](void* c, hipStream_t st) {
+        auto* x = (SetupCtx*)c;
+        return launch_setup(x->in->d_text_mask, x->in->d_flag, x->m->cls_token, x->w.X, x->w.key_add, x->w.bert_add, x->B,
+                            x->m->nz, x->m->nv, x->m->nj, x->m->npad, x->m->T, x->m->D, x->skip, st);
+    }, &sc);
+    if (fork) {
+        if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(sa, m->ev_fork, 0) != hipSuccess) return fail(UVL_EHIP, "fork failed");
+    }
+    // -- patch embed (mae_vit.py:203-215)
+    struct ImCtx { const uvl_inputs* in; Workspace w; int B, hz, hx; } ic{in, w, B, m->cfg.template_size, m->cfg.search_size};
+    L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
+    {
+        GemmParams p;
+        p.A = w.P; p.lda = 768; p.W = m->w_patch; p.ldw = 768; p.bias = m->b_patch;
+        p.M = B * (nz + nx); p.N = D; p.K = 768; p.epi = 1; p.C = w.X; p.ldc = D;
+        p.rpb = nz + nx; p.obs = nj; p.oro = 1; p.addtab = m->pos_tab;
+        RUN_GEMM(L, s, p, "gemm.patch");
+    }
+    // -- text embedding (bert_backbone.py:740-750)
+    if (!skip) {
+        struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
+        L.run(sa, "bert_embed", 0, 0, [](void* c, hipStream_t st) {
+            auto* x = (BeCtx*)c;
+            return launch_bert_embed(x->in->d_text_ids, x->m->word, x->m->pos, x->m->type0, x->m->emb_g, x->m->emb_b, x->w.X, x->m->nj, x->m->nv,
+                                     x->w.Tn, x->B, x->m->T, x->m->D, x->m->cfg.vocab, st);
+        }, &bc);
+    }
+
+    int cont_slot = 0;
+    for (int i = 0; i < m->depth; ++i) {
+        const bool joint = i >= m->nf;
+        const int N = (joint && !skip) ? nj : nv;
+        const int M = B * N;
+        const VitBlockW& vw = m->vit[i];
+        if (joint && i == m->nf && fork) {
+            if (hipEventRecord(m->ev_join, sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
+        }
+        // ---- ViT block (block.py:29-32) ----
+        {
+            LnParams p;
+            p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
+            if (joint) { p.pre_add0 = m->modal; p.pre_add1 = m->modal + D; p.split = nv; }     // forward_joint, mae_vit.py:196
+            p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
+            L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
+        }
+        {
+            GemmParams p;
+            p.A = w.Xn; p.lda = D; p.W = vw.wqkv; p.ldw = D; p.bias = vw.bqkv; p.M = M; p.N = 3 * D; p.K = D;
+            p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D;
+            RUN_GEMM(L, s, p, "gemm.qkv");
+        }
+        {
+            AttnParams p;
+            p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad;
+            L.run(s, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, tramp<AttnParams, launch_attention>, &p);
+        }
+        {
+            GemmParams p;
+            p.A = w.O; p.lda = D; p.W = vw.wproj; p.ldw = D; p.bias = vw.bproj; p.M = M; p.N = D; p.K = D;
+            p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = N; p.obs = nj; p.oro = 0;
+            RUN_GEMM(L, s, p, "gemm.proj");
+        }
+        {
+            LnParams p;
+            p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
+            p.gamma = vw.ln2g; p.beta = vw.ln2b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
+            L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
+        }
+        {
+            GemmParams p;
+            p.A = w.Xn; p.lda = D; p.W = vw.wfc1; p.ldw = D; p.bias = vw.bfc1; p.M = M; p.N = Fn; p.K = D;
+            p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
+            RUN_GEMM(L, s, p, "gemm.fc1");
+        }
+        {
+            GemmParams p;
+            p.A = w.Hb; p.lda = Fn; p.W = vw.wfc2; p.ldw = Fn; p.bias = vw.bfc2; p.M = M; p.N = D; p.K = Fn;
+            p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = N; p.obs = nj; p.oro = 0;
+            RUN_GEMM(L, s, p, "gemm.fc2");
+        }
+        // ---- BERT layer beside it (bert_backbone.py:390-394) ----
+        if (!joint && !skip) {
+            const BertLayerW& bw = m->bert[i];
+            const int Mt = B * T;
+            {
+                GemmParams p;
+                p.A = w.Tn; p.lda = D; p.W = bw.wqkv; p.ldw = D; p.bias = bw.bqkv; p.M = Mt; p.N = 3 * D; p.K = D;
+                p.epi = 2; p.rpb = T; p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.H = H; p.Npad = 64; p.D = D;
+                RUN_GEMM(L, sa, p, "gemm.bert_qkv");
+            }
+            {
+                AttnParams p;
+                p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64;
+                L.run(sa, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, tramp<AttnParams, launch_attention>, &p);
+            }
+            {
+                GemmParams p;
+                p.A = w.To; p.lda = D; p.W = bw.wao; p.ldw = D; p.bias = bw.bao; p.M = Mt; p.N = D; p.K = D;
+                p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = T; p.obs = nj; p.oro = nv;
+                RUN_GEMM(L, sa, p, "gemm.bert_ao");
+            }
+            {
+                LnParams p;        // post-LN in place on the text rows
+                p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
+                p.gamma = bw.ln1g; p.beta = bw.ln1b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
+                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
+            }
+            {
+                GemmParams p;
+                p.A = w.Tn; p.lda = D; p.W = bw.wi; p.ldw = D; p.bias = bw.bi; p.M = Mt; p.N = Fn; p.K = D;
+                p.epi = 0; p.C = w.Th; p.ldc = Fn; p.act = 1;
+                RUN_GEMM(L, sa, p, "gemm.bert_i");
+            }
+            {
+                GemmParams p;
+                p.A = w.Th; p.lda = Fn; p.W = bw.wo; p.ldw = Fn; p.bias = bw.bo; p.M = Mt; p.N = D; p.K = Fn;
+                p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = T; p.obs = nj; p.oro = nv;
+                RUN_GEMM(L, sa, p, "gemm.bert_o");
+            }
+            {
+                LnParams p;
+                p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
+                p.gamma = bw.ln2g; p.beta = bw.ln2b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
+                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
+            }
+        }
+        // ---- contrastive logits (extractor.py:64-65,85-93) ----
+        bool is_cont = false;
+        for (int k = 0; k < m->cfg.n_cont; ++k) is_cont |= (m->cfg.cont_layers[k] == i);
+        if (is_cont) {
+            if (out->d_logits) {
+                if (!joint && fork) {   // needs this layer's text stream
+                    if (hipEventRecord(m->ev_bert[i], sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_bert[i], 0) != hipSuccess) return fail(UVL_EHIP, "bert event failed");
+                }
+                struct CtCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; float* logits; int slot, B, skip; } cc{m, in, w, out->d_logits, cont_slot, B, skip};
+                L.run(s, "contrast", 0, 0, [](void* c, hipStream_t st) {
+                    auto* x = (CtCtx*)c;
+                    return launch_contrast(x->w.X, x->m->nj, x->m->nz, x->m->nx, x->m->nv, x->m->D, x->in->d_text_mask, x->m->T, x->m->cfg.txt_token_mean,
+                                           x->in->d_flag, x->m->logit_scale_bb, x->logits, x->slot, x->m->cfg.n_cont, x->B, x->skip, st);
+                }, &cc);
+            }
+            ++cont_slot;
+        }
+        if (m->debug_stop_layer == i) {
+            if (!joint && fork) {       // text branch must be joined before the head reads the residual stream
+                if (hipEventRecord(m->ev_join, sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
+            }
+            break;
+        }
+    }
+    if (m->nf >= m->depth && fork && m->debug_stop_layer < 0) {   // no fusion layer at all: still join the text branch
+        if (hipEventRecord(m->ev_join, sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
+    }
+
+    // ---- head (modality_adaptive_box_head.py:62-94) ----
+    const int S = m->S, C = m->C;
+    float* cont = out->d_cont_score ? out->d_cont_score : w.cont;
+    float* bbox = out->d_bbox_map ? out->d_bbox_map : w.bbox;
+    const int g0_ld = m->cfg.cls_tokenize ? 2 * D : D;
+    {
+        HeadPrepParams p;
+        p.x = w.X; p.nj = nj; p.nv = nv; p.nz = nz; p.nx = nx; p.T = T; p.D = D; p.B = B;
+        p.prompt = in->d_prompt; p.logit_scale = m->logit_scale_head; p.text_mask = in->d_text_mask; p.flag = in->d_flag;
+        p.softmax_one = m->cfg.softmax_one; p.mean_mode = m->cfg.txt_token_mean; p.cls_tokenize = m->cfg.cls_tokenize; p.skip_text = skip;
+        p.g0 = w.G0; p.g0_ld = g0_ld;
+        p.o_search = out->d_search; p.o_template = out->d_template; p.o_text = out->d_text; p.o_vis = out->d_vis_token; p.o_txt = out->d_txt_token;
+        p.o_cont = cont;
+        L.run(s, "head_prep", 0, 0, tramp<HeadPrepParams, launch_head_prep>, &p);
+    }
+    const bf16_t* cin[4] = {w.G0, w.G1, w.G2, w.G3};
+    bf16_t* cout[4] = {w.G1, w.G2, w.G3, w.G4};
+    const int in_ld[4] = {g0_ld, 4 * C, 2 * C, C};
+    for (int l = 0; l < 4; ++l) {
+        const ConvLayerW& cw = m->conv[l];
+        GemmParams p;
+        p.A = cin[l]; p.lda = in_ld[l]; p.W = cw.w; p.ldw = 9 * cw.cin; p.bias = cw.b;
+        p.M = B * S; p.N = cw.cout; p.K = 9 * cw.cin; p.epi = 0; p.C = cout[l]; p.ldc = 4 * cw.cout; p.act = 2;
+        p.groups = 4; p.conv_F = m->F; p.cin_g = cw.cin;
+        for (int g = 0; g < 4; ++g) p.a_goff[g] = (l == 0) ? ((g == 0 && m->cfg.cls_tokenize) ? D : 0) : g * cw.cin;
+        RUN_GEMM(L, s, p, "conv3x3");
+    }
+    {
+        HeadTailParams p;
+        p.g4 = w.G4; p.ld = C / 2; p.c8 = C / 8; p.w1 = m->w1; p.b1 = m->b1; p.cont = cont; p.cont_ch = m->cfg.softmax_one ? 3 : 2;
+        p.flag = in->d_flag; p.coord = m->coord; p.B = B; p.S = S; p.F = m->F; p.offset_sigmoid = m->cfg.offset_sigmoid; p.joint_cls = m->cfg.joint_cls;
+        p.o_cls = out->d_cls_score; p.o_cls_test = out->d_cls_score_test; p.o_bbox_map = bbox; p.o_pred = out->d_pred_boxes; p.o_argmax = out->d_argmax;
+        L.run(s, "head_tail", 0, 0, tramp<HeadTailParams, launch_head_tail>, &p);
+    }
+    return L.err;
+}
+
+extern "C" int uvl_forward_test(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, void* stream) {
+    return run_forward(m, in, out, d_ws, ws_bytes, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int uvl_forward_test_profiled(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, void* stream,
+                                         float ms_per_family[UVL_NFAM], int launches_per_family[UVL_NFAM]) {
+    Profiler prof;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = run_forward(m, in, out, d_ws, ws_bytes, s, &prof);
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(UVL_EHIP, "sync failed");
+    std::map<std::string, ProfEntry> agg;
+    if (ms_per_family) for (int i = 0; i < UVL_NFAM; ++i) { ms_per_family[i] = 0; if (launches_per_family) launches_per_family[i] = 0; }
+    for (auto& r : prof.recs) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        ProfEntry& e = agg[r.name];
+        e.name = r.name; e.kernel = r.kernel; e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
+        int fam = 4;
+        if (!strncmp(r.name, "gemm", 4)) fam = 0;
+        else if (!strncmp(r.name, "attention", 9)) fam = 1;
+        else if (!strncmp(r.name, "layernorm", 9)) fam = 2;
+        else if (!strncmp(r.name, "conv", 4)) fam = 3;
+        if (ms_per_family) ms_per_family[fam] += ms;
+        if (launches_per_family) launches_per_family[fam] += 1;
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    if (m) { m->prof.clear(); for (auto& kv : agg) m->prof.push_back(kv.second); }
+    return rc;
+}
+
+extern "C" int uvl_profile_count(const uvl_model_t* m) { return m ? (int)m->prof.size() : 0; }
+extern "C" int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int name_cap, double* ms, double* flops, double* bytes, int* launches) {
+    if (!m || i < 0 || i >= (int)m->prof.size()) return fail(UVL_EINVAL, "bad profile index");
+    const ProfEntry& e = m->prof[i];
+    if (name && name_cap > 0) { strncpy(name, e.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (kernel && name_cap > 0) { strncpy(kernel, e.kernel.c_str(), name_cap - 1); kernel[name_cap - 1] = 0; }
+    if (ms) *ms = e.ms; if (flops) *flops = e.flops; if (bytes) *bytes = e.bytes; if (launches) *launches = e.launches;
+    return UVL_OK;
+}
+
+extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
+    if (!m || !key) return fail(UVL_EINVAL, "null argument");
+    if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
+    return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
+}
+
+// ---- hipGraph --------------------------------------------------------------------------------------
+extern "C" int uvl_graph_release(uvl_model_t* m) {
+    if (!m) return fail(UVL_EINVAL, "null model");
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+    return UVL_OK;
+}
+
+extern "C" int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes) {
+    if (!m) return fail(UVL_EINVAL, "null model");
+    uvl_graph_release(m);
+    if (!m->cap_stream) HIPCHK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+    int rc = run_forward(m, in, out, d_ws, ws_bytes, m->cap_stream, nullptr);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(UVL_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    m->graph = g;
+    HIPCHK(hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0));
+    return UVL_OK;
+}
+
+extern "C" int uvl_graph_launch(uvl_model_t* m, void* stream) {
+    if (!m || !m->graph_exec) return fail(UVL_ESTATE, "no captured graph");
+    HIPCHK(hipGraphLaunch(m->graph_exec, (hipStream_t)stream));
+    return UVL_OK;
+}
+
+// ---- per-kernel entry points -----------------------------------------------------------------------
+extern "C" int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
+                          int accumulate, void* stream) {
+    if (!d_x || !d_w || !d_y || M <= 0 || N % 32 != 0 || K % 64 != 0) return fail(UVL_EINVAL, "uvl_linear: need N %% 32 == 0 and K %% 64 == 0");
+    GemmParams p;
+    p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
+    p.epi = out_f32 ? 1 : 0; p.C = d_y; p.ldc = N; p.act = act; p.accumulate = accumulate;
+    HIPCHK(launch_gemm(p, (hipStream_t)stream));
+    return UVL_OK;
+}
+
+extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o, int B, int H, int N, int Npad, void* stream) {
+    if (!d_q || !d_k || !d_vt || !d_key_add || !d_o) return fail(UVL_EINVAL, "uvl_attention: null pointer");
+    AttnParams p;
+    p.q = (const bf16_t*)d_q; p.k = (const bf16_t*)d_k; p.vt = (const bf16_t*)d_vt; p.key_add = d_key_add; p.key_add_stride = Npad;
+    p.o = (bf16_t*)d_o; p.B = B; p.H = H; p.N = N; p.Npad = Npad;
+    HIPCHK(launch_attention(p, (hipStream_t)stream));
+    return UVL_OK;
+}
+
+extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, void* stream) {
+    if (!d_x || !d_w || !d_q || !d_k || !d_vt || D % 64 != 0) return fail(UVL_EINVAL, "uvl_qkv_project: bad argument");
+    GemmParams p;
+    p.A = (const bf16_t*)d_x; p.lda = D; p.W = (const bf16_t*)d_w; p.ldw = D; p.bias = d_bias; p.M = B * N; p.N = 3 * D; p.K = D;
+    p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D;
+    HIPCHK(launch_gemm(p, (hipStream_t)stream));
+    return UVL_OK;
+}
+
+extern "C" int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps, void* d_y_bf16, float* d_y_f32, int M, int D, void* stream) {
+    if (!d_x || !d_gamma || !d_beta) return fail(UVL_EINVAL, "uvl_layernorm: null pointer");
+    LnParams p;
+    p.x = d_x; p.M = M; p.D = D; p.gamma = d_gamma; p.beta = d_beta; p.eps = eps; p.y_bf16 = (bf16_t*)d_y_bf16; p.y_f32 = d_y_f32;
+    HIPCHK(launch_layernorm(p, (hipStream_t)stream));
+    return UVL_OK;
+}
+
+extern "C" int uvl_f32_to_bf16(const float* d_in, void* d_out, size_t n, void* stream) {
+    HIPCHK(launch_f32_to_bf16(d_in, (bf16_t*)d_out, n, (hipStream_t)stream));
+    return UVL_OK;
+}

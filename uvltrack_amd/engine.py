@@ -1,0 +1,218 @@
+"""Host side of the HIP forward pass: owns the native model handle, the activation workspace and
+(optionally) a captured hipGraph.  PyTorch is used only for device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native
+from .spec import ModelSpec
+
+OUT_SHAPES = {
+    "search": lambda s, B: (B, s.nx, s.dim), "template": lambda s, B: (B, s.nz, s.dim),
+    "text": lambda s, B: (B, s.text_len, s.dim), "vis_token": lambda s, B: (B, 1, s.dim),
+    "txt_token": lambda s, B: (B, 1, s.dim),
+    "logits": lambda s, B: (B, len(s.cont_layers), s.feat_sz, s.feat_sz),
+    "cls_score": lambda s, B: (B, s.feat_sz, s.feat_sz), "cls_score_test": lambda s, B: (B, s.feat_sz, s.feat_sz),
+    "bbox_map": lambda s, B: (B, s.nx, 4), "pred_boxes": lambda s, B: (B, 1, 4),
+    "cont_score": lambda s, B: (B, s.nx, 3 if s.softmax_one else 2),
+}
+_OUT_FIELD = {"search": "d_search", "template": "d_template", "text": "d_text", "vis_token": "d_vis_token",
+              "txt_token": "d_txt_token", "logits": "d_logits", "cls_score": "d_cls_score",
+              "cls_score_test": "d_cls_score_test", "bbox_map": "d_bbox_map", "pred_boxes": "d_pred_boxes",
+              "cont_score": "d_cont_score"}
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _native.NativeLibraryError(
+            "%s is on %s: the UVLTrack forward pass runs only on a HIP device (no CPU fallback)" % (what, t.device))
+
+
+class HipEngine:
+    """One native model per (device, process).  Not thread-safe (same contract as an nn.Module)."""
+
+    def __init__(self, spec: ModelSpec, device: torch.device, max_batch: int = 64):
+        spec.validate()
+        self.spec = spec
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _native.NativeLibraryError("HipEngine needs a HIP device, got %s" % device)
+        self.lib = _native.load()
+        self.max_batch = max_batch
+        with torch.cuda.device(self.device):
+            cfg = _native.config_from_spec(spec, max_batch)
+            self.handle = self.lib.uvl_create(C.byref(cfg))
+        if not self.handle:
+            raise _native.NativeLibraryError("uvl_create failed: %s" % self.lib.uvl_last_error().decode())
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+        self._graph_io = None
+        self.weights_loaded = False
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.uvl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_state_dict(self, sd: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = False):
+        """Upload a reference-format state_dict (names of SURVEY.md section 8b) and pack it."""
+        unknown = []
+        with torch.cuda.device(self.device):
+            for name, t in sd.items():
+                if isinstance(t, np.ndarray):
+                    t = torch.from_numpy(np.ascontiguousarray(t))
+                if not t.dtype.is_floating_point:
+                    continue                                   # num_batches_tracked
+                t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+                dims = (C.c_int64 * max(1, t.dim()))(*t.shape)
+                rc = self.lib.uvl_load_tensor(self.handle, name.encode(), C.c_void_p(t.data_ptr()), t.dim(), dims, self._stream())
+                if rc == -4:
+                    unknown.append(name)
+                else:
+                    _native.check(rc, "uvl_load_tensor(%s)" % name)
+                # the D2D copy is enqueued on the current stream; torch's allocator is stream-ordered, so a
+                # temporary `t` cannot be recycled before the copy has run
+            torch.cuda.current_stream(self.device).synchronize()
+            if strict and unknown:
+                raise KeyError("unexpected tensors: %s" % unknown[:5])
+            _native.check(self.lib.uvl_finalize_weights(self.handle, self._stream()), "uvl_finalize_weights")
+        self.weights_loaded = True
+        self._graph_io = None
+        return unknown
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, B: int) -> torch.Tensor:
+        if self._ws is None or self._ws_batch < B:
+            n = self.lib.uvl_workspace_bytes(self.handle, B)
+            self._ws = torch.empty(n + 256, dtype=torch.uint8, device=self.device)
+            self._ws_batch = B
+            self._graph_io = None
+        return self._ws
+
+    def _ws_ptr(self, ws):
+        p = ws.data_ptr()
+        return (p + 255) // 256 * 256
+
+    def alloc_outputs(self, B: int, want=None) -> Dict[str, torch.Tensor]:
+        names = want if want is not None else list(OUT_SHAPES)
+        outs = {k: torch.empty(OUT_SHAPES[k](self.spec, B), dtype=torch.float32, device=self.device) for k in names}
+        outs["argmax"] = torch.empty(B, dtype=torch.int64, device=self.device)
+        return outs
+
+    def _pack_io(self, template, search, ids, mask, prompt, flag, outs, skip_text):
+        B = search.shape[0]
+        i = _native.UvlInputs()
+        i.batch = B
+        i.d_template, i.d_search = template.data_ptr(), search.data_ptr()
+        i.d_text_ids = ids.data_ptr() if ids is not None else None
+        i.d_text_mask = mask.data_ptr() if mask is not None else None
+        i.d_prompt, i.d_flag = prompt.data_ptr(), flag.data_ptr()
+        i.skip_text = 1 if skip_text else 0
+        o = _native.UvlOutputs()
+        for k, f in _OUT_FIELD.items():
+            setattr(o, f, outs[k].data_ptr() if k in outs else None)
+        o.d_argmax = outs["argmax"].data_ptr() if "argmax" in outs else None
+        return i, o
+
+    def _canon_inputs(self, template, search, ids, mask, prompt, flag):
+        s = self.spec
+        for t, w in ((template, "template"), (search, "search"), (prompt, "prompt"), (flag, "flag")):
+            _require_cuda(t, w)
+        B = search.shape[0]
+        if tuple(template.shape) != (B, 3, s.template_size, s.template_size) or tuple(search.shape) != (B, 3, s.search_size, s.search_size):
+            raise ValueError("image shapes %s / %s do not match the model geometry (%d / %d)" %
+                             (tuple(template.shape), tuple(search.shape), s.template_size, s.search_size))
+        template = template.to(torch.float32).contiguous()
+        search = search.to(torch.float32).contiguous()
+        prompt = prompt.to(torch.float32).contiguous()
+        if tuple(prompt.shape) != (B, 3, s.dim):
+            raise ValueError("prompt must be [B,3,%d]" % s.dim)
+        flag = flag.reshape(-1).to(torch.int64).contiguous()
+        if flag.numel() != B:
+            raise ValueError("flag must carry one entry per sample")
+        if ids is not None:
+            _require_cuda(ids, "text.tensors")
+            ids = ids.to(torch.int64).contiguous()
+            mask = (mask != 0).to(torch.uint8).contiguous()
+            if tuple(ids.shape) != (B, s.text_len) or tuple(mask.shape) != (B, s.text_len):
+                raise ValueError("text must be [B,%d]" % s.text_len)
+        return template, search, ids, mask, prompt, flag
+
+    def forward(self, template, search, ids, mask, prompt, flag, skip_text: bool = False, outs=None, profile: bool = False):
+        """UVLTrack.forward_test on device tensors; returns the output dict (f32 device tensors)."""
+        if not self.weights_loaded:
+            raise _native.NativeLibraryError("weights have not been loaded")
+        template, search, ids, mask, prompt, flag = self._canon_inputs(template, search, ids, mask, prompt, flag)
+        B = search.shape[0]
+        if B > self.max_batch:
+            raise ValueError("batch %d exceeds max_batch %d" % (B, self.max_batch))
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B)
+            if outs is None:
+                outs = self.alloc_outputs(B)
+            i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text)
+            n = self.lib.uvl_workspace_bytes(self.handle, B)
+            if profile:
+                ms = (C.c_float * _native.UVL_NFAM)()
+                cnt = (C.c_int * _native.UVL_NFAM)()
+                _native.check(self.lib.uvl_forward_test_profiled(self.handle, C.byref(i), C.byref(o), C.c_void_p(self._ws_ptr(ws)), n,
+                                                                 self._stream(), ms, cnt), "uvl_forward_test_profiled")
+            else:
+                _native.check(self.lib.uvl_forward_test(self.handle, C.byref(i), C.byref(o), C.c_void_p(self._ws_ptr(ws)), n, self._stream()),
+                              "uvl_forward_test")
+        outs["flag"] = flag
+        outs["prompt"] = prompt
+        outs["prompts"] = prompt
+        self._keep = (template, search, ids, mask)      # inputs must outlive the asynchronous launches
+        return outs
+
+    def profile_entries(self):
+        """Per-launch-site breakdown of the last profile=True forward."""
+        n = self.lib.uvl_profile_count(self.handle)
+        res = []
+        for k in range(n):
+            name = C.create_string_buffer(96)
+            kern = C.create_string_buffer(96)
+            ms, fl, by, ln = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            _native.check(self.lib.uvl_profile_entry(self.handle, k, name, kern, 96, C.byref(ms), C.byref(fl), C.byref(by), C.byref(ln)))
+            res.append(dict(site=name.value.decode(), kernel=kern.value.decode(), ms=ms.value, flops=fl.value, bytes=by.value, launches=ln.value))
+        return res
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def capture(self, template, search, ids, mask, prompt, flag, skip_text: bool = False):
+        """Record the frame into a hipGraph bound to private copies of the inputs; returns (static_inputs, outputs)."""
+        template, search, ids, mask, prompt, flag = self._canon_inputs(template, search, ids, mask, prompt, flag)
+        B = search.shape[0]
+        with torch.cuda.device(self.device):
+            st = dict(template=template.clone(), search=search.clone(), ids=None if ids is None else ids.clone(),
+                      mask=None if mask is None else mask.clone(), prompt=prompt.clone(), flag=flag.clone())
+            outs = self.alloc_outputs(B)
+            ws = self._workspace(B)
+            i, o = self._pack_io(st["template"], st["search"], st["ids"], st["mask"], st["prompt"], st["flag"], outs, skip_text)
+            n = self.lib.uvl_workspace_bytes(self.handle, B)
+            torch.cuda.synchronize(self.device)
+            _native.check(self.lib.uvl_graph_capture(self.handle, C.byref(i), C.byref(o), C.c_void_p(self._ws_ptr(ws)), n), "uvl_graph_capture")
+        outs["flag"], outs["prompt"], outs["prompts"] = st["flag"], st["prompt"], st["prompt"]
+        self._graph_io = (st, outs)
+        return st, outs
+
+    def replay(self):
+        if self._graph_io is None:
+            raise _native.NativeLibraryError("no captured graph")
+        _native.check(self.lib.uvl_graph_launch(self.handle, self._stream()), "uvl_graph_launch")
+        return self._graph_io[1]

@@ -130,9 +130,10 @@ def spec_l(template_size=128, search_size=256, **kw) -> ModelSpec:
 
 
 def spec_tiny(**kw) -> ModelSpec:
-    """The small golden-fixture model of SURVEY.md §8c (D=128, hd=64, depth 4)."""
+    """The small golden-fixture model of SURVEY.md §8c (D=128, hd=64, depth 4; head width 256 because the
+    implicit-GEMM conv towers need every tower width to be a multiple of the 64-channel K chunk)."""
     base = dict(dim=128, heads=2, depth=4, fusion_layers=[2, 3], cont_layers=[1, 2, 3],
-                template_size=32, search_size=64, text_len=8, head_dim=32, vocab=64,
+                template_size=32, search_size=64, text_len=8, head_dim=256, vocab=64,
                 max_pos=32, bert_total_layers=4)
     base.update(kw)
     return ModelSpec(**base)
