@@ -84,6 +84,7 @@ def _purge_lib_modules():
 def build_reference_model(spec):
     """Return (model.eval(), cfg) of the real reference for a ModelSpec."""
     import torch
+    sys.dont_write_bytecode = True          # never write __pycache__ into the read-only reference tree
     _install_stubs()
     _purge_lib_modules()
     sys.path.insert(0, REF_ROOT)

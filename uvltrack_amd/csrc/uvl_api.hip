@@ -82,7 +82,7 @@ struct uvl_model {
     // streams / events
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_bert;
+    std::vector<hipEvent_t> ev_bert, ev_cont;
     // graph
     hipStream_t cap_stream = nullptr;
     hipGraph_t graph = nullptr;
@@ -123,7 +123,9 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
         return nullptr;
     }
     m->ev_bert.resize(c->depth);
+    m->ev_cont.resize(c->depth);
     for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    for (auto& e : m->ev_cont) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     return m;
 }
 
@@ -136,6 +138,7 @@ extern "C" void uvl_destroy(uvl_model_t* m) {
     for (auto& kv : m->raw) if (kv.second.d) hipFree(kv.second.d);
     for (void* p : m->owned) hipFree(p);
     for (auto& e : m->ev_bert) hipEventDestroy(e);
+    for (auto& e : m->ev_cont) hipEventDestroy(e);
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     if (m->ev_join) hipEventDestroy(m->ev_join);
     if (m->aux) hipStreamDestroy(m->aux);
@@ -565,6 +568,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 }, &cc);
             }
             ++cont_slot;
+            if (out->d_logits && !joint && fork && i + 1 < m->nf) {
+                // the next BERT layer rewrites the text rows in place: it must not start before this read finished
+                if (hipEventRecord(m->ev_cont[i], s) != hipSuccess || hipStreamWaitEvent(sa, m->ev_cont[i], 0) != hipSuccess) return fail(UVL_EHIP, "cont event failed");
+            }
         }
         if (m->debug_stop_layer == i) {
             if (!joint && fork) {       // text branch must be joined before the head reads the residual stream

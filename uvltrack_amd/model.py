@@ -1,0 +1,159 @@
+"""Drop-in module objects behind the reference's registry surface.
+
+`UVLTrack` mirrors reference lib/models/uvltrack/uvltrack.py:8-45 for the inference path:
+`.backbone`, `.box_head`, `.to()`, `.eval()`, `.state_dict()`, `.load_state_dict(strict=False)` and
+`.forward_test(template, search, text, prompt, flag) -> dict`.  The modules are plain parameter
+containers with the reference's state_dict key schema; all arithmetic happens in the
+HIP library through uvltrack_amd.engine.HipEngine.  There is no CPU path: forward_test on CPU tensors,
+or without the built library, raises NativeLibraryError.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import weightgen
+from ._native import NativeLibraryError
+from .spec import ModelSpec, spec_from_cfg, state_dict_schema
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "coodinate")
+
+
+class _Node(nn.Module):
+    """A parameter container; children are created on demand from dotted state_dict names."""
+
+    def _attach(self, dotted: str, tensor: torch.Tensor):
+        parts = dotted.split(".")
+        node = self
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        leaf = parts[-1]
+        if leaf in _BUFFER_LEAVES:
+            node.register_buffer(leaf, tensor)
+        else:
+            node.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
+
+
+def _init_tensor(name, shape, spec):
+    """Cheap deterministic init (the reference initialises randomly and then loads a checkpoint)."""
+    if name.endswith("num_batches_tracked"):
+        return torch.zeros((), dtype=torch.long)
+    if name.endswith(("pos_embed_z", "pos_embed_x", "coodinate", "logit_scale")):
+        return torch.from_numpy(np.asarray(weightgen.make_tensor(0, name, shape, spec)))
+    if name.endswith("running_var") or (name.endswith("weight") and len(shape) == 1):
+        return torch.ones(shape)
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        g = torch.Generator().manual_seed(weightgen._fnv1a64(name) & 0x7FFFFFFF)
+        return (torch.rand(shape, generator=g) * 2 - 1) * float(np.sqrt(3.0 / fan_in))
+    return torch.zeros(shape)
+
+
+class ModalityUnifiedFeatureExtractor(_Node):
+    """Parameter container for reference extractor.py:11-41 (ViT + truncated BERT)."""
+
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        self.spec = spec
+        for name, shape in state_dict_schema(spec).items():
+            if name.startswith("backbone."):
+                self._attach(name[len("backbone."):], _init_tensor(name, shape, spec))
+
+
+class ModalityAdaptiveBoxHead(_Node):
+    """Parameter container for reference modality_adaptive_box_head.py:10-60."""
+
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        self.spec = spec
+        self.feat_sz = spec.feat_sz
+        for name, shape in state_dict_schema(spec).items():
+            if name.startswith("box_head."):
+                self._attach(name[len("box_head."):], _init_tensor(name, shape, spec))
+
+
+class UVLTrack(nn.Module):
+    """Inference-path mirror of reference UVLTrack (uvltrack.py:8-45)."""
+
+    def __init__(self, backbone: ModalityUnifiedFeatureExtractor, box_head: ModalityAdaptiveBoxHead, max_batch: int = 64):
+        super().__init__()
+        self.backbone = backbone
+        self.box_head = box_head
+        self.spec: ModelSpec = backbone.spec
+        self.max_batch = max_batch
+        self._engine = None
+        self._engine_key = None
+        self._weights_version = 0
+        self.eval()
+
+    # weights changed -> the packed copy in the HIP library is stale
+    def _apply(self, fn, *a, **k):
+        self._weights_version += 1
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._weights_version += 1
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def train(self, mode: bool = True):
+        if mode:
+            # the reference's profile_model.py never calls eval(), which leaves dropout / batch-norm in training
+            # mode; this implementation is eval-only by design (SURVEY.md 7.3 "train/eval trap")
+            import warnings
+            warnings.warn("uvltrack_amd.UVLTrack implements eval semantics only; train(True) is ignored")
+        return super().train(False)
+
+    def _get_engine(self, device):
+        from .engine import HipEngine
+        key = (str(device), self._weights_version)
+        if self._engine is None or self._engine.device != torch.device(device):
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = HipEngine(self.spec, device, self.max_batch)
+            self._engine_key = None
+        if self._engine_key != key:
+            self._engine.load_state_dict(self.state_dict())
+            self._engine_key = key
+        return self._engine
+
+    def forward_test(self, template, search, text, prompt, flag):
+        """Same signature and output dict as reference uvltrack.py:41-45."""
+        if not search.is_cuda:
+            raise NativeLibraryError("forward_test needs tensors on a HIP device (got %s); there is no CPU fallback" % search.device)
+        p0 = next(self.parameters())
+        if p0.device != search.device:
+            raise RuntimeError("model is on %s but inputs are on %s -- call model.to(device) first" % (p0.device, search.device))
+        eng = self._get_engine(search.device)
+        ids, mask = text.tensors, text.mask
+        if mask is None:
+            mask = torch.ones_like(ids)
+        out = eng.forward(template, search, ids, mask, prompt, flag)
+        out.pop("argmax", None)
+        return out
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("only the per-frame path forward_test is implemented (training forward is out of scope)")
+
+    def forward_prompt_init(self, *a, **k):
+        raise NotImplementedError("the prompter (heads/utils.py:23-99) is a 'next' row of SURVEY.md section 8f, not built yet")
+
+    forward_prompt = forward_prompt_init
+
+
+def build_backbone(cfg):
+    return ModalityUnifiedFeatureExtractor(spec_from_cfg(cfg))
+
+
+def build_head(cfg):
+    return ModalityAdaptiveBoxHead(spec_from_cfg(cfg))
+
+
+def build_model(cfg):
+    """registry.MODELS['uvltrack'] (reference uvltrack.py:47-57)."""
+    from lib import registry
+    backbone = registry.BACKBONES[cfg.MODEL.BACKBONE.TYPE](cfg)
+    head = registry.HEADS[cfg.MODEL.HEAD.TYPE](cfg)
+    return UVLTrack(backbone, head)
