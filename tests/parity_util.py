@@ -20,9 +20,12 @@ def softmax_np(x):
     return e / e.sum(-1, keepdims=True)
 
 
-def compare_outputs(got, ref, skip=()):
-    """got/ref: dict name -> ndarray (ref may hold '<name>.slice' = [:, :8, :32]).  Returns (ok, report)."""
+def compare_outputs(got, ref, skip=(), depth=12):
+    """got/ref: dict name -> ndarray (ref may hold '<name>.slice' = [:, :8, :32]).  Returns (ok, report).
+    bf16 rounding noise grows with the number of layers: the absolute gates are stated for the 12-layer
+    UVLTrack-B and scale linearly with depth (x2 for the 24-layer UVLTrack-L, never below x1)."""
     report, ok = {}, True
+    scale = max(1.0, depth / 12.0)
     for k, v in ref.items():
         if k in ("flag",) or k in skip or k.split(".")[0] in skip:
             continue
@@ -38,7 +41,7 @@ def compare_outputs(got, ref, skip=()):
             continue
         err = float(np.abs(g - v).max()) if np.isfinite(g).all() else float("inf")
         if name in ATOL:
-            tol = ATOL[name]
+            tol = ATOL[name] * scale
         else:
             tol = REL_ABSMAX.get(name, 0.03) * float(np.abs(v).max())
         report[k] = (err, tol)
@@ -50,8 +53,8 @@ def compare_outputs(got, ref, skip=()):
         idx = np.asarray(got["argmax"]).reshape(-1)
         gap = float((score.max(-1) - score[np.arange(B), idx]).max())
         box_err = float(np.abs(np.asarray(got["pred_boxes"])[:, 0] - ref["bbox_map"][np.arange(B), idx]).max())
-        report["pred_boxes(tie-aware)"] = (max(gap, box_err), 1e-2)
-        ok &= gap <= 1e-2 and box_err <= 1e-2
+        report["pred_boxes(tie-aware)"] = (max(gap, box_err), 1e-2 * scale)
+        ok &= gap <= 1e-2 * scale and box_err <= 1e-2 * scale
     return ok, report
 
 

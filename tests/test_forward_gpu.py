@@ -35,7 +35,7 @@ def test_forward_matches_reference_fixture(name):
     meta, spec, ref = load_case(name)
     inp = rebuild_inputs(meta, spec)
     got = _run(_engine(meta, spec), inp)
-    ok, rep = compare_outputs(got, ref)
+    ok, rep = compare_outputs(got, ref, depth=spec.depth)
     assert ok, "\n" + fmt_report(rep)
 
 

@@ -37,7 +37,7 @@ def main(names):
             out = eng.forward(*args)
             torch.cuda.synchronize()
             got = {k: v.cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
-            ok, rep = compare_outputs(got, ref)
+            ok, rep = compare_outputs(got, ref, depth=spec.depth)
             print("[%s] %s\n%s" % (name, "PASS" if ok else "FAIL", fmt_report(rep)))
             res[name] = {"ok": bool(ok), "report": {k: list(v) if isinstance(v, tuple) else v for k, v in rep.items()}}
             if name.startswith("tiny") or not ok:

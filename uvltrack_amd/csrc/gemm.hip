@@ -12,12 +12,66 @@
 // 128 bytes and XOR-swizzled so ds_read_b128 is conflict-free.  The blockIdx -> tile map keeps all
 // M-tiles of one N-tile on one XCD so a weight panel is fetched into exactly one L2.
 #include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
 namespace uvl {
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_QKV = 2 };
+
+// Shared epilogue: bias, activation / residual accumulate / QKV scatter (see GemmParams).
+template <int TM, int TN, int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int g) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row_base = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
+        int b0 = 0, rem0 = row_base;
+        if (EPI != EPI_BF16) {
+            b0 = row_base / p.rpb;
+            rem0 = row_base - b0 * p.rpb;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + (lane & 31);
+            const float bias = p.bias ? p.bias[(size_t)g * p.N + col] : 0.f;
+            // QKV scatter targets (wave-uniform `which`/h for a 32-column tile since D % 64 == 0)
+            int which = 0, hh = 0, dd = 0;
+            if (EPI == EPI_QKV) {
+                which = col / p.D;
+                const int cc = col - which * p.D;
+                hh = cc >> 6;
+                dd = cc & 63;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int inc = (r & 3) + 8 * (r >> 2);
+                const int row = row_base + inc;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (EPI == EPI_BF16) {
+                    if (p.act == 1) v = gelu_erf(v);
+                    else if (p.act == 2) v = fmaxf(v, 0.f);
+                    reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + (size_t)g * p.N + col] = f2bf(v);
+                } else {
+                    int b = b0, rem = rem0 + inc;
+                    while (rem >= p.rpb) { rem -= p.rpb; ++b; }
+                    if (EPI == EPI_F32) {
+                        if (p.addtab) v += p.addtab[(size_t)rem * p.N + col];
+                        float* dst = reinterpret_cast<float*>(p.C) + ((size_t)b * p.obs + p.oro + rem) * p.ldc + col;
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                    } else {
+                        const size_t bh = (size_t)b * p.H + hh;
+                        if (which == 0) p.q[(bh * p.Npad + rem) * 64 + dd] = f2bf(v);
+                        else if (which == 1) p.k[(bh * p.Npad + rem) * 64 + dd] = f2bf(v);
+                        else p.vt[(bh * 64 + dd) * p.Npad + rem] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
@@ -137,55 +191,119 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    // ---------------- epilogue ----------------
+    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined variant for the plain (non-conv) GEMMs: tiles go HBM -> LDS directly (global_load_lds,
+// 16 B per lane, no VGPR round trip) into an NS-deep ring, NS-1 tiles in flight per workgroup, counted
+// s_waitcnt vmcnt(N) so loads stay in flight across the (raw) barrier.  The LDS image of a DMA is
+// lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address (same 128-byte line, no
+// extra fetch) and again on the fragment read.  At batch 1 a workgroup streams its weight panel with
+// exposed HBM latency per K-step; the ring hides it.
+// ------------------------------------------------------------------------------------------------
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
+    constexpr int BK = 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int ROWS = BM + BN;                    // stage = A rows then W rows, 128 B each
+    constexpr int STAGE = ROWS * 128;
+    constexpr int LPT = ROWS / 32;                   // DMA instructions per wave per tile (each fills 8 rows)
+    static_assert(WGM * WGN == 4 && BM % 16 == 0 && LPT * (NS - 2) <= 63, "geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int nt = (idx / MT) * 8 + xcd, mt = idx % MT;
+    if (nt >= NT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + 4*i), +8)
+    const bf16_t* src[LPT];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row_base = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
-        int b0 = 0, rem0 = row_base;
-        if (EPI != EPI_BF16) {
-            b0 = row_base / p.rpb;
-            rem0 = row_base - b0 * p.rpb;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + (lane & 31);
-            const float bias = p.bias ? p.bias[(size_t)g * p.N + col] : 0.f;
-            // QKV scatter targets (wave-uniform `which`/h for a 32-column tile since D % 64 == 0)
-            int which = 0, hh = 0, dd = 0;
-            if (EPI == EPI_QKV) {
-                which = col / p.D;
-                const int cc = col - which * p.D;
-                hh = cc >> 6;
-                dd = cc & 63;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int inc = (r & 3) + 8 * (r >> 2);
-                const int row = row_base + inc;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (EPI == EPI_BF16) {
-                    if (p.act == 1) v = gelu_erf(v);
-                    else if (p.act == 2) v = fmaxf(v, 0.f);
-                    reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + (size_t)g * p.N + col] = f2bf(v);
-                } else {
-                    int b = b0, rem = rem0 + inc;
-                    while (rem >= p.rpb) { rem -= p.rpb; ++b; }
-                    if (EPI == EPI_F32) {
-                        if (p.addtab) v += p.addtab[(size_t)rem * p.N + col];
-                        float* dst = reinterpret_cast<float*>(p.C) + ((size_t)b * p.obs + p.oro + rem) * p.ldc + col;
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
-                    } else {
-                        const size_t bh = (size_t)b * p.H + hh;
-                        if (which == 0) p.q[(bh * p.Npad + rem) * 64 + dd] = f2bf(v);
-                        else if (which == 1) p.k[(bh * p.Npad + rem) * 64 + dd] = f2bf(v);
-                        else p.vt[(bh * 64 + dd) * p.Npad + rem] = f2bf(v);
-                    }
-                }
-            }
+    for (int i = 0; i < LPT; ++i) {
+        const int r = 8 * (wave + 4 * i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);        // logical 16-byte chunk that belongs at this physical slot
+        if (r < BM) {
+            int gm = m0 + r;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[i] = p.A + (size_t)gm * p.lda + chunk * 8;
+        } else {
+            src[i] = p.W + (size_t)(n0 + r - BM) * p.ldw + chunk * 8;
         }
     }
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        char* st = smem + (kt % NS) * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(t);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight
+        const int ahead = nk - 1 - kt;
+        if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
+        else if (NS > 3 && ahead == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);            // its stage was last read in iteration kt-1
+        const char* sA = smem + (kt % NS) * STAGE;
+        const char* sB = sA + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+            const int chunk = ks * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(sA + swz128(wm * WM + i * 32 + (lane & 31), chunk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sB + swz128(wn * WN + j * 32 + (lane & 31), chunk));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, 0);
+}
+
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
+static hipError_t launch_glds(const GemmParams& p, hipStream_t s) {
+    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
+    const int nblk = 8 * ((NT + 7) / 8) * MT;
+    const size_t lds = (size_t)NS * (BM + BN) * 128;
+    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS);
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, s, p);
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
@@ -207,8 +325,19 @@ static hipError_t launch_cfg(const GemmParams& p, int groups, hipStream_t s) {
     return hipGetLastError();
 }
 
+static bool use_v1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UVL_GEMM_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 template <int EPI, bool CONV>
 static hipError_t launch_epi(const GemmParams& p, int groups, hipStream_t s) {
+    if (!CONV && groups == 1 && p.N % 64 == 0 && !use_v1()) {
+        const long t128 = (long)((p.M + 127) / 128) * (p.N / 128);
+        if (p.N % 128 == 0 && t128 >= 512) return launch_glds<128, 128, 2, 2, EPI, 3>(p, s);
+        return launch_glds<64, 64, 2, 2, EPI, 4>(p, s);
+    }
     if (p.N % 64 != 0) {
         if (p.N % 32 == 0) return launch_cfg<128, 32, 4, 1, EPI, CONV>(p, groups, s);
         return hipErrorInvalidValue;
