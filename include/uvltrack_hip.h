@@ -139,6 +139,12 @@ int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int
  * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs. */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
+/* Tuning hooks for tools/gemm_bench.py (not part of the product path): force a plain-GEMM tile configuration
+ * (key "gemm_cfg", -1 = heuristic) and run a GEMM with split-K f32 slabs [splitk][M,N]. */
+int uvl_tune_set(const char* key, int value);
+int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, float* d_slabs,
+                      int M, int N, int K, int splitk, void* stream);
+
 /* ---- per-kernel entry points (used by the parity tests; same kernels the forward uses) ---------- */
 
 /* y = act(x W^T + b): nn.Linear (block.py:42,44; backbones/utils.py:58,61; bert_backbone.py:289-291,338,366,379).

@@ -18,7 +18,7 @@ UVL_NFAM = 5
 EXPORTS = [
     "uvl_last_error", "uvl_version", "uvl_create", "uvl_destroy", "uvl_load_tensor", "uvl_finalize_weights",
     "uvl_workspace_bytes", "uvl_forward_test", "uvl_graph_capture", "uvl_graph_launch", "uvl_graph_release",
-    "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_debug_set",
+    "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_debug_set", "uvl_tune_set", "uvl_linear_splitk",
     "uvl_linear", "uvl_attention", "uvl_qkv_project", "uvl_layernorm", "uvl_f32_to_bf16",
 ]
 
@@ -84,6 +84,8 @@ def load():
     lib.uvl_profile_entry.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.uvl_debug_set.argtypes = [vp, C.c_char_p, i32]
+    lib.uvl_tune_set.argtypes = [C.c_char_p, i32]
+    lib.uvl_linear_splitk.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.uvl_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.uvl_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.uvl_qkv_project.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]

@@ -22,7 +22,7 @@ enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_QKV = 2 };
 
 // Shared epilogue: bias, activation / residual accumulate / QKV scatter (see GemmParams).
 template <int TM, int TN, int WM, int WN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int g) {
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int g, int sk = 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row_base = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
@@ -34,7 +34,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + (lane & 31);
-            const float bias = p.bias ? p.bias[(size_t)g * p.N + col] : 0.f;
+            const float bias = (p.bias && sk == 0) ? p.bias[(size_t)g * p.N + col] : 0.f;
             // QKV scatter targets (wave-uniform `which`/h for a 32-column tile since D % 64 == 0)
             int which = 0, hh = 0, dd = 0;
             if (EPI == EPI_QKV) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     while (rem >= p.rpb) { rem -= p.rpb; ++b; }
                     if (EPI == EPI_F32) {
                         if (p.addtab) v += p.addtab[(size_t)rem * p.N + col];
-                        float* dst = reinterpret_cast<float*>(p.C) + ((size_t)b * p.obs + p.oro + rem) * p.ldc + col;
+                        float* dst = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + col;
                         if (p.accumulate) v += *dst;
                         *dst = v;
                     } else {
@@ -223,6 +223,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
     if (nt >= NT) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
+    // split-K: blockIdx.y owns the K range [sk*K/splitk, (sk+1)*K/splitk) and writes its own f32 partial slab
+    const int sk = blockIdx.y;
+    const int kspan = p.K / p.splitk;
+    const int kbase = sk * kspan;
     // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + 4*i), +8)
     const bf16_t* src[LPT];
 #pragma unroll
@@ -232,9 +236,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
         if (r < BM) {
             int gm = m0 + r;
             gm = gm < p.M ? gm : p.M - 1;
-            src[i] = p.A + (size_t)gm * p.lda + chunk * 8;
+            src[i] = p.A + (size_t)gm * p.lda + kbase + chunk * 8;
         } else {
-            src[i] = p.W + (size_t)(n0 + r - BM) * p.ldw + chunk * 8;
+            src[i] = p.W + (size_t)(n0 + r - BM) * p.ldw + kbase + chunk * 8;
         }
     }
     auto issue = [&](int kt) __attribute__((always_inline)) {
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk = kspan / BK;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) issue(t);
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, 0);
+    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, 0, sk);
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
@@ -302,7 +306,7 @@ static hipError_t launch_glds(const GemmParams& p, hipStream_t s) {
     static char name[64];
     if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS);
     g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -331,12 +335,44 @@ static bool use_v1() {
     return v == 1;
 }
 
+// tuning override for tools/gemm_bench.py: -1 = heuristic, otherwise index into the config table below
+int g_tune_gemm_cfg = -1;
+
+template <int EPI>
+static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) {
+    switch (cfg) {
+        case 0: return launch_glds<64, 64, 2, 2, EPI, 4>(p, s);
+        case 1: return launch_glds<128, 64, 2, 2, EPI, 4>(p, s);
+        case 2: return launch_glds<128, 128, 2, 2, EPI, 3>(p, s);
+        case 3: return launch_glds<64, 128, 2, 2, EPI, 4>(p, s);
+        case 4: return launch_glds<64, 64, 2, 2, EPI, 3>(p, s);
+        case 5: return launch_glds<64, 64, 2, 2, EPI, 6>(p, s);
+        case 6: return launch_glds<128, 128, 2, 2, EPI, 2>(p, s);
+        case 7: return launch_glds<64, 64, 2, 2, EPI, 2>(p, s);
+        case 8: return launch_glds<128, 64, 2, 2, EPI, 3>(p, s);
+        case 9: return launch_glds<128, 64, 2, 2, EPI, 2>(p, s);
+        case 10: return launch_glds<64, 128, 2, 2, EPI, 2>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+static int pick_plain_cfg(const GemmParams& p) {
+    if (g_tune_gemm_cfg == -1) { const char* e = getenv("UVL_GEMM_CFG"); g_tune_gemm_cfg = e ? atoi(e) : -2; }
+    if (g_tune_gemm_cfg >= 0) return g_tune_gemm_cfg;
+    // measured on MI355X (tools/gemm_bench.py, profiles/): co-resident workgroups matter more than ring depth, so
+    // the 2-stage ring wins everywhere; small M keeps 64x64 tiles for parallelism, large M takes 64x128 / 128x64
+    const long t64 = (long)((p.M + 63) / 64) * (p.N / 64);
+    if (t64 < 2048) return 7;                       // 64x64, 2 stages
+    if (p.N % 128 == 0) return 10;                  // 64x128, 2 stages
+    return 9;                                       // 128x64, 2 stages
+}
+
 template <int EPI, bool CONV>
 static hipError_t launch_epi(const GemmParams& p, int groups, hipStream_t s) {
     if (!CONV && groups == 1 && p.N % 64 == 0 && !use_v1()) {
-        const long t128 = (long)((p.M + 127) / 128) * (p.N / 128);
-        if (p.N % 128 == 0 && t128 >= 512) return launch_glds<128, 128, 2, 2, EPI, 3>(p, s);
-        return launch_glds<64, 64, 2, 2, EPI, 4>(p, s);
+        int cfg = pick_plain_cfg(p);
+        if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10) && p.N % 128 != 0) cfg = 0;
+        return launch_plain_cfg<EPI>(cfg, p, s);
     }
     if (p.N % 64 != 0) {
         if (p.N % 32 == 0) return launch_cfg<128, 32, 4, 1, EPI, CONV>(p, groups, s);
@@ -349,7 +385,9 @@ static hipError_t launch_epi(const GemmParams& p, int groups, hipStream_t s) {
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
-    if (p.K % 64 != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
+    if (p.K % 64 != 0 || p.M <= 0 || p.N <= 0 || p.splitk < 1) return hipErrorInvalidValue;
+    if (p.splitk > 1 && (p.epi != EPI_F32 || p.accumulate || p.conv_F > 0 || p.N % 64 != 0 || (p.K / 64) % p.splitk != 0 || use_v1()))
+        return hipErrorInvalidValue;      // partial slabs: f32 store epilogue of the pipelined kernel only
     const int groups = p.groups > 0 ? p.groups : 1;
     if (p.conv_F > 0) {
         if (p.epi != EPI_BF16 || p.cin_g % 64 != 0) return hipErrorInvalidValue;

@@ -8,6 +8,7 @@ namespace uvl {
 
 // name of the kernel instantiation the last launcher picked (for per-kernel profiles)
 extern thread_local const char* g_last_kernel;
+extern int g_tune_gemm_cfg;      // tools/gemm_bench.py override of the plain-GEMM tile configuration (-1 = heuristic)
 
 struct GemmParams {
     const bf16_t* A = nullptr; int lda = 0;      // [M,K] bf16 (plain) or NHWC activations (conv)
@@ -22,6 +23,7 @@ struct GemmParams {
     const float* addtab = nullptr;               // [rpb, N] f32 added by t            (EPI_F32; pos-embed)
     bf16_t *q = nullptr, *k = nullptr, *vt = nullptr; int H = 0, Npad = 0, D = 0;   // EPI_QKV
     int groups = 1;
+    int splitk = 1; size_t part_stride = 0;      // split-K: slab sk of C (f32, + sk*part_stride elements) holds partial sums of K-range sk
     int conv_F = 0, cin_g = 0;                   // conv mode: feature-map side, input channels per group
     int a_goff[4] = {0, 0, 0, 0};                // conv mode: channel offset of each group's input inside a row
 };
@@ -39,12 +41,15 @@ struct LnParams {
     const float* x = nullptr;                    // input rows, f32
     int M = 0, D = 0;                            // compact row count
     int rpb = 1 << 30, xbs = 0, xro = 0;         // compact row m -> x row (m/rpb)*xbs + xro + m%rpb
+    const float* part = nullptr; int nsplit = 0, part_rows = 0; size_t part_stride = 0;   // pending split-K slabs [nsplit][B*part_rows, D]
+                                                 // added to the row first and written back: x += sum_s part[s]
     const float* pre_add0 = nullptr;             // optional vector added to rows with t <  split (then written back to x)
     const float* pre_add1 = nullptr;             //                          rows with t >= split
     int split = 0;
     const float *gamma = nullptr, *beta = nullptr; float eps = 1e-6f;
     bf16_t* y_bf16 = nullptr;                    // [M,D] compact, optional
     float* y_f32 = nullptr; int y_remap = 0;     // optional f32 output; y_remap: same row map as x (in-place LN) else compact
+    float* y_copy = nullptr;                     // optional second f32 output, compact [M,D] (text snapshot)
 };
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
 
@@ -62,9 +67,15 @@ hipError_t launch_setup(const uint8_t* text_mask, const int64_t* flag, const flo
                         int skip_text, hipStream_t s);
 
 // ModalityUnifiedFeatureExtractor.contractive_learning (extractor.py:85-93) for one layer.
-hipError_t launch_contrast(const float* x, int nj, int nz, int nx, int nv, int D, const uint8_t* text_mask, int T,
-                           int mean_mode, const int64_t* flag, const float* logit_scale, float* logits,
-                           int layer_slot, int n_cont, int B, int skip_text, hipStream_t s);
+struct ContrastParams {
+    const float* x = nullptr; int nj = 0, nz = 0, nx = 0, nv = 0, D = 0, T = 0, B = 0;
+    const uint8_t* text_mask = nullptr; const int64_t* flag = nullptr; const float* logit_scale = nullptr;
+    int mean_mode = 0, skip_text = 0;
+    float* logits = nullptr; int slot = 0, n_cont = 0;
+    const float* part = nullptr; int nsplit = 0, part_rows = 0; size_t part_stride = 0;   // pending split-K slabs
+    const float* txt_snap = nullptr;             // [B,T,D] text rows of this layer (pre-fusion layers) or null = read x
+};
+hipError_t launch_contrast(const ContrastParams& p, hipStream_t s);
 
 // Head prologue: copy residual rows to the output dict, emit the bf16 NHWC conv input and cont_score (head:140-148).
 struct HeadPrepParams {

@@ -11,6 +11,8 @@ namespace uvl {
 // Optionally adds a per-row-type vector first and writes it back: that is the permanent
 // `img_feat + modal_embed[0]`, `txt_feat + modal_embed[1]` of forward_joint (mae_vit.py:196).
 // ------------------------------------------------------------------------------------------------
+#define LN_MAX_SLABS 4
+
 template <int NV>
 __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -20,6 +22,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
     const size_t xrow = (size_t)b * p.xbs + p.xro + t;
     float* xr = const_cast<float*>(p.x) + xrow * p.D;
     const float* padd = (t < p.split) ? p.pre_add0 : p.pre_add1;
+    const int nsp = (t < p.part_rows) ? p.nsplit : 0;       // rows beyond part_rows were not produced by that GEMM
+    const size_t pm = (size_t)b * p.part_rows + t;           // compact row index inside a slab
     float4 v[NV];
     float sum = 0.f;
 #pragma unroll
@@ -27,11 +31,19 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
         const int c = (lane + 64 * i) * 4;
         if (c < p.D) {
             v[i] = *reinterpret_cast<const float4*>(xr + c);
+            float4 sl[LN_MAX_SLABS];                         // pending split-K slabs: issue every load, then add in slab order
+#pragma unroll
+            for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
+                sl[sp] = (sp < nsp) ? *reinterpret_cast<const float4*>(p.part + (size_t)sp * p.part_stride + pm * p.D + c)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
+                if (sp < nsp) { v[i].x += sl[sp].x; v[i].y += sl[sp].y; v[i].z += sl[sp].z; v[i].w += sl[sp].w; }
             if (padd) {
                 const float4 a = *reinterpret_cast<const float4*>(padd + c);
                 v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
-                *reinterpret_cast<float4*>(xr + c) = v[i];
             }
+            if (padd || nsp > 0) *reinterpret_cast<float4*>(xr + c) = v[i];
             sum += v[i].x + v[i].y + v[i].z + v[i].w;
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -61,6 +73,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
             y.z = (v[i].z - mean) * rstd * g.z + be.z;
             y.w = (v[i].w - mean) * rstd * g.w + be.w;
             if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + yrow * p.D + c) = y;
+            if (p.y_copy) *reinterpret_cast<float4*>(p.y_copy + (size_t)m * p.D + c) = y;
             if (p.y_bf16) {
                 uint2 w;
                 w.x = pack_bf16x2(y.x, y.y);
@@ -261,47 +274,106 @@ __device__ __forceinline__ void block_txt_token(float* dst, const float* xtext, 
 // ------------------------------------------------------------------------------------------------
 // Backbone contrastive logits for one layer (extractor.py:85-93):
 //   tau * normalize(x) . normalize(tok) for tok in {vis_token, txt_token}; select [vis, txt, mean][flag].
-// grid (ceil(nx/4), B), one wave per search token.
+// grid (ceil(nx/4), B), one wave per search token.  The residual stream may still carry pending split-K
+// slabs of the layer's last GEMM (x_eff = x + sum_s part[s]); rows t < part_rows of each sample have them.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void contrast_kernel(const float* __restrict__ x, int nj, int nz, int nx, int nv, int D,
-                                                       const uint8_t* __restrict__ tmask, int T, int mean_mode,
-                                                       const int64_t* __restrict__ flag, const float* __restrict__ logit_scale,
-                                                       float* __restrict__ logits, int slot, int n_cont, int skip_text) {
-    extern __shared__ float sh[];              // [D] txt token
-    const int b = blockIdx.y;
+struct RowView {
+    const float* xb;          // sample base in the residual stream
+    const float* part;        // slabs [nsplit][B*part_rows, D] or null
+    int nsplit, part_rows, D;
+    size_t part_stride, mbase;   // mbase = b * part_rows
+    __device__ __forceinline__ float4 load(int t, int c) const {
+        float4 v = *reinterpret_cast<const float4*>(xb + (size_t)t * D + c);
+        const int nsp = (t < part_rows) ? nsplit : 0;
+        float4 sl[LN_MAX_SLABS];
+#pragma unroll
+        for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
+            sl[sp] = (sp < nsp) ? *reinterpret_cast<const float4*>(part + (size_t)sp * part_stride + (mbase + t) * D + c)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
+            if (sp < nsp) { v.x += sl[sp].x; v.y += sl[sp].y; v.z += sl[sp].z; v.w += sl[sp].w; }
+        return v;
+    }
+};
+
+__global__ __launch_bounds__(256) void contrast_kernel(const ContrastParams p) {
+    extern __shared__ float sh[];              // [D] txt token, [D] vis token
+    const int b = blockIdx.y, D = p.D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* xb = x + (size_t)b * nj * D;
-    const int fl = (int)flag[b];
-    if (!skip_text) block_txt_token(sh, xb + (size_t)nv * D, tmask + (size_t)b * T, T, D, mean_mode);
-    const int s = blockIdx.x * 4 + wave;
-    if (s >= nx) return;
-    const float* xr = xb + (size_t)(1 + nz + s) * D;
-    const float* vt = xb;                      // vis token = row 0
-    const float tau = __expf(logit_scale[0]);
-    const float xx = fmaxf(sqrtf(wave_dot(xr, xr, D, lane)), 1e-12f);
-    float lt = 0.f;
-    const float vv = fmaxf(sqrtf(wave_dot(vt, vt, D, lane)), 1e-12f);
-    const float lv = tau * wave_dot(xr, vt, D, lane) / (xx * vv);
-    if (!skip_text) {
-        float tt = 0.f, xt = 0.f;
-        for (int c = lane * 4; c < D; c += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(xr + c);
-            const float4 q = *reinterpret_cast<const float4*>(sh + c);
-            tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-            xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+    RowView rv{p.x + (size_t)b * p.nj * D, p.part, p.nsplit, p.part_rows, D, p.part_stride, (size_t)b * p.part_rows};
+    const int fl = (int)p.flag[b];
+    float* txt = sh;
+    float* vis = sh + D;
+    // stage the two tokens (generate_txt_token, extractor.py:79-83: 'cls' = first text row, 'mean' = masked mean)
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        *reinterpret_cast<float4*>(vis + c) = rv.load(0, c);
+        if (!p.skip_text) {
+            float4 tk;
+            if (p.txt_snap) {                  // pre-fusion layer: text rows of THIS layer, snapshotted by the BERT LayerNorm
+                const float* ts = p.txt_snap + (size_t)b * p.T * D;
+                if (!p.mean_mode) {
+                    tk = *reinterpret_cast<const float4*>(ts + c);
+                } else {
+                    tk = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float cnt = 0.f;
+                    const uint8_t* tm = p.text_mask + (size_t)b * p.T;
+                    for (int t = 0; t < p.T; ++t)
+                        if (tm[t]) {
+                            const float4 a = *reinterpret_cast<const float4*>(ts + (size_t)t * D + c);
+                            tk.x += a.x; tk.y += a.y; tk.z += a.z; tk.w += a.w;
+                            cnt += 1.f;
+                        }
+                    tk.x /= cnt; tk.y /= cnt; tk.z /= cnt; tk.w /= cnt;
+                }
+            } else if (!p.mean_mode) {
+                tk = rv.load(p.nv, c);
+            } else {
+                tk = make_float4(0.f, 0.f, 0.f, 0.f);
+                float cnt = 0.f;
+                const uint8_t* tm = p.text_mask + (size_t)b * p.T;
+                for (int t = 0; t < p.T; ++t)
+                    if (tm[t]) {
+                        const float4 a = rv.load(p.nv + t, c);
+                        tk.x += a.x; tk.y += a.y; tk.z += a.z; tk.w += a.w;
+                        cnt += 1.f;
+                    }
+                tk.x /= cnt; tk.y /= cnt; tk.z /= cnt; tk.w /= cnt;
+            }
+            *reinterpret_cast<float4*>(txt + c) = tk;
         }
+    }
+    __syncthreads();
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= p.nx) return;
+    float xx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 a = rv.load(1 + p.nz + s, c);
+        const float4 v = *reinterpret_cast<const float4*>(vis + c);
+        xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        xv += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+        vv += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        if (!p.skip_text) {
+            const float4 q = *reinterpret_cast<const float4*>(txt + c);
+            xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+            tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+        }
+    }
+    const float tau = __expf(p.logit_scale[0]);
+    xx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
+    vv = fmaxf(sqrtf(wave_sum(vv)), 1e-12f);
+    const float lv = tau * wave_sum(xv) / (xx * vv);
+    float lt = 0.f;
+    if (!p.skip_text) {
         tt = fmaxf(sqrtf(wave_sum(tt)), 1e-12f);
         lt = tau * wave_sum(xt) / (xx * tt);
     }
     const float out = fl == 0 ? lv : (fl == 1 ? lt : 0.5f * (lv + lt));
-    if (lane == 0) logits[((size_t)b * n_cont + slot) * nx + s] = out;
+    if (lane == 0) p.logits[((size_t)b * p.n_cont + p.slot) * p.nx + s] = out;
 }
 
-hipError_t launch_contrast(const float* x, int nj, int nz, int nx, int nv, int D, const uint8_t* text_mask, int T,
-                           int mean_mode, const int64_t* flag, const float* logit_scale, float* logits,
-                           int layer_slot, int n_cont, int B, int skip_text, hipStream_t s) {
-    hipLaunchKernelGGL(contrast_kernel, dim3((nx + 3) / 4, B), dim3(256), D * sizeof(float), s, x, nj, nz, nx, nv, D,
-                       text_mask, T, mean_mode, flag, logit_scale, logits, layer_slot, n_cont, skip_text);
+hipError_t launch_contrast(const ContrastParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(contrast_kernel, dim3((p.nx + 3) / 4, p.B), dim3(256), 2 * p.D * sizeof(float), s, p);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -336,10 +337,27 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
 }
 
 // ---- workspace ------------------------------------------------------------------------------------
+#define UVL_SKMAX 4
+
+// Split-K factor for an `x += A W^T` GEMM that would otherwise leave most CUs idle (batch-1 shapes): each split
+// writes an f32 slab, the consuming LayerNorm / contrast kernel adds the slabs on read (deterministic, no atomics).
+static int choose_splitk(int M, int N, int K) {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("UVL_SPLITK_MAX"); cap = e ? atoi(e) : UVL_SKMAX; if (cap < 1) cap = 1; if (cap > UVL_SKMAX) cap = UVL_SKMAX; }
+    const long tiles = (long)((M + 63) / 64) * (N / 64);
+    const int nk = K / 64;
+    // measured (tools/gemm_bench.py): with ~100 tiles, K=768 likes 2 splits and K=3072 likes 4; nothing above ~250 tiles
+    int sk = 1;
+    while (sk * 2 <= cap && tiles * sk < 256 && nk % (sk * 2) == 0 && nk / (sk * 2) >= 6) sk *= 2;
+    return sk;
+}
+
+struct Pending { const float* part = nullptr; int nsplit = 0, rows = 0; size_t stride = 0; };
+
 struct Workspace {
     float* X; bf16_t *Xn, *Q, *K, *Vt, *O, *Hb, *P;
     bf16_t *Tn, *Tq, *Tk, *Tvt, *To, *Th;
-    float *key_add, *bert_add, *cont, *bbox;
+    float *key_add, *bert_add, *cont, *bbox, *Part, *PartT, *TxtSnap;
     bf16_t *G0, *G1, *G2, *G3, *G4;
     size_t total;
 };
@@ -364,6 +382,9 @@ static Workspace carve(const uvl_model* m, int B, char* base) {
     w.Th = (bf16_t*)take(B * T * 4 * D * 2);
     w.key_add = (float*)take(B * npad * 4);
     w.bert_add = (float*)take(B * 64 * 4);
+    w.Part = (float*)take((size_t)UVL_SKMAX * B * nj * D * 4);
+    w.PartT = (float*)take((size_t)UVL_SKMAX * B * T * D * 4);
+    w.TxtSnap = (float*)take((size_t)(m->nf > 0 ? m->nf : 1) * B * T * D * 4);
     w.cont = (float*)take(B * S * 3 * 4);
     w.bbox = (float*)take(B * S * 4 * 4);
     w.G0 = (bf16_t*)take(B * S * 2 * D * 2);
@@ -434,6 +455,75 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     if (fork) {
         if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(sa, m->ev_fork, 0) != hipSuccess) return fail(UVL_EHIP, "fork failed");
     }
+    // -- text branch (extractor.py:54,62): embedding + the first nf BERT layers depend on the text only, so the whole
+    //    chain is enqueued up front on its own stream; layers whose output the contrastive logits need leave a snapshot
+    Pending pend_t;
+    auto consume = [](LnParams& p, Pending& pd) { p.part = pd.part; p.nsplit = pd.nsplit; p.part_rows = pd.rows; p.part_stride = pd.stride; pd = Pending(); };
+    auto is_cont_layer = [&](int i) { bool c = false; for (int k = 0; k < m->cfg.n_cont; ++k) c |= (m->cfg.cont_layers[k] == i); return c; };
+    auto residual_gemm = [&](hipStream_t st, const char* what, const bf16_t* A, int lda, const bf16_t* Wt, const float* bias, int Mr, int K,
+                             int rpb, int oro, float* slab, Pending& pd, bool allow_split) {
+        GemmParams p;
+        p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
+        const int sk = allow_split ? choose_splitk(Mr, D, K) : 1;
+        if (sk > 1) {             // slabs [sk][Mr, D], folded in by the next LayerNorm / contrast kernel
+            p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D;
+            pd.part = slab; pd.nsplit = sk; pd.rows = rpb; pd.stride = p.part_stride;
+        } else {                  // x += A W^T + b in place
+            p.C = w.X; p.accumulate = 1; p.rpb = rpb; p.obs = nj; p.oro = oro;
+        }
+        RUN_GEMM(L, st, p, what);
+    };
+    if (!skip) {
+        struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
+        L.run(sa, "bert_embed", 0, 0, [](void* c, hipStream_t st) {
+            auto* x = (BeCtx*)c;
+            return launch_bert_embed(x->in->d_text_ids, x->m->word, x->m->pos, x->m->type0, x->m->emb_g, x->m->emb_b, x->w.X, x->m->nj, x->m->nv,
+                                     x->w.Tn, x->B, x->m->T, x->m->D, x->m->cfg.vocab, st);
+        }, &bc);
+        const int last_bert = (m->debug_stop_layer >= 0 && m->debug_stop_layer < m->nf - 1) ? m->debug_stop_layer : m->nf - 1;
+        for (int i = 0; i <= last_bert; ++i) {        // BertLayer.forward (bert_backbone.py:390-394)
+            const BertLayerW& bw = m->bert[i];
+            const int Mt = B * T;
+            {
+                GemmParams p;
+                p.A = w.Tn; p.lda = D; p.W = bw.wqkv; p.ldw = D; p.bias = bw.bqkv; p.M = Mt; p.N = 3 * D; p.K = D;
+                p.epi = 2; p.rpb = T; p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.H = H; p.Npad = 64; p.D = D;
+                RUN_GEMM(L, sa, p, "gemm.bert_qkv");
+            }
+            {
+                AttnParams p;
+                p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64;
+                L.run(sa, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, tramp<AttnParams, launch_attention>, &p);
+            }
+            residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, true);
+            {
+                LnParams p;        // post-LN in place on the text rows
+                p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
+                consume(p, pend_t);
+                p.gamma = bw.ln1g; p.beta = bw.ln1b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
+                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
+            }
+            {
+                GemmParams p;
+                p.A = w.Tn; p.lda = D; p.W = bw.wi; p.ldw = D; p.bias = bw.bi; p.M = Mt; p.N = Fn; p.K = D;
+                p.epi = 0; p.C = w.Th; p.ldc = Fn; p.act = 1;
+                RUN_GEMM(L, sa, p, "gemm.bert_i");
+            }
+            residual_gemm(sa, "gemm.bert_o", w.Th, Fn, bw.wo, bw.bo, Mt, Fn, T, nv, w.PartT, pend_t, true);
+            {
+                LnParams p;
+                p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
+                consume(p, pend_t);
+                p.gamma = bw.ln2g; p.beta = bw.ln2b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
+                if (is_cont_layer(i) && out->d_logits) p.y_copy = w.TxtSnap + (size_t)i * Mt * D;   // this layer's text rows for the logits
+                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
+            }
+            if (fork && is_cont_layer(i) && out->d_logits) {
+                if (hipEventRecord(m->ev_bert[i], sa) != hipSuccess) return fail(UVL_EHIP, "bert event failed");
+            }
+        }
+        if (fork && hipEventRecord(m->ev_join, sa) != hipSuccess) return fail(UVL_EHIP, "join record failed");
+    }
     // -- patch embed (mae_vit.py:203-215)
     struct ImCtx { const uvl_inputs* in; Workspace w; int B, hz, hx; } ic{in, w, B, m->cfg.template_size, m->cfg.search_size};
     L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
@@ -444,29 +534,22 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         p.rpb = nz + nx; p.obs = nj; p.oro = 1; p.addtab = m->pos_tab;
         RUN_GEMM(L, s, p, "gemm.patch");
     }
-    // -- text embedding (bert_backbone.py:740-750)
-    if (!skip) {
-        struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
-        L.run(sa, "bert_embed", 0, 0, [](void* c, hipStream_t st) {
-            auto* x = (BeCtx*)c;
-            return launch_bert_embed(x->in->d_text_ids, x->m->word, x->m->pos, x->m->type0, x->m->emb_g, x->m->emb_b, x->w.X, x->m->nj, x->m->nv,
-                                     x->w.Tn, x->B, x->m->T, x->m->D, x->m->cfg.vocab, st);
-        }, &bc);
-    }
-
     int cont_slot = 0;
+    Pending pend_v;                              // split-K slabs not yet folded into the residual stream (visual/joint rows)
     for (int i = 0; i < m->depth; ++i) {
         const bool joint = i >= m->nf;
         const int N = (joint && !skip) ? nj : nv;
         const int M = B * N;
         const VitBlockW& vw = m->vit[i];
-        if (joint && i == m->nf && fork) {
-            if (hipEventRecord(m->ev_join, sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
+        const bool last = (i == m->depth - 1) || (m->debug_stop_layer == i);
+        if (joint && i == m->nf && fork) {       // first fusion layer reads the text rows
+            if (hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
         }
         // ---- ViT block (block.py:29-32) ----
         {
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
+            consume(p, pend_v);
             if (joint) { p.pre_add0 = m->modal; p.pre_add1 = m->modal + D; p.split = nv; }     // forward_joint, mae_vit.py:196
             p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
             L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
@@ -482,15 +565,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad;
             L.run(s, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, tramp<AttnParams, launch_attention>, &p);
         }
-        {
-            GemmParams p;
-            p.A = w.O; p.lda = D; p.W = vw.wproj; p.ldw = D; p.bias = vw.bproj; p.M = M; p.N = D; p.K = D;
-            p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = N; p.obs = nj; p.oro = 0;
-            RUN_GEMM(L, s, p, "gemm.proj");
-        }
+        residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true);
         {
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
+            consume(p, pend_v);
             p.gamma = vw.ln2g; p.beta = vw.ln2b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
             L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
         }
@@ -500,89 +579,32 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
             RUN_GEMM(L, s, p, "gemm.fc1");
         }
-        {
-            GemmParams p;
-            p.A = w.Hb; p.lda = Fn; p.W = vw.wfc2; p.ldw = Fn; p.bias = vw.bfc2; p.M = M; p.N = D; p.K = Fn;
-            p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = N; p.obs = nj; p.oro = 0;
-            RUN_GEMM(L, s, p, "gemm.fc2");
-        }
-        // ---- BERT layer beside it (bert_backbone.py:390-394) ----
-        if (!joint && !skip) {
-            const BertLayerW& bw = m->bert[i];
-            const int Mt = B * T;
-            {
-                GemmParams p;
-                p.A = w.Tn; p.lda = D; p.W = bw.wqkv; p.ldw = D; p.bias = bw.bqkv; p.M = Mt; p.N = 3 * D; p.K = D;
-                p.epi = 2; p.rpb = T; p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.H = H; p.Npad = 64; p.D = D;
-                RUN_GEMM(L, sa, p, "gemm.bert_qkv");
-            }
-            {
-                AttnParams p;
-                p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64;
-                L.run(sa, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, tramp<AttnParams, launch_attention>, &p);
-            }
-            {
-                GemmParams p;
-                p.A = w.To; p.lda = D; p.W = bw.wao; p.ldw = D; p.bias = bw.bao; p.M = Mt; p.N = D; p.K = D;
-                p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = T; p.obs = nj; p.oro = nv;
-                RUN_GEMM(L, sa, p, "gemm.bert_ao");
-            }
-            {
-                LnParams p;        // post-LN in place on the text rows
-                p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
-                p.gamma = bw.ln1g; p.beta = bw.ln1b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
-                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
-            }
-            {
-                GemmParams p;
-                p.A = w.Tn; p.lda = D; p.W = bw.wi; p.ldw = D; p.bias = bw.bi; p.M = Mt; p.N = Fn; p.K = D;
-                p.epi = 0; p.C = w.Th; p.ldc = Fn; p.act = 1;
-                RUN_GEMM(L, sa, p, "gemm.bert_i");
-            }
-            {
-                GemmParams p;
-                p.A = w.Th; p.lda = Fn; p.W = bw.wo; p.ldw = Fn; p.bias = bw.bo; p.M = Mt; p.N = D; p.K = Fn;
-                p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1; p.rpb = T; p.obs = nj; p.oro = nv;
-                RUN_GEMM(L, sa, p, "gemm.bert_o");
-            }
-            {
-                LnParams p;
-                p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
-                p.gamma = bw.ln2g; p.beta = bw.ln2b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
-                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
-            }
-        }
+        residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last);
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
-        bool is_cont = false;
-        for (int k = 0; k < m->cfg.n_cont; ++k) is_cont |= (m->cfg.cont_layers[k] == i);
-        if (is_cont) {
+        if (is_cont_layer(i)) {
             if (out->d_logits) {
-                if (!joint && fork) {   // needs this layer's text stream
-                    if (hipEventRecord(m->ev_bert[i], sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_bert[i], 0) != hipSuccess) return fail(UVL_EHIP, "bert event failed");
+                ContrastParams p;
+                if (!joint && !skip) {   // text token of THIS layer comes from the text branch's snapshot
+                    if (fork && hipStreamWaitEvent(s, m->ev_bert[i], 0) != hipSuccess) return fail(UVL_EHIP, "bert event failed");
+                    p.txt_snap = w.TxtSnap + (size_t)i * B * T * D;
                 }
-                struct CtCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; float* logits; int slot, B, skip; } cc{m, in, w, out->d_logits, cont_slot, B, skip};
-                L.run(s, "contrast", 0, 0, [](void* c, hipStream_t st) {
-                    auto* x = (CtCtx*)c;
-                    return launch_contrast(x->w.X, x->m->nj, x->m->nz, x->m->nx, x->m->nv, x->m->D, x->in->d_text_mask, x->m->T, x->m->cfg.txt_token_mean,
-                                           x->in->d_flag, x->m->logit_scale_bb, x->logits, x->slot, x->m->cfg.n_cont, x->B, x->skip, st);
-                }, &cc);
+                p.x = w.X; p.nj = nj; p.nz = nz; p.nx = nx; p.nv = nv; p.D = D; p.T = T; p.B = B;
+                p.text_mask = in->d_text_mask; p.flag = in->d_flag; p.logit_scale = m->logit_scale_bb;
+                p.mean_mode = m->cfg.txt_token_mean; p.skip_text = skip; p.logits = out->d_logits; p.slot = cont_slot; p.n_cont = m->cfg.n_cont;
+                p.part = pend_v.part; p.nsplit = pend_v.nsplit; p.part_rows = pend_v.rows; p.part_stride = pend_v.stride;   // read-only view
+                L.run(s, "contrast", 0, 0, tramp<ContrastParams, launch_contrast>, &p);
             }
             ++cont_slot;
-            if (out->d_logits && !joint && fork && i + 1 < m->nf) {
-                // the next BERT layer rewrites the text rows in place: it must not start before this read finished
-                if (hipEventRecord(m->ev_cont[i], s) != hipSuccess || hipStreamWaitEvent(sa, m->ev_cont[i], 0) != hipSuccess) return fail(UVL_EHIP, "cont event failed");
-            }
         }
         if (m->debug_stop_layer == i) {
-            if (!joint && fork) {       // text branch must be joined before the head reads the residual stream
-                if (hipEventRecord(m->ev_join, sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
-            }
+            if (!joint && fork && hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
             break;
         }
     }
     if (m->nf >= m->depth && fork && m->debug_stop_layer < 0) {   // no fusion layer at all: still join the text branch
-        if (hipEventRecord(m->ev_join, sa) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
+        if (hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
     }
+    if (pend_v.nsplit || pend_t.nsplit) return fail(UVL_ESTATE, "internal: split-K slabs left unconsumed");
 
     // ---- head (modality_adaptive_box_head.py:62-94) ----
     const int S = m->S, C = m->C;
@@ -661,6 +683,12 @@ extern "C" int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* 
     return UVL_OK;
 }
 
+extern "C" int uvl_tune_set(const char* key, int value) {
+    if (!key) return fail(UVL_EINVAL, "null key");
+    if (!strcmp(key, "gemm_cfg")) { uvl::g_tune_gemm_cfg = value; return UVL_OK; }
+    return fail(UVL_ENOTFOUND, "unknown tuning key '%s'", key);
+}
+
 extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!m || !key) return fail(UVL_EINVAL, "null argument");
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
@@ -704,6 +732,16 @@ extern "C" int uvl_linear(const void* d_x, const void* d_w, const float* d_bias,
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
     p.epi = out_f32 ? 1 : 0; p.C = d_y; p.ldc = N; p.act = act; p.accumulate = accumulate;
+    HIPCHK(launch_gemm(p, (hipStream_t)stream));
+    return UVL_OK;
+}
+
+/* tuning entry: y[sk] (f32 slabs [splitk][M,N]) = partial sums over K-range sk (bias in slab 0) */
+extern "C" int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, float* d_slabs, int M, int N, int K, int splitk, void* stream) {
+    if (!d_x || !d_w || !d_slabs || M <= 0) return fail(UVL_EINVAL, "uvl_linear_splitk: bad argument");
+    GemmParams p;
+    p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
+    p.epi = 1; p.C = d_slabs; p.ldc = N; p.splitk = splitk; p.part_stride = (size_t)M * N;
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
