@@ -39,7 +39,10 @@ def parse_args():
     ap.add_argument("--search-size", type=int, default=None)
     ap.add_argument("--mode", default="NLBBOX", choices=["BBOX", "NL", "NLBBOX"])
     ap.add_argument("--skip-text", action="store_true", help="BBOX mode only: do not run the text branch (configs[1])")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--launch", default="eager", choices=["eager", "graph"],
+                    help="eager: the frame's ~150 kernels are launched on two HIP streams each step (fastest on ROCm 7.2, where "
+                         "hipGraphLaunch costs more host time per node than a plain launch); graph: hipGraph replay")
+    ap.add_argument("--no-graph", action="store_true", help="alias of --launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--profile-json", default=None, help="also write the per-kernel breakdown to this file")
@@ -105,32 +108,27 @@ def main():
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     targs = (t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
 
-    if args.no_graph:
+    use_graph = args.launch == "graph" and not args.no_graph
+    if not use_graph:
         outs = eng.alloc_outputs(B)
-        step_fn = lambda: eng.forward(*targs, skip_text=skip_text, outs=outs)
+        step_fn = eng.make_eager_step(*targs, skip_text=skip_text, outs=outs)
     else:
         _, outs = eng.capture(*targs, skip_text=skip_text)
         step_fn = eng.replay
 
-    # RCCL all-gather of the per-shard boxes, double-buffered on the collective's own stream
-    gather_in = [torch.zeros(B, 4, device=dev) for _ in range(2)]
-    gather_out = [torch.zeros(world * B, 4, device=dev) for _ in range(2)]
-    pending = [None, None]
+    # RCCL all-gather of the per-shard boxes: rank r owns sequences [r*B, (r+1)*B); the gather of step i
+    # overlaps the forward pass of step i+1 (uvltrack_amd/shard.py, covered on CPU by tests/test_shard_gloo.py)
+    from uvltrack_amd.shard import BoxGatherer
+    gatherer = BoxGatherer(world * B, dev) if world > 1 else None
 
     def step(i):
         step_fn()
-        if world > 1:
-            k = i & 1
-            if pending[k] is not None:
-                pending[k].wait()
-            gather_in[k].copy_(outs["pred_boxes"].view(B, 4))
-            pending[k] = dist.all_gather_into_tensor(gather_out[k], gather_in[k], async_op=True)
+        if gatherer is not None:
+            gatherer.submit(i, outs["pred_boxes"].view(B, 4))
 
     def drain():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        if gatherer is not None:
+            gatherer.drain()
 
     for i in range(args.warmup):
         step(i)
@@ -184,7 +182,7 @@ def main():
             "config": {"workload": "UVLTrack-%s z%d/x%d/T%d %s%s, %d sequence(s)/GPU, batch shards + RCCL all-gather of boxes" % (
                 args.model, spec.template_size, spec.search_size, spec.text_len, args.mode, " (text branch skipped)" if skip_text else "", B),
                 "per_gpu_batch": B, "global_batch": B * world, "tokens_visual": spec.nv, "tokens_joint": spec.nj,
-                "gflop_per_frame": flops_frame / 1e9, "hipgraph": not args.no_graph, "parallelism": "dp%d" % world},
+                "gflop_per_frame": flops_frame / 1e9, "launch": "hipgraph" if use_graph else "eager-2-streams", "parallelism": "dp%d" % world},
             "frame_model_tflops": flops_frame * fps / 1e12,
             "frame_mfma_frac": flops_frame * fps / 1e12 / (PEAK_BF16_TFLOPS * world),
             "frame_hbm_frac": (weight_bytes * (args.steps / elapsed)) / 1e9 / PEAK_HBM_GBS,

@@ -1,0 +1,91 @@
+"""CPU checks of the drop-in surface: the C ABI exports, the registry/config contract, error behaviour."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from uvltrack_amd import _native, build
+    build.build()
+    return _native.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from uvltrack_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "uvltrack_hip.h")).read()
+    declared = set(re.findall(r"\b(uvl_[a-z0-9_]+)\s*\(", hdr)) - {"uvl_config", "uvl_inputs", "uvl_outputs", "uvl_model_t"}
+    assert declared, "header parse failed"
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(_native.EXPORTS), (declared ^ set(_native.EXPORTS))
+
+
+def test_config_struct_layout_matches_header(lib):
+    from uvltrack_amd import _native
+    assert ctypes.sizeof(_native.UvlConfig) == 4 * (5 + 64 + 12)
+    assert lib.uvl_version() >= 1
+
+
+def test_create_without_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is about the no-GPU container")
+    from uvltrack_amd import _native
+    from uvltrack_amd.spec import spec_tiny
+    cfg = _native.config_from_spec(spec_tiny())
+    assert not lib.uvl_create(ctypes.byref(cfg))
+    assert lib.uvl_last_error()
+
+
+def test_bad_geometry_is_rejected(lib):
+    from uvltrack_amd import _native
+    from uvltrack_amd.spec import spec_tiny
+    for kw in (dict(dim=96, heads=2), dict(head_dim=32), dict(text_len=80, max_pos=128)):
+        cfg = _native.config_from_spec(spec_tiny(**kw))
+        assert not lib.uvl_create(ctypes.byref(cfg))
+        assert b"must" in lib.uvl_last_error() or b"bad" in lib.uvl_last_error()
+
+
+def test_registry_and_build_model_surface():
+    from lib import registry
+    import lib.models as M
+    from lib.config.uvltrack import config as C
+    C.update_config_from_file(os.path.join(ROOT, "experiments", "uvltrack", "baseline_base.yaml"))
+    assert set(["uvltrack"]) <= set(registry.MODELS)
+    assert "modality_unified_feature_extractor" in registry.BACKBONES and "modality_adaptive_box_head" in registry.HEADS
+    model = M.uvltrack.build_model(C.cfg)               # the access path tracking/profile_model.py:66-67 uses
+    assert hasattr(model, "backbone") and hasattr(model, "box_head") and hasattr(model, "forward_test")
+    from uvltrack_amd.spec import state_dict_schema
+    sch = state_dict_schema(model.spec)
+    sd = model.state_dict()
+    assert set(sd) == set(sch) and all(tuple(sd[k].shape) == tuple(sch[k]) for k in sch)
+    r = registry.Registry()
+    r.register("a", 1)
+    with pytest.raises(AssertionError):
+        r.register("a", 2)
+
+
+def test_unknown_yaml_key_raises_value_error(tmp_path):
+    from lib.config.uvltrack import config as C
+    p = tmp_path / "bad.yaml"
+    p.write_text("MODEL:\n  NOT_A_KEY: 1\n")
+    with pytest.raises(ValueError, match="not exist in config.py"):
+        C.update_config_from_file(str(p))
+
+
+def test_forward_test_on_cpu_tensors_raises():
+    import torch
+    import lib.models as M
+    from lib.config.uvltrack import config as C
+    from lib.utils.misc import NestedTensor
+    from uvltrack_amd._native import NativeLibraryError
+    C.update_config_from_file(os.path.join(ROOT, "experiments", "uvltrack", "baseline_base.yaml"))
+    model = M.uvltrack.build_model(C.cfg)
+    text = NestedTensor(torch.ones(1, 40).long(), torch.ones(1, 40).bool())
+    with pytest.raises(NativeLibraryError):
+        model.forward_test(torch.zeros(1, 3, 128, 128), torch.zeros(1, 3, 256, 256), text, torch.zeros(1, 3, 768), torch.ones(1).long())

@@ -58,7 +58,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     while (rem >= p.rpb) { rem -= p.rpb; ++b; }
                     if (EPI == EPI_F32) {
                         if (p.addtab) v += p.addtab[(size_t)rem * p.N + col];
-                        float* dst = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + col;
+                        float* dst = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
                         if (p.accumulate) v += *dst;
                         *dst = v;
                     } else {
@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
+__device__ uint32_t g_zero_page[64];      // 256 zero bytes: DMA source of out-of-image conv taps (zero padding)
+
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
     constexpr int BK = 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -212,11 +214,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
     constexpr int ROWS = BM + BN;                    // stage = A rows then W rows, 128 B each
     constexpr int STAGE = ROWS * 128;
     constexpr int LPT = ROWS / 32;                   // DMA instructions per wave per tile (each fills 8 rows)
-    static_assert(WGM * WGN == 4 && BM % 16 == 0 && LPT * (NS - 2) <= 63, "geometry");
+    constexpr int LPT_A = BM / 32;                   // the first LPT_A instructions of a wave fill A rows, the rest W rows
+    static_assert(WGM * WGN == 4 && BM % 32 == 0 && LPT * (NS - 2) <= 63, "geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
+    const int g = CONV ? blockIdx.z : 0;             // conv tower (group)
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int nt = (idx / MT) * 8 + xcd, mt = idx % MT;
@@ -229,24 +233,52 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
     const int kbase = sk * kspan;
     // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + 4*i), +8)
     const bf16_t* src[LPT];
+    int a_i[LPT_A], a_j[LPT_A];                              // conv: pixel of the A row this lane fetches
+    const int convF = p.conv_F, cin_g = p.cin_g, lda = p.lda;
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int r = 8 * (wave + 4 * i) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);        // logical 16-byte chunk that belongs at this physical slot
-        if (r < BM) {
+        if (i < LPT_A) {
             int gm = m0 + r;
             gm = gm < p.M ? gm : p.M - 1;
-            src[i] = p.A + (size_t)gm * p.lda + kbase + chunk * 8;
+            if (CONV) {
+                const int S = convF * convF;
+                const int b = gm / S, pix = gm - b * S;
+                a_i[i] = pix / convF;
+                a_j[i] = pix - a_i[i] * convF;
+                const int goff = g == 0 ? p.a_goff[0] : g == 1 ? p.a_goff[1] : g == 2 ? p.a_goff[2] : p.a_goff[3];
+                src[i] = p.A + (size_t)b * S * lda + goff + chunk * 8;       // + (pixel row) * lda + channel, per K tile
+            } else {
+                src[i] = p.A + (size_t)gm * lda + kbase + chunk * 8;
+            }
         } else {
-            src[i] = p.W + (size_t)(n0 + r - BM) * p.ldw + kbase + chunk * 8;
+            src[i] = p.W + ((size_t)g * p.N + n0 + r - BM) * p.ldw + kbase + chunk * 8;
         }
     }
     auto issue = [&](int kt) __attribute__((always_inline)) {
         char* st = smem + (kt % NS) * STAGE;
+        int tap_di = 0, tap_dj = 0, c0 = 0;
+        if (CONV) {                                           // K index = tap * cin_g + channel; a 64-wide tile never straddles taps
+            const int k0 = kbase + kt * BK;
+            const int tap = k0 / cin_g;
+            c0 = k0 - tap * cin_g;
+            tap_di = tap / 3 - 1;
+            tap_dj = tap % 3 - 1;
+        }
 #pragma unroll
-        for (int i = 0; i < LPT; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
+        for (int i = 0; i < LPT; ++i) {
+            const bf16_t* gp;
+            if (CONV && i < LPT_A) {
+                const int ii = a_i[i] + tap_di, jj = a_j[i] + tap_dj;
+                const bool ok = (unsigned)ii < (unsigned)convF && (unsigned)jj < (unsigned)convF;
+                gp = ok ? src[i] + (size_t)(ii * convF + jj) * lda + c0 : reinterpret_cast<const bf16_t*>(g_zero_page);
+            } else {
+                gp = src[i] + kt * BK;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                              (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -288,15 +320,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, 0, sk);
+    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, g, sk);
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false>
 static hipError_t launch_glds(const GemmParams& p, hipStream_t s) {
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
     const int nblk = 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * 128;
-    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS>;
+    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -304,9 +336,9 @@ static hipError_t launch_glds(const GemmParams& p, hipStream_t s) {
         attr_done = true;
     }
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS);
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
     g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -362,6 +394,7 @@ static int pick_plain_cfg(const GemmParams& p) {
     // measured on MI355X (tools/gemm_bench.py, profiles/): co-resident workgroups matter more than ring depth, so
     // the 2-stage ring wins everywhere; small M keeps 64x64 tiles for parallelism, large M takes 64x128 / 128x64
     const long t64 = (long)((p.M + 63) / 64) * (p.N / 64);
+    if (t64 < 1024) return 4;                       // 64x64, 3 stages: batch-1 panels stream from HBM, one more tile in flight pays
     if (t64 < 2048) return 7;                       // 64x64, 2 stages
     if (p.N % 128 == 0) return 10;                  // 64x128, 2 stages
     return 9;                                       // 128x64, 2 stages
@@ -386,11 +419,17 @@ static hipError_t launch_epi(const GemmParams& p, int groups, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.K % 64 != 0 || p.M <= 0 || p.N <= 0 || p.splitk < 1) return hipErrorInvalidValue;
-    if (p.splitk > 1 && (p.epi != EPI_F32 || p.accumulate || p.conv_F > 0 || p.N % 64 != 0 || (p.K / 64) % p.splitk != 0 || use_v1()))
+    if (p.splitk > 1 && (p.epi != EPI_F32 || p.accumulate || p.N % 64 != 0 || (p.K / 64) % p.splitk != 0 || use_v1()))
         return hipErrorInvalidValue;      // partial slabs: f32 store epilogue of the pipelined kernel only
     const int groups = p.groups > 0 ? p.groups : 1;
     if (p.conv_F > 0) {
-        if (p.epi != EPI_BF16 || p.cin_g % 64 != 0) return hipErrorInvalidValue;
+        if (p.cin_g % 64 != 0) return hipErrorInvalidValue;
+        if (!use_v1() && p.N % 64 == 0) {          // implicit GEMM on the LDS-DMA pipeline (optionally split-K into f32 slabs)
+            if (p.epi == EPI_BF16) return launch_glds<64, 64, 2, 2, EPI_BF16, 3, true>(p, s);
+            if (p.epi == EPI_F32) return launch_glds<64, 64, 2, 2, EPI_F32, 3, true>(p, s);
+            return hipErrorInvalidValue;
+        }
+        if (p.epi != EPI_BF16) return hipErrorInvalidValue;
         return launch_epi<EPI_BF16, true>(p, groups, s);
     }
     switch (p.epi) {

@@ -64,7 +64,7 @@ hipError_t launch_bert_embed(const int64_t* ids, const float* word, const float*
 // cat_mask (extractor.py:43-50) + cls-token rows: per-key additive terms and the [cls] row of the residual stream.
 hipError_t launch_setup(const uint8_t* text_mask, const int64_t* flag, const float* cls_token, float* x,
                         float* key_add, float* bert_add, int B, int nz, int nv, int nj, int npad, int T, int D,
-                        int skip_text, hipStream_t s);
+                        int skip_text, int what /* 1 = key_add + cls rows, 2 = BERT mask */, hipStream_t s);
 
 // ModalityUnifiedFeatureExtractor.contractive_learning (extractor.py:85-93) for one layer.
 struct ContrastParams {
@@ -98,6 +98,9 @@ struct HeadTailParams {
     float *o_cls = nullptr, *o_cls_test = nullptr, *o_bbox_map = nullptr, *o_pred = nullptr; int64_t* o_argmax = nullptr;
 };
 hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s);
+
+// out = relu(sum of split-K slabs) as bf16 (conv towers)
+hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_t* out, size_t n, hipStream_t s);
 
 // weight packing
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);

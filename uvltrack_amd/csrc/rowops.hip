@@ -218,9 +218,14 @@ hipError_t launch_bert_embed(const int64_t* ids, const float* word, const float*
 __global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ tmask, const int64_t* __restrict__ flag,
                                                     const float* __restrict__ cls_token, float* __restrict__ x,
                                                     float* __restrict__ key_add, float* __restrict__ bert_add,
-                                                    int nz, int nv, int nj, int npad, int T, int D, int skip_text) {
+                                                    int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what) {
     const int b = blockIdx.x;
     const int fl = (int)flag[b];
+    if (what & 2) {
+        for (int t = threadIdx.x; t < 64; t += 256)
+            bert_add[(size_t)b * 64 + t] = (t < T) ? (tmask[(size_t)b * T + t] ? 0.f : -10000.f) : -INFINITY;
+    }
+    if (!(what & 1)) return;
     for (int i = threadIdx.x; i < npad; i += 256) {
         float a;
         if (i < 1 + nz) a = (fl == 1) ? -1e10f : 0.f;                 // cls + template keys
@@ -229,16 +234,13 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ 
         else a = -INFINITY;
         key_add[(size_t)b * npad + i] = a;
     }
-    if (!skip_text)
-        for (int t = threadIdx.x; t < 64; t += 256)
-            bert_add[(size_t)b * 64 + t] = (t < T) ? (tmask[(size_t)b * T + t] ? 0.f : -10000.f) : -INFINITY;
     for (int c = threadIdx.x; c < D; c += 256) x[(size_t)b * nj * D + c] = cls_token[c];
 }
 
 hipError_t launch_setup(const uint8_t* text_mask, const int64_t* flag, const float* cls_token, float* x,
                         float* key_add, float* bert_add, int B, int nz, int nv, int nj, int npad, int T, int D,
-                        int skip_text, hipStream_t s) {
-    hipLaunchKernelGGL(setup_kernel, dim3(B), dim3(256), 0, s, text_mask, flag, cls_token, x, key_add, bert_add, nz, nv, nj, npad, T, D, skip_text);
+                        int skip_text, int what, hipStream_t s) {
+    hipLaunchKernelGGL(setup_kernel, dim3(B), dim3(256), 0, s, text_mask, flag, cls_token, x, key_add, bert_add, nz, nv, nj, npad, T, D, skip_text, what);
     return hipGetLastError();
 }
 
@@ -552,6 +554,31 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) 
 
 hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s) {
     hipLaunchKernelGGL(head_tail_kernel, dim3(p.B), dim3(256), (7 * p.c8 + 8) * sizeof(float), s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fold the split-K f32 slabs of a conv layer: out = relu(sum_s slab[s]) as bf16 (bias was added into slab 0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_relu_kernel(const float* __restrict__ slabs, int nsplit, size_t stride,
+                                                        bf16_t* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 sl[8];
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp)
+        sl[sp] = (sp < nsplit) ? *reinterpret_cast<const float4*>(slabs + (size_t)sp * stride + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a = sl[0];
+#pragma unroll
+    for (int sp = 1; sp < 8; ++sp) { a.x += sl[sp].x; a.y += sl[sp].y; a.z += sl[sp].z; a.w += sl[sp].w; }
+    uint2 w;
+    w.x = pack_bf16x2(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f));
+    w.y = pack_bf16x2(fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+    *reinterpret_cast<uint2*>(out + i) = w;
+}
+hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_t* out, size_t n, hipStream_t s) {
+    if (nsplit < 1 || nsplit > 8 || n % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(slab_relu_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, slabs, nsplit, stride, out, n);
     return hipGetLastError();
 }
 

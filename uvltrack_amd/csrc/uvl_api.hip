@@ -86,8 +86,9 @@ struct uvl_model {
     std::vector<hipEvent_t> ev_bert, ev_cont;
     // graph
     hipStream_t cap_stream = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph3[3] = {nullptr, nullptr, nullptr};          // T, V1, V2 (or only [1] = whole frame without text)
+    hipGraphExec_t graph_exec3[3] = {nullptr, nullptr, nullptr};
+    bool graph_has_text = false;
     // profile of the last profiled call
     std::vector<ProfEntry> prof;
     int debug_stop_layer = -1;          // >= 0: leave the layer loop after this layer (tests localise errors with it)
@@ -133,8 +134,10 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
 extern "C" void uvl_destroy(uvl_model_t* m) {
     if (!m) return;
     hipDeviceSynchronize();
-    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) hipGraphDestroy(m->graph);
+    for (int k = 0; k < 3; ++k) {
+        if (m->graph_exec3[k]) hipGraphExecDestroy(m->graph_exec3[k]);
+        if (m->graph3[k]) hipGraphDestroy(m->graph3[k]);
+    }
     if (m->cap_stream) hipStreamDestroy(m->cap_stream);
     for (auto& kv : m->raw) if (kv.second.d) hipFree(kv.second.d);
     for (void* p : m->owned) hipFree(p);
@@ -331,13 +334,17 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
     }
     for (int l = 0; l < 4; ++l)
         for (int t = 0; t < 4; ++t) P.drop(std::string("box_head.") + towers[t] + "." + std::to_string(l) + ".0.weight");
-    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    for (int k = 0; k < 3; ++k) {
+        if (m->graph_exec3[k]) { hipGraphExecDestroy(m->graph_exec3[k]); m->graph_exec3[k] = nullptr; }
+        if (m->graph3[k]) { hipGraphDestroy(m->graph3[k]); m->graph3[k] = nullptr; }
+    }
     m->finalized = true;
     return UVL_OK;
 }
 
 // ---- workspace ------------------------------------------------------------------------------------
 #define UVL_SKMAX 4
+#define UVL_CONV_SKMAX 8
 
 // Split-K factor for an `x += A W^T` GEMM that would otherwise leave most CUs idle (batch-1 shapes): each split
 // writes an f32 slab, the consuming LayerNorm / contrast kernel adds the slabs on read (deterministic, no atomics).
@@ -357,7 +364,7 @@ struct Pending { const float* part = nullptr; int nsplit = 0, rows = 0; size_t s
 struct Workspace {
     float* X; bf16_t *Xn, *Q, *K, *Vt, *O, *Hb, *P;
     bf16_t *Tn, *Tq, *Tk, *Tvt, *To, *Th;
-    float *key_add, *bert_add, *cont, *bbox, *Part, *PartT, *TxtSnap;
+    float *key_add, *bert_add, *cont, *bbox, *Part, *PartT, *TxtSnap, *ConvPart;
     bf16_t *G0, *G1, *G2, *G3, *G4;
     size_t total;
 };
@@ -385,6 +392,7 @@ static Workspace carve(const uvl_model* m, int B, char* base) {
     w.Part = (float*)take((size_t)UVL_SKMAX * B * nj * D * 4);
     w.PartT = (float*)take((size_t)UVL_SKMAX * B * T * D * 4);
     w.TxtSnap = (float*)take((size_t)(m->nf > 0 ? m->nf : 1) * B * T * D * 4);
+    w.ConvPart = (float*)take((size_t)UVL_CONV_SKMAX * B * S * 4 * C * 4);
     w.cont = (float*)take(B * S * 3 * 4);
     w.bbox = (float*)take(B * S * 4 * 4);
     w.G0 = (bf16_t*)take(B * S * 2 * D * 2);
@@ -402,11 +410,16 @@ extern "C" size_t uvl_workspace_bytes(const uvl_model_t* m, int batch) {
 }
 
 // ---- the frame -----------------------------------------------------------------------------------
+// The frame is walked in full on the host every time (so split-K / pending-slab state evolves identically), but only
+// the launches of the enabled parts are issued: eager runs enable everything, graph capture records one part per graph.
+enum { PART_TEXT = 1, PART_V1 = 2, PART_V2 = 4, PART_ALL = 7 };
+
 struct Launcher {
     Profiler* prof;
+    int parts = PART_ALL, cur = PART_V1;
     int err = 0;
     void run(hipStream_t s, const char* what, double flops, double bytes, hipError_t (*fn)(void*, hipStream_t), void* ctx) {
-        if (err) return;
+        if (err || !(parts & cur)) return;
         Profiler::Rec r{};
         if (prof) {
             hipEventCreate(&r.a); hipEventCreate(&r.b);
@@ -428,7 +441,8 @@ static hipError_t tramp(void* ctx, hipStream_t s) { return F(*(const P_*)ctx, s)
 #define RUN_GEMM(L, s, p, what) (L).run((s), (what), 2.0 * (p).M * (p).N * (p).K * ((p).groups > 0 ? (p).groups : 1), \
     2.0 * ((double)(p).M * (p).K + (double)(p).N * (p).K * ((p).groups > 0 ? (p).groups : 1)), tramp<GemmParams, launch_gemm>, &(p))
 
-static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, hipStream_t s, Profiler* prof) {
+static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, hipStream_t s, Profiler* prof,
+                       int parts = PART_ALL) {
     if (!m || !in || !out) return fail(UVL_EINVAL, "null argument");
     if (!m->finalized) return fail(UVL_ESTATE, "uvl_finalize_weights has not been called");
     const int B = in->batch;
@@ -442,19 +456,27 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
 
     const int D = m->D, H = m->H, nz = m->nz, nx = m->nx, nv = m->nv, nj = m->nj, npad = m->npad, T = m->T, Fn = m->ffn;
     Launcher L{prof};
-    const bool fork = !skip && !prof && m->nf > 0;
+    L.parts = parts;
+    // eager full-frame runs fork the text branch onto the library's second stream and join with events; a partial walk
+    // (graph capture of one part) launches on `s` only and leaves the cross-part ordering to uvl_graph_launch
+    const bool fork = !skip && !prof && m->nf > 0 && parts == PART_ALL;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
 
-    // -- setup: masks, cls rows
-    struct SetupCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B, skip; } sc{m, in, w, B, skip};
-    L.run(s, "setup", 0, 0, [](void* c, hipStream_t st) {
+    // -- setup: masks, cls rows (visual part) / BERT additive mask (text part)
+    struct SetupCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B, skip, what; } sc{m, in, w, B, skip, 1};
+    auto setup_fn = [](void* c, hipStream_t st) {
         auto* x = (SetupCtx*)c;
         return launch_setup(x->in->d_text_mask, x->in->d_flag, x->m->cls_token, x->w.X, x->w.key_add, x->w.bert_add, x->B,
-                            x->m->nz, x->m->nv, x->m->nj, x->m->npad, x->m->T, x->m->D, x->skip, st);
-    }, &sc);
+                            x->m->nz, x->m->nv, x->m->nj, x->m->npad, x->m->T, x->m->D, x->skip, x->what, st);
+    };
     if (fork) {
         if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(sa, m->ev_fork, 0) != hipSuccess) return fail(UVL_EHIP, "fork failed");
     }
+    L.cur = PART_V1;
+    L.run(s, "setup", 0, 0, setup_fn, &sc);
+    SetupCtx sct = sc;
+    sct.what = 2;
+    if (!skip) { L.cur = PART_TEXT; L.run(sa, "setup", 0, 0, setup_fn, &sct); L.cur = PART_V1; }
     // -- text branch (extractor.py:54,62): embedding + the first nf BERT layers depend on the text only, so the whole
     //    chain is enqueued up front on its own stream; layers whose output the contrastive logits need leave a snapshot
     Pending pend_t;
@@ -475,13 +497,21 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     };
     if (!skip) {
         struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
+        L.cur = PART_TEXT;
         L.run(sa, "bert_embed", 0, 0, [](void* c, hipStream_t st) {
             auto* x = (BeCtx*)c;
             return launch_bert_embed(x->in->d_text_ids, x->m->word, x->m->pos, x->m->type0, x->m->emb_g, x->m->emb_b, x->w.X, x->m->nj, x->m->nv,
                                      x->w.Tn, x->B, x->m->T, x->m->D, x->m->cfg.vocab, st);
         }, &bc);
-        const int last_bert = (m->debug_stop_layer >= 0 && m->debug_stop_layer < m->nf - 1) ? m->debug_stop_layer : m->nf - 1;
-        for (int i = 0; i <= last_bert; ++i) {        // BertLayer.forward (bert_backbone.py:390-394)
+        L.cur = PART_V1;
+    }
+    const int last_bert = skip ? -1 : ((m->debug_stop_layer >= 0 && m->debug_stop_layer < m->nf - 1) ? m->debug_stop_layer : m->nf - 1);
+    int text_err = 0;
+    // one BERT layer (BertLayer.forward, bert_backbone.py:390-394); launched interleaved with the visual layers so both
+    // hardware queues are fed in step (the host enqueues ~3.5 us per launch)
+    auto text_layer = [&](int i) {
+            const int saved_part = L.cur;
+            L.cur = PART_TEXT;
             const BertLayerW& bw = m->bert[i];
             const int Mt = B * T;
             {
@@ -519,11 +549,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
             }
             if (fork && is_cont_layer(i) && out->d_logits) {
-                if (hipEventRecord(m->ev_bert[i], sa) != hipSuccess) return fail(UVL_EHIP, "bert event failed");
+                if (hipEventRecord(m->ev_bert[i], sa) != hipSuccess) text_err = fail(UVL_EHIP, "bert event failed");
             }
-        }
-        if (fork && hipEventRecord(m->ev_join, sa) != hipSuccess) return fail(UVL_EHIP, "join record failed");
-    }
+        if (i == last_bert && fork && hipEventRecord(m->ev_join, sa) != hipSuccess) text_err = fail(UVL_EHIP, "join record failed");
+        L.cur = saved_part;
+    };
+    if (last_bert < 0 && fork && hipEventRecord(m->ev_join, sa) != hipSuccess) return fail(UVL_EHIP, "join record failed");
     // -- patch embed (mae_vit.py:203-215)
     struct ImCtx { const uvl_inputs* in; Workspace w; int B, hz, hx; } ic{in, w, B, m->cfg.template_size, m->cfg.search_size};
     L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
@@ -542,8 +573,9 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         const int M = B * N;
         const VitBlockW& vw = m->vit[i];
         const bool last = (i == m->depth - 1) || (m->debug_stop_layer == i);
-        if (joint && i == m->nf && fork) {       // first fusion layer reads the text rows
-            if (hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
+        if (joint && i == m->nf) {               // first fusion layer reads the text rows
+            if (!skip) L.cur = PART_V2;
+            if (fork && hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
         }
         // ---- ViT block (block.py:29-32) ----
         {
@@ -580,10 +612,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             RUN_GEMM(L, s, p, "gemm.fc1");
         }
         residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last);
+        if (i <= last_bert) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
         if (is_cont_layer(i)) {
             if (out->d_logits) {
                 ContrastParams p;
+                if (!skip) L.cur = PART_V2;    // first consumer of text data on the visual side: everything from here is part V2
                 if (!joint && !skip) {   // text token of THIS layer comes from the text branch's snapshot
                     if (fork && hipStreamWaitEvent(s, m->ev_bert[i], 0) != hipSuccess) return fail(UVL_EHIP, "bert event failed");
                     p.txt_snap = w.TxtSnap + (size_t)i * B * T * D;
@@ -606,6 +640,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     }
     if (pend_v.nsplit || pend_t.nsplit) return fail(UVL_ESTATE, "internal: split-K slabs left unconsumed");
 
+    if (!skip) L.cur = PART_V2;
     // ---- head (modality_adaptive_box_head.py:62-94) ----
     const int S = m->S, C = m->C;
     float* cont = out->d_cont_score ? out->d_cont_score : w.cont;
@@ -628,10 +663,25 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         const ConvLayerW& cw = m->conv[l];
         GemmParams p;
         p.A = cin[l]; p.lda = in_ld[l]; p.W = cw.w; p.ldw = 9 * cw.cin; p.bias = cw.b;
-        p.M = B * S; p.N = cw.cout; p.K = 9 * cw.cin; p.epi = 0; p.C = cout[l]; p.ldc = 4 * cw.cout; p.act = 2;
+        p.M = B * S; p.N = cw.cout; p.K = 9 * cw.cin; p.ldc = 4 * cw.cout;
         p.groups = 4; p.conv_F = m->F; p.cin_g = cw.cin;
         for (int g = 0; g < 4; ++g) p.a_goff[g] = (l == 0) ? ((g == 0 && m->cfg.cls_tokenize) ? D : 0) : g * cw.cin;
-        RUN_GEMM(L, s, p, "conv3x3");
+        // few output tiles and a long K (9*Cin): split K into f32 slabs, folded (+ReLU) by a small kernel
+        const long tiles = (long)((p.M + 63) / 64) * (p.N / 64 > 0 ? p.N / 64 : 1) * 4;
+        const int nk = p.K / 64;
+        int sk = 1;
+        if (p.N % 64 == 0)
+            for (int c = 2; c <= 8 && c <= UVL_CONV_SKMAX; ++c)
+                if (nk % c == 0 && nk / c >= 6 && tiles * c <= 768) sk = c;
+        if (sk > 1) {
+            p.epi = 1; p.C = w.ConvPart; p.splitk = sk; p.part_stride = (size_t)p.M * p.ldc;
+            RUN_GEMM(L, s, p, "conv3x3");
+            struct RCtx { const float* slabs; int sk; size_t stride; bf16_t* out; size_t n; } rc{w.ConvPart, sk, p.part_stride, cout[l], p.part_stride};
+            L.run(s, "conv_fold", 0, 0, [](void* c, hipStream_t st) { auto* x = (RCtx*)c; return launch_slab_relu(x->slabs, x->sk, x->stride, x->out, x->n, st); }, &rc);
+        } else {
+            p.epi = 0; p.C = cout[l]; p.act = 2;
+            RUN_GEMM(L, s, p, "conv3x3");
+        }
     }
     {
         HeadTailParams p;
@@ -696,32 +746,61 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
 }
 
 // ---- hipGraph --------------------------------------------------------------------------------------
+// A multi-stream graph replays badly on ROCm 7.2 (the executor enqueues one branch after the other, so the second
+// branch starts hundreds of microseconds late); single-stream graphs replay at GPU speed.  The frame is therefore
+// recorded as up to three single-stream graphs: T (text branch) replayed on the library's second stream, V1 (visual
+// stream up to the first consumer of text data) and V2 (the rest) replayed on the caller's stream, ordered by events.
+static void graph_free(uvl_model* m) {
+    for (int k = 0; k < 3; ++k) {
+        if (m->graph_exec3[k]) { hipGraphExecDestroy(m->graph_exec3[k]); m->graph_exec3[k] = nullptr; }
+        if (m->graph3[k]) { hipGraphDestroy(m->graph3[k]); m->graph3[k] = nullptr; }
+    }
+}
+
 extern "C" int uvl_graph_release(uvl_model_t* m) {
     if (!m) return fail(UVL_EINVAL, "null model");
-    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+    graph_free(m);
     return UVL_OK;
 }
 
 extern "C" int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes) {
-    if (!m) return fail(UVL_EINVAL, "null model");
-    uvl_graph_release(m);
+    if (!m || !in) return fail(UVL_EINVAL, "null argument");
+    graph_free(m);
     if (!m->cap_stream) HIPCHK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
-    int rc = run_forward(m, in, out, d_ws, ws_bytes, m->cap_stream, nullptr);
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
-    if (rc) { if (g) hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess) return fail(UVL_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    m->graph = g;
-    HIPCHK(hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0));
+    const bool text = !in->skip_text && m->nf >= 0;
+    const int part_of[3] = {PART_TEXT, PART_V1, PART_V2};
+    for (int k = 0; k < 3; ++k) {
+        if (!text && k != 1) continue;
+        const int parts = text ? part_of[k] : PART_ALL;       // no text branch: one graph holds the whole frame
+        HIPCHK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+        int rc = run_forward(m, in, out, d_ws, ws_bytes, m->cap_stream, nullptr, parts);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); graph_free(m); return rc; }
+        if (e != hipSuccess) { graph_free(m); return fail(UVL_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
+        m->graph3[k] = g;
+        HIPCHK(hipGraphInstantiate(&m->graph_exec3[k], g, nullptr, nullptr, 0));
+    }
+    m->graph_has_text = text;
     return UVL_OK;
 }
 
 extern "C" int uvl_graph_launch(uvl_model_t* m, void* stream) {
-    if (!m || !m->graph_exec) return fail(UVL_ESTATE, "no captured graph");
-    HIPCHK(hipGraphLaunch(m->graph_exec, (hipStream_t)stream));
+    if (!m || !m->graph_exec3[1]) return fail(UVL_ESTATE, "no captured graph");
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->graph_has_text) {
+        HIPCHK(hipGraphLaunch(m->graph_exec3[1], s));
+        return UVL_OK;
+    }
+    // the text graph may start once everything queued on the caller's stream so far (previous frame, input copies) is done
+    HIPCHK(hipEventRecord(m->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(m->aux, m->ev_fork, 0));
+    HIPCHK(hipGraphLaunch(m->graph_exec3[0], m->aux));
+    HIPCHK(hipEventRecord(m->ev_join, m->aux));
+    HIPCHK(hipGraphLaunch(m->graph_exec3[1], s));
+    HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
+    HIPCHK(hipGraphLaunch(m->graph_exec3[2], s));
     return UVL_OK;
 }
 
