@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="alias of --launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--profile-json", default=None, help="also write the per-kernel breakdown to this file")
     return ap.parse_args()
 
@@ -63,14 +64,26 @@ def cpu_baseline(spec, args, flags):
     sd = wg.make_state_dict(spec, 0, include_unused=False)
     inp = wg.make_inputs(spec, batch=1, seed=100, flags=flags[:1])
     run = lambda: O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"])
-    run()
-    n = max(1, args.cpu_frames)
-    t0 = time.perf_counter()
-    for _ in range(n):
+    # OpenBLAS with one thread per host core (256 on the GPU box) thrashes on these small GEMMs: cap the pool
+    threads = min(os.cpu_count() or 1, args.cpu_threads)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter, threads = None, os.cpu_count()
+    try:
         run()
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d frames of the same workload (batch 1, fp32 numpy/OpenBLAS oracle, %d threads)" % (n, os.cpu_count())}
+        n = max(1, args.cpu_frames)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run()
+        dt = time.perf_counter() - t0
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d frames of the same workload (batch 1, fp32 numpy/OpenBLAS oracle, %d BLAS threads of %d host cores)" % (
+                n, threads, os.cpu_count())}
 
 
 def main():
@@ -167,10 +180,21 @@ def main():
         dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = dom["ms"] / max(dom["launches"], 1)
         achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12 if dom["flops"] > 0 else 0.0
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see
+        # profiles/*_pmc_summary.md); null when no PMC pass of this kernel instantiation has been committed
+        traffic = None
+        try:
+            pdir = os.path.join(ROOT, "profiles")
+            for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")):
+                tb = json.load(open(os.path.join(pdir, fn))).get("bytes_per_launch", {})
+                if dom_name in tb and B == 1 and args.model == "B":
+                    traffic = tb[dom_name]
+        except OSError:
+            pass
         roofline = {"bound": "mfma", "kernel": dom_name, "sites": sorted(set(dom["sites"])), "launches_per_frame": dom["launches"],
                     "avg_launch_us": avg_ms * 1e3, "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                    "traffic": None}
+                    "traffic": traffic}
         flops_frame = spec.flops_per_frame(skip_text=skip_text)
         weight_bytes = 2.0 * sum(int(np.prod(s)) for n, s in __import__("uvltrack_amd.spec", fromlist=["x"]).state_dict_schema(spec, False).items()
                                  if len(s) >= 2 and "embeddings" not in n and "pos_embed" not in n)

@@ -1,0 +1,73 @@
+"""Condense the rocprofv3 outputs a gpurun call left under gpurun_out/<tag>/ into the small, committed files of
+profiles/: the --stats CSV, a per-kernel PMC summary (MFMA busy, HBM bytes) and the traffic table bench.py reads.
+Usage: python tools/make_profiles.py <gpurun_out/tag> <round-prefix, e.g. r01>"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    """'void uvl::gemm_glds_kernel<64, 64, 2, 2, 1, 3, false>(uvl::GemmParams)' -> 'gemm_glds_kernel<64,64,2,2,1,3,0>'"""
+    n = name.split("(")[0].replace("void ", "").replace("uvl::", "").replace(" ", "")
+    return n.replace("false", "0").replace("true", "1")
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        d[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        n[k].add(r["Dispatch_Id"])
+    return d, {k: len(v) for k, v in n.items()}
+
+
+def main(src, tag):
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    st = os.path.join(src, "stats", "bench_kernel_stats.csv")
+    stats = {}
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(out, tag + "_bench_kernel_stats.csv"))
+        for r in csv.DictReader(open(st)):
+            stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+    lines = ["# %s -- rocprofv3 PMC summary per kernel (bench.py default workload: UVLTrack-B z256/x256/T40, batch 1)" % tag, "",
+             "Separate `--pmc` passes (MFMA / FETCH_SIZE / WRITE_SIZE), each with `--kernel-trace` only.  `avg us` is from the",
+             "un-instrumented `--kernel-trace --stats` run (PMC passes serialise and slow the kernels).  HBM bytes per launch =",
+             "2 x FETCH_SIZE + WRITE_SIZE (KB): MI355X_MICROARCH.md says FETCH_SIZE reports half of a wide coalesced stream.",
+             "MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (avg duration x 2.1 GHz x 1024 SIMDs).", "",
+             "| kernel | launches/run | avg us | % of GPU time | MFMA busy cyc/launch | MFMA util % | FETCH_SIZE KB | WRITE_SIZE KB | HBM MB/launch (corrected) |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    traffic = {}
+    m, nm = agg(os.path.join(src, "pmc_mfma", "bench_counter_collection.csv"))
+    f, nf = agg(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"))
+    w, nw = agg(os.path.join(src, "pmc_write", "bench_counter_collection.csv"))
+    for k in sorted(stats, key=lambda k: -stats[k][2]):
+        if not re.match(r"(gemm|attn|ln_|contrast|head|im2row|bert|setup|slab)", k):
+            continue
+        calls, avg_us, pct = stats[k]
+        busy = m.get(k, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(nm.get(k, 1), 1)
+        fe = f.get(k, {}).get("FETCH_SIZE", 0.0) / max(nf.get(k, 1), 1)
+        wr = w.get(k, {}).get("WRITE_SIZE", 0.0) / max(nw.get(k, 1), 1)
+        hbm = (2 * fe + wr) * 1024
+        util = 100.0 * busy / (avg_us * 1e-6 * 2.1e9 * 1024) if avg_us > 0 else 0.0
+        traffic[k] = hbm
+        lines.append("| `%s` | %d | %.2f | %.1f | %.0f | %.1f | %.0f | %.0f | %.2f |" % (k, calls, avg_us, pct, busy, util, fe, wr, hbm / 1e6))
+    open(os.path.join(out, tag + "_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py` (%s)" % tag,
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", "bytes_per_launch": traffic},
+              open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
+    for fn in os.listdir(src):
+        if fn.startswith("bench_") and fn.endswith(".json") and "profile" not in fn:
+            shutil.copy(os.path.join(src, fn), os.path.join(out, tag + "_" + fn))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
