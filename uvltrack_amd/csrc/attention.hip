@@ -5,37 +5,52 @@
 // (bert_backbone.py:311-324: scores/sqrt(64) + (1-mask)*-10000 -> softmax -> @v).
 //
 // Layout/algorithm (wave64, v_mfma_f32_32x32x16_bf16):
-//   * one wave owns 32 query rows; NW waves per workgroup share LDS-staged 64-key K and V^T tiles
-//     (HBM -> VGPR -> LDS, next tile's loads issued before the current tile's math)
-//   * scores are computed TRANSPOSED, S^T = K Q^T, so lane (q = lane&31) holds 16 of the 32 keys of its
-//     query column per 32-key block: the online-softmax row max / row sum are lane-local plus ONE
-//     cross-half exchange (__shfl_xor 32)
-//   * P^T feeds the second MFMA as the B operand with no data movement at all: the contraction slot of
-//     lane-half g, element e is bound to key (16t + 8(e>>2) + 4g + (e&3)), and the V^T A-operand is read
-//     from LDS in that same order (two ds_read_b64 per fragment)
+//   * one wave owns 32 query rows; QW query-waves x KS key-split-waves per workgroup.  KS > 1 is the batch-1
+//     shape: wave (qw, ks) walks key tiles ks, ks+KS, ... and the KS partial (m, l, O) triples are merged
+//     through LDS at the end (4x more resident waves, 4x shorter serial chain)
+//   * K and V^T 64-key tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into an NS-stage ring with
+//     counted s_waitcnt vmcnt + raw s_barrier; no staging VGPRs, no ds_write pass.  LDS rows are 128 B with the
+//     16-byte chunk index XORed by (row>>1)&7 -- applied to the per-lane SOURCE address (a DMA image is lane-linear)
+//     and again on the fragment reads
+//   * scores are computed TRANSPOSED, S^T = K Q^T, so lane (q = lane&31) holds 16 of the 32 keys of its query
+//     column per 32-key block: row max / row sum are lane-local plus ONE cross-half exchange (__shfl_xor 32)
+//   * P^T feeds the second MFMA as the B operand with no data movement at all: the contraction slot of lane-half g,
+//     element e is bound to key (16t + 8(e>>2) + 4g + (e&3)), and the V^T A-operand is read from LDS in that same
+//     order (two ds_read_b64 per fragment)
 //   * O^T = V^T P^T accumulates [d][q]; the rescale factor and 1/l are per-lane scalars
-//   * key_add is a per-key additive f32 term staged with the tile; keys >= N get -inf
-//   * K rows / V^T columns beyond N are zero-filled when staged, so garbage in the padded workspace
-//     can never reach an accumulator
+//   * softmax runs in the log2 domain: p = exp2(s * (log2e/8) + add - m), one v_fma + one v_exp per score when the
+//     tile carries no mask (a per-tile flag is set while the tile lands); the running max is only raised, and the
+//     accumulators rescaled, when some row's maximum grew by more than 2^8 ("defer-max"), so the common tile
+//     touches neither l nor O
+//   * key_add is a per-key additive f32 term (natural-log domain, as the reference applies it) staged with the
+//     tile; keys >= N get -inf; K rows / V^T columns beyond N are zeroed IN LDS on the tail tile only, so garbage
+//     (even NaN) in the padded workspace can never reach an accumulator
 #include <cstdio>
 #include "common.h"
 #include "kernels.h"
 
 namespace uvl {
 
-template <int QW, int KS>
-__global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) {
-    // QW waves along queries (32 rows each) x KS waves along keys: wave (qw, ks) walks key tiles ks, ks+KS, ...
-    // of its 32 queries; the KS partial (m, l, O) triples are merged through LDS at the end.  KS > 1 is the
-    // batch-1 shape: it multiplies the number of resident waves and divides the serial tile chain by KS.
-    constexpr int NT = 64 * QW * KS;
-    constexpr int CPT = (KS * 512) / NT;          // 16-byte chunks per thread per round for each of K and V^T
-    constexpr int K_BYTES = 8192, V_BYTES = 8192, ADD_BYTES = 256, SLOT = K_BYTES + V_BYTES + ADD_BYTES;
-    constexpr int BUF = KS * SLOT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * BUF
+template <int N_> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+#define ATTN_LOG2E 1.4426950408889634f
+#define ATTN_DEFER 8.0f
+
+template <int QW, int KS, int NS>
+__global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) {
+    constexpr int NWAVES = QW * KS;
+    constexpr int K_BYTES = 8192, V_BYTES = 8192, ADD_BYTES = 256, FLAG_BYTES = 16;
+    constexpr int SLOT = K_BYTES + V_BYTES + ADD_BYTES + FLAG_BYTES;
+    constexpr int STAGE = KS * SLOT;
+    constexpr int KV_PER_WAVE = (16 * KS) / NWAVES;      // K/V DMA instructions per wave per round (16 per slot)
+    constexpr int LPW = KV_PER_WAVE + 1;                 // + one key_add DMA, issued only by the slot's owner wave (qw == 0)
+    static_assert((16 * KS) % NWAVES == 0 && LPW * (NS - 2) <= 63, "geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // NS * STAGE (>= the merge exchange area)
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = wave / KS, ks = wave % KS;
+    const bool add_owner = (qw == 0);                    // exactly one wave per slot stages (and rewrites) its key_add row
     const int h = blockIdx.y, b = blockIdx.z;
     const int N = p.N, Npad = p.Npad;
     const size_t bh = (size_t)b * p.H + h;
@@ -53,71 +68,100 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
 
     const int nt = (N + 63) >> 6;                 // key tiles
     const int rounds = (nt + KS - 1) / KS;
-    u32x4 rk[CPT], rv[CPT];
-    float radd = 0.f;
-    auto load_round = [&](int r) __attribute__((always_inline)) {
+
+    // DMA plan of this wave: instruction i covers global K/V piece g = wave + NWAVES*i: slot g/16, piece g%16
+    // (pieces 0-7 = K rows 8j..8j+7, pieces 8-15 = V^T rows), plus key_add of slot (wave % KS)
+    auto issue = [&](int r) __attribute__((always_inline)) {
+        char* st = smem + (r % NS) * STAGE;
 #pragma unroll
-        for (int it = 0; it < CPT; ++it) {
-            const int c = tid + it * NT, slot = c >> 9, cc = c & 511, row = cc >> 3, ch = cc & 7;
-            const int k0 = (r * KS + slot) * 64;
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-            if (k0 < N) {
-                const u32x4 kv = *reinterpret_cast<const u32x4*>(K + (size_t)(k0 + row) * 64 + ch * 8);
-                rk[it] = (k0 + row < N) ? kv : zero;
-                u32x4 vv = *reinterpret_cast<const u32x4*>(Vt + (size_t)row * Npad + k0 + ch * 8);
-                const int kb = k0 + ch * 8;
-                if (kb + 8 > N) {                 // tail chunk: zero the key columns >= N (bf16 pairs per dword)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t w = vv[e];
-                        if (kb + 2 * e >= N) w &= 0xffff0000u;
-                        if (kb + 2 * e + 1 >= N) w &= 0x0000ffffu;
-                        vv[e] = w;
-                    }
-                }
-                rv[it] = vv;
-            } else {
-                rk[it] = zero;
-                rv[it] = zero;
-            }
+        for (int i = 0; i < KV_PER_WAVE; ++i) {
+            const int g = wave + NWAVES * i, slot = g >> 4, piece = g & 15;
+            int k0 = (r * KS + slot) * 64;
+            if (k0 >= N) k0 = 0;                                       // tile does not exist: harmless re-read, never consumed
+            const int row = 8 * (piece & 7) + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);           // logical chunk that belongs at this physical slot
+            const bf16_t* gp = (piece < 8) ? K + (size_t)(k0 + row) * 64 + chunk * 8 : Vt + (size_t)row * Npad + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(st + slot * SLOT + piece * 1024), 16, 0, 0);
         }
-        if (tid < 64 * KS) {
-            const int key = r * KS * 64 + tid;
-            radd = (key < N) ? kadd[key] : -INFINITY;
+        if (add_owner) {
+            const int slot = ks;
+            int k0 = (r * KS + slot) * 64;
+            if (k0 >= N) k0 = 0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kadd + k0 + lane),
+                                             (__attribute__((address_space(3))) void*)(st + slot * SLOT + K_BYTES + V_BYTES), 4, 0, 0);
         }
     };
-    auto store_round = [&](int buf) __attribute__((always_inline)) {
-        char* base = smem + buf * BUF;
-#pragma unroll
-        for (int it = 0; it < CPT; ++it) {
-            const int c = tid + it * NT, slot = c >> 9, cc = c & 511, row = cc >> 3, ch = cc & 7;
-            char* sK = base + slot * SLOT;
-            char* sV = sK + K_BYTES;
-            *reinterpret_cast<u32x4*>(sK + swz128(row, ch)) = rk[it];
-            *reinterpret_cast<uint2*>(sV + swz64(row, 2 * ch)) = make_uint2(rv[it][0], rv[it][1]);
-            *reinterpret_cast<uint2*>(sV + swz64(row, 2 * ch + 1)) = make_uint2(rv[it][2], rv[it][3]);
+    // after this wave's own DMAs of round r have landed: finish the tile image (own-lane rewrites only)
+    auto fixup = [&](int r) __attribute__((always_inline)) {
+        char* st = smem + (r % NS) * STAGE;
+        if (add_owner) {   // key_add -> log2 domain, -inf beyond N, and the per-tile "carries a mask" flag
+            const int slot = ks;
+            const int k0 = (r * KS + slot) * 64;
+            float* sA = reinterpret_cast<float*>(st + slot * SLOT + K_BYTES + V_BYTES);
+            float a = sA[lane] * ATTN_LOG2E;
+            if (k0 + lane >= N) a = -INFINITY;
+            sA[lane] = a;
+            const bool any = __any(a != 0.f);
+            if (lane == 0) *reinterpret_cast<int*>(st + slot * SLOT + K_BYTES + V_BYTES + ADD_BYTES) = any ? 1 : 0;
         }
-        if (tid < 64 * KS) {
-            float* sA = reinterpret_cast<float*>(base + (tid >> 6) * SLOT + K_BYTES + V_BYTES);
-            sA[tid & 63] = radd;
+#pragma unroll
+        for (int i = 0; i < KV_PER_WAVE; ++i) {
+            const int g = wave + NWAVES * i, slot = g >> 4, piece = g & 15;
+            const int k0 = (r * KS + slot) * 64;
+            if (k0 < N && k0 + 64 > N) {                               // wave-uniform: only the tail tile
+                const int row = 8 * (piece & 7) + (lane >> 3);
+                char* at = st + slot * SLOT + piece * 1024 + lane * 16;
+                if (piece < 8) {
+                    if (k0 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
+                } else {
+                    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                    const int kb = k0 + chunk * 8;
+                    if (kb + 8 > N) {
+                        u32x4 v = *reinterpret_cast<u32x4*>(at);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            uint32_t wv = v[e];
+                            if (kb + 2 * e >= N) wv &= 0xffff0000u;
+                            if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
+                            v[e] = wv;
+                        }
+                        *reinterpret_cast<u32x4*>(at) = v;
+                    }
+                }
+            }
         }
     };
 
     f32x16 o[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                 // log2-domain running max, per-lane partial row sum
+    constexpr float CS = 0.125f * ATTN_LOG2E;             // score scale folded with log2(e)
 
-    load_round(0);
-    store_round(0);
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < rounds) issue(t);
     for (int rd = 0; rd < rounds; ++rd) {
-        const int buf = rd & 1;
-        if (rd + 1 < rounds) load_round(rd + 1);
+        const int ahead = rounds - 1 - rd;
+        if (ahead >= NS - 2) {                            // leave NS-2 rounds of this wave's own DMAs in flight
+            if (add_owner) attn_wait_vmcnt<LPW * (NS - 2)>();
+            else attn_wait_vmcnt<KV_PER_WAVE * (NS - 2)>();
+        } else if (NS > 3 && ahead == 1) {
+            if (add_owner) attn_wait_vmcnt<LPW>();
+            else attn_wait_vmcnt<KV_PER_WAVE>();
+        } else {
+            attn_wait_vmcnt<0>();
+        }
+        fixup(rd);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fix-up's LDS writes are done before the barrier
+        __builtin_amdgcn_s_barrier();
+        if (rd + NS - 1 < rounds) issue(rd + NS - 1);     // its stage was last read in round rd-1
         if (rd * KS + ks < nt) {
-            const char* sK = smem + buf * BUF + ks * SLOT;
+            const char* sK = smem + (rd % NS) * STAGE + ks * SLOT;
             const char* sV = sK + K_BYTES;
             const float* sA = reinterpret_cast<const float*>(sV + V_BYTES);
+            const int masked = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(sV + V_BYTES + ADD_BYTES));
 
             // ---- S^T = K Q^T for two 32-key blocks ----
             f32x16 s[2];
@@ -131,37 +175,60 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
                     s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[jb], 0, 0, 0);
                 }
             }
-            // ---- scale, per-key additive term, tile max ----
+            // ---- log2-domain scores, tile max ----
             float tmax = -INFINITY;
+            if (masked) {                                 // wave-uniform: t = s*c + add
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
+                for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(sA + 32 * jb + 8 * gq + 4 * half);
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(sA + 32 * jb + 8 * gq + 4 * half);
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = fmaf(s[jb][4 * gq + e], 0.125f, av[e]);
-                        s[jb][4 * gq + e] = v;
-                        tmax = fmaxf(tmax, v);
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = fmaf(s[jb][4 * gq + e], CS, av[e]);
+                            s[jb][4 * gq + e] = v;
+                            tmax = fmaxf(tmax, v);
+                        }
                     }
-                }
+            } else {                                      // max of the raw scores, scaled once (c > 0)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
+                tmax *= CS;
+            }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __expf(m_run - m_new);
-            m_run = m_new;
+            if (__any(tmax > m_run + ATTN_DEFER)) {       // rare after the first tiles: raise the max, rescale l and O
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            }
             float psum = 0.f;
+            if (masked) {
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
+                for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __expf(s[jb][r] - m_new);
-                    s[jb][r] = pv;
-                    psum += pv;
-                }
-            l_run = l_run * alpha + psum;
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(s[jb][r] - m_run);
+                        s[jb][r] = pv;
+                        psum += pv;
+                    }
+            } else {
+                const float nm = -m_run;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[jb][r], CS, nm));
+                        s[jb][r] = pv;
+                        psum += pv;
+                    }
+            }
+            l_run += psum;
 
             // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -171,20 +238,18 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
                     union { uint32_t u[4]; bf16x8 v; } pf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t + 2 * e], s[jb][8 * t + 2 * e + 1]);
-                    const int base = 32 * jb + 16 * t;
-                    const int c8a = (base + 4 * half) >> 2, c8b = (base + 8 + 4 * half) >> 2;
+                    const int base = 32 * jb + 16 * t;                 // keys base+4g..+3 and base+8+4g..+3
+                    const int ca = base >> 3, cb = ca + 1;             // their 16-byte chunks; 8-byte half = g
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         const int d = 32 * db + (lane & 31);
                         union { uint2 u[2]; bf16x8 v; } vf;
-                        vf.u[0] = *reinterpret_cast<const uint2*>(sV + swz64(d, c8a));
-                        vf.u[1] = *reinterpret_cast<const uint2*>(sV + swz64(d, c8b));
+                        vf.u[0] = *reinterpret_cast<const uint2*>(sV + swz128(d, ca) + 8 * half);
+                        vf.u[1] = *reinterpret_cast<const uint2*>(sV + swz128(d, cb) + 8 * half);
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
                     }
                 }
         }
-        if (rd + 1 < rounds) store_round(buf ^ 1);
-        __syncthreads();
     }
 
     bf16_t* dst = p.o + ((size_t)b * N + (qrow < N ? qrow : 0)) * (p.H * 64) + h * 64;
@@ -204,7 +269,9 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
                 }
         }
     } else {
-        // ---- merge the KS key-split partials: exchange [wave][34][64] floats through LDS (staging is dead now) ----
+        // ---- merge the KS key-split partials: exchange [wave][34][64] floats through LDS (the ring is dead now) ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         float* xch = reinterpret_cast<float*>(smem);
         float* mine = xch + (size_t)wave * 34 * 64;
 #pragma unroll
@@ -219,7 +286,7 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
         float sc[KS], lsum = 0.f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) {
-            sc[w] = __expf(grp[(w * 34 + 32) * 64 + lane] - mstar);       // exp(-inf) = 0 for a wave that saw no tile
+            sc[w] = __builtin_amdgcn_exp2f(grp[(w * 34 + 32) * 64 + lane] - mstar);   // exp2(-inf) = 0 for a wave that saw no tile
             lsum += grp[(w * 34 + 33) * 64 + lane] * sc[w];
         }
         lsum += __shfl_xor(lsum, 32, 64);
@@ -248,33 +315,47 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
     }
 }
 
-template <int QW, int KS>
+template <int QW, int KS, int NS>
 static hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
-    constexpr size_t lds = 2 * KS * (8192 + 8192 + 256);
-    auto kern = attn_kernel<QW, KS>;
+    constexpr size_t ring = (size_t)NS * KS * (8192 + 8192 + 256 + 16);
+    constexpr size_t xch = (size_t)QW * KS * 34 * 64 * 4;
+    constexpr size_t lds = ring > xch ? ring : xch;
+    auto kern = attn_kernel<QW, KS, NS>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    static char name[32];
-    if (!name[0]) snprintf(name, sizeof(name), "attn_kernel<%d,%d>", QW, KS);
+    static char name[40];
+    if (!name[0]) snprintf(name, sizeof(name), "attn_kernel<%d,%d,%d>", QW, KS, NS);
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3((p.N + 32 * QW - 1) / (32 * QW), p.H, p.B), dim3(64 * QW * KS), lds, s, p);
     return hipGetLastError();
 }
 
+int g_tune_attn_cfg = -1;      // tools/attn_bench.py override
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.N <= 0 || p.Npad % 64 != 0 || p.Npad < ((p.N + 63) / 64) * 64) return hipErrorInvalidValue;
-    // enough (batch x heads x query blocks) to fill the chip with 128-query workgroups -> share K/V tiles across
-    // 4 query waves; otherwise split the KEYS across the 4 waves (batch-1 latency shape)
-    const long wg4 = (long)((p.N + 127) / 128) * p.H * p.B;
-    const int nt = (p.N + 63) / 64;
-    if (wg4 >= 512) return launch_attn_cfg<4, 1>(p, s);
-    if (nt >= 4) return launch_attn_cfg<1, 4>(p, s);
-    if (nt >= 2) return launch_attn_cfg<2, 2>(p, s);
-    return launch_attn_cfg<4, 1>(p, s);
+    int cfg = g_tune_attn_cfg;
+    if (cfg < 0) {
+        // enough (batch x heads x query blocks) to fill the chip with 128-query workgroups -> share the K/V tiles across
+        // 4 query waves; otherwise split the KEYS across the 4 waves (batch-1 latency shape)
+        const long wg4 = (long)((p.N + 127) / 128) * p.H * p.B;
+        const int nt = (p.N + 63) / 64;
+        if (wg4 >= 256 || nt < 2) cfg = 0;
+        else if (nt >= 4) cfg = 2;
+        else cfg = 1;
+    }
+    switch (cfg) {
+        case 0: return launch_attn_cfg<4, 1, 2>(p, s);
+        case 1: return launch_attn_cfg<2, 2, 2>(p, s);
+        case 2: return launch_attn_cfg<1, 4, 2>(p, s);
+        case 3: return launch_attn_cfg<4, 1, 3>(p, s);
+        case 4: return launch_attn_cfg<1, 4, 3>(p, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace uvl

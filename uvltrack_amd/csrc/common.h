@@ -15,11 +15,14 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // 16-byte staging
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)f; }          // RNE (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ float bf2f(bf16_t h) { return (float)h; }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two f32 -> packed bf16 pair (RNE), ONE v_cvt_pk_bf16_f32 (the scalar-cast form costs 2 cvt + shift + or)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    union { bf16_t h[2]; uint32_t u; } v;
-    v.h[0] = (bf16_t)lo;
-    v.h[1] = (bf16_t)hi;
-    return v.u;
+    const f32x2 v = {lo, hi};
+    union { bf16x2 h; uint32_t u; } r;
+    r.h = __builtin_convertvector(v, bf16x2);
+    return r.u;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -8,6 +8,7 @@ namespace uvl {
 
 // name of the kernel instantiation the last launcher picked (for per-kernel profiles)
 extern thread_local const char* g_last_kernel;
+extern int g_tune_attn_cfg;      // tools/attn_bench.py override of the attention configuration (-1 = heuristic)
 extern int g_tune_gemm_cfg;      // tools/gemm_bench.py override of the plain-GEMM tile configuration (-1 = heuristic)
 
 struct GemmParams {
@@ -101,6 +102,9 @@ hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s);
 
 // out = relu(sum of split-K slabs) as bf16 (conv towers)
 hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_t* out, size_t n, hipStream_t s);
+
+// touch a weight blob so it is resident in the memory-side cache when the consuming GEMM runs
+hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t s);
 
 // weight packing
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);

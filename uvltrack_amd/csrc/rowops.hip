@@ -583,6 +583,27 @@ hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight prefetch: stream a weight blob through the memory-side cache ahead of the GEMM that will DMA it, so the
+// GEMM's tiles come from the Infinity Cache instead of HBM (batch-1 frames touch 274 MB of weights once each).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const u32x4 v = __builtin_nontemporal_load(p + i);
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+    asm volatile("" ::"v"(acc));
+}
+hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t s) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    size_t blocks = (n16 + 2047) / 2048;          // ~8 x 16 B per thread
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4*)p, n16);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packers
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {

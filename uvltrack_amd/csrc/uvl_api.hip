@@ -81,7 +81,9 @@ struct uvl_model {
     ConvLayerW conv[4];
     float *w1 = nullptr, *b1 = nullptr;
     // streams / events
-    hipStream_t aux = nullptr;
+    hipStream_t aux = nullptr, pf = nullptr;     // text-branch stream, weight-prefetch stream
+    std::vector<hipEvent_t> ev_pf;
+    int prefetch = 0;                            // UVL_PREFETCH=1: measured -9 % FPS on MI355X (48 extra launches), off by default
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_bert, ev_cont;
     // graph
@@ -124,6 +126,10 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
         delete m;
         return nullptr;
     }
+    hipStreamCreateWithFlags(&m->pf, hipStreamNonBlocking);
+    m->ev_pf.resize(c->depth);
+    for (auto& e : m->ev_pf) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    { const char* e = getenv("UVL_PREFETCH"); if (e) m->prefetch = atoi(e); }
     m->ev_bert.resize(c->depth);
     m->ev_cont.resize(c->depth);
     for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -142,6 +148,8 @@ extern "C" void uvl_destroy(uvl_model_t* m) {
     for (auto& kv : m->raw) if (kv.second.d) hipFree(kv.second.d);
     for (void* p : m->owned) hipFree(p);
     for (auto& e : m->ev_bert) hipEventDestroy(e);
+    for (auto& e : m->ev_pf) hipEventDestroy(e);
+    if (m->pf) hipStreamDestroy(m->pf);
     for (auto& e : m->ev_cont) hipEventDestroy(e);
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     if (m->ev_join) hipEventDestroy(m->ev_join);
@@ -577,6 +585,16 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             if (!skip) L.cur = PART_V2;
             if (fork && hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
         }
+        if (m->prefetch && parts == PART_ALL && !prof && i + 1 < m->depth) {
+            // while layer i computes, pull layer i+1's weights (14 MB for ViT-B) into the memory-side cache
+            const VitBlockW& nw = m->vit[i + 1];
+            if (hipEventRecord(m->ev_pf[i], s) == hipSuccess && hipStreamWaitEvent(m->pf, m->ev_pf[i], 0) == hipSuccess) {
+                launch_prefetch(nw.wqkv, (size_t)3 * D * D * 2, m->pf);
+                launch_prefetch(nw.wproj, (size_t)D * D * 2, m->pf);
+                launch_prefetch(nw.wfc1, (size_t)Fn * D * 2, m->pf);
+                launch_prefetch(nw.wfc2, (size_t)Fn * D * 2, m->pf);
+            }
+        }
         // ---- ViT block (block.py:29-32) ----
         {
             LnParams p;
@@ -736,6 +754,7 @@ extern "C" int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* 
 extern "C" int uvl_tune_set(const char* key, int value) {
     if (!key) return fail(UVL_EINVAL, "null key");
     if (!strcmp(key, "gemm_cfg")) { uvl::g_tune_gemm_cfg = value; return UVL_OK; }
+    if (!strcmp(key, "attn_cfg")) { uvl::g_tune_attn_cfg = value; return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown tuning key '%s'", key);
 }
 
