@@ -17,7 +17,12 @@ def p(t):
 
 def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for B, H, N in [(1, 12, 553), (8, 12, 553), (64, 12, 553), (1, 16, 681), (8, 16, 681), (8, 16, 873), (64, 16, 681)]:
+    shapes = [(1, 12, 553), (8, 12, 553), (64, 12, 553), (1, 16, 681), (8, 16, 681), (8, 16, 873), (64, 16, 681)]
+    if len(sys.argv) > 3:
+        shapes = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
+    if len(sys.argv) > 4:
+        lib.uvl_tune_set(b"attn_cfg", int(sys.argv[4]))
+    for B, H, N in shapes:
         Npad = (N + 63) // 64 * 64
         q = torch.randn(B, H, Npad, 64, device="cuda").bfloat16()
         k = torch.randn(B, H, Npad, 64, device="cuda").bfloat16()

@@ -37,7 +37,7 @@ template <int N_> __device__ __forceinline__ void attn_wait_vmcnt() { asm volati
 #define ATTN_DEFER 8.0f
 
 template <int QW, int KS, int NS>
-__global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(const AttnParams p) {
     constexpr int NWAVES = QW * KS;
     constexpr int K_BYTES = 8192, V_BYTES = 8192, ADD_BYTES = 256, FLAG_BYTES = 16;
     constexpr int SLOT = K_BYTES + V_BYTES + ADD_BYTES + FLAG_BYTES;
@@ -59,6 +59,8 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
     const bf16_t* __restrict__ Vt = p.vt + bh * 64 * Npad;
     const float* __restrict__ kadd = p.key_add + (size_t)b * p.key_add_stride;
 
+    const int nt = (N + 63) >> 6;                 // key tiles
+    const int rounds = (nt + KS - 1) / KS;
     const int q0 = (blockIdx.x * QW + qw) * 32;
     const int qrow = q0 + (lane & 31);
     const int qld = qrow < N ? qrow : N - 1;
@@ -66,30 +68,33 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
 
-    const int nt = (N + 63) >> 6;                 // key tiles
-    const int rounds = (nt + KS - 1) / KS;
-
     // DMA plan of this wave: instruction i covers global K/V piece g = wave + NWAVES*i: slot g/16, piece g%16
-    // (pieces 0-7 = K rows 8j..8j+7, pieces 8-15 = V^T rows), plus key_add of slot (wave % KS)
+    // (pieces 0-7 = K rows 8j..8j+7, pieces 8-15 = V^T rows), plus key_add of the slot this wave owns.
+    // Per-lane source pointers are formed once; a round only adds the (wave-uniform) tile offset.
+    const bf16_t* src[KV_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < KV_PER_WAVE; ++i) {
+        const int g = wave + NWAVES * i, piece = g & 15;
+        const int row = 8 * (piece & 7) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);               // logical chunk that belongs at this physical slot
+        src[i] = (piece < 8) ? K + (size_t)row * 64 + chunk * 8 : Vt + (size_t)row * Npad + chunk * 8;
+    }
     auto issue = [&](int r) __attribute__((always_inline)) {
         char* st = smem + (r % NS) * STAGE;
 #pragma unroll
         for (int i = 0; i < KV_PER_WAVE; ++i) {
             const int g = wave + NWAVES * i, slot = g >> 4, piece = g & 15;
-            int k0 = (r * KS + slot) * 64;
-            if (k0 >= N) k0 = 0;                                       // tile does not exist: harmless re-read, never consumed
-            const int row = 8 * (piece & 7) + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);           // logical chunk that belongs at this physical slot
-            const bf16_t* gp = (piece < 8) ? K + (size_t)(k0 + row) * 64 + chunk * 8 : Vt + (size_t)row * Npad + k0 + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+            int kt = r * KS + slot;
+            kt = kt < nt ? kt : nt - 1;                                // tile does not exist: harmless re-read, never consumed
+            const size_t off = (piece < 8) ? (size_t)kt * 64 * 64 : (size_t)kt * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + off),
                                              (__attribute__((address_space(3))) void*)(st + slot * SLOT + piece * 1024), 16, 0, 0);
         }
         if (add_owner) {
-            const int slot = ks;
-            int k0 = (r * KS + slot) * 64;
-            if (k0 >= N) k0 = 0;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kadd + k0 + lane),
-                                             (__attribute__((address_space(3))) void*)(st + slot * SLOT + K_BYTES + V_BYTES), 4, 0, 0);
+            int kt = r * KS + ks;
+            kt = kt < nt ? kt : nt - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kadd + kt * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(st + ks * SLOT + K_BYTES + V_BYTES), 4, 0, 0);
         }
     };
     // after this wave's own DMAs of round r have landed: finish the tile image (own-lane rewrites only)
@@ -133,6 +138,14 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
         }
     };
 
+    // lane-dependent LDS offsets of the fragments (tile-independent): K chunk 2kk+half of row lane&31 (+4096 for the
+    // second 32-key block), V^T chunks 0..7 of row lane&31 (+4096 for the second 32 d-rows), 8-byte half = lane half
+    int koff[4], voff[8];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = swz128(lane & 31, 2 * kk + half);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) voff[c] = swz128(lane & 31, c) + 8 * half;
+
     f32x16 o[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
@@ -165,14 +178,13 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
 
             // ---- S^T = K Q^T for two 32-key blocks ----
             f32x16 s[2];
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
-#pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + swz128(32 * jb + (lane & 31), 2 * kk + half));
-                    s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[jb], 0, 0, 0);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
+                    s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : s[jb], 0, 0, 0);
                 }
             }
             // ---- log2-domain scores, tile max ----
@@ -238,14 +250,12 @@ __global__ __launch_bounds__(64 * QW * KS) void attn_kernel(const AttnParams p) 
                     union { uint32_t u[4]; bf16x8 v; } pf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t + 2 * e], s[jb][8 * t + 2 * e + 1]);
-                    const int base = 32 * jb + 16 * t;                 // keys base+4g..+3 and base+8+4g..+3
-                    const int ca = base >> 3, cb = ca + 1;             // their 16-byte chunks; 8-byte half = g
+                    const int ca = 4 * jb + 2 * t;                     // keys base+4g..+3 live in 16-byte chunk ca, base+8+4g.. in ca+1
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        const int d = 32 * db + (lane & 31);
                         union { uint2 u[2]; bf16x8 v; } vf;
-                        vf.u[0] = *reinterpret_cast<const uint2*>(sV + swz128(d, ca) + 8 * half);
-                        vf.u[1] = *reinterpret_cast<const uint2*>(sV + swz128(d, cb) + 8 * half);
+                        vf.u[0] = *reinterpret_cast<const uint2*>(sV + db * 4096 + voff[ca]);
+                        vf.u[1] = *reinterpret_cast<const uint2*>(sV + db * 4096 + voff[ca + 1]);
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
                     }
                 }
