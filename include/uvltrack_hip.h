@@ -114,6 +114,18 @@ size_t uvl_workspace_bytes(const uvl_model_t* m, int batch);
 int uvl_forward_test(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out,
                      void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* UVLTrack.forward_prompt (uvltrack.py:33-38): the prompter = ModalityAdaptiveBoxHead.forward_prompt (head:96-106) ->
+ * DistributionBasedCrossAttention.forward (heads/utils.py:82-99).  Inputs are entries of a previous forward_test output
+ * dict (template [B,nz,D], search [B,S,D], vis_token / txt_token [B,1,D], flag [B]) plus the target-cell masks
+ * (u8/bool, 1 = cell inside the box; tracker anno2mask, lib/test/tracker/uvltrack.py:183-194).
+ * Output: prompt [B,3,D] f32 = (target, distractor, background) tokens; flag 1 (grounding) returns the un-updated queries.
+ * Needs box_head.prompter.{logit_scale, query_embed.weight, mlp.fc1.*, mlp.fc2.*} to have been loaded; uses the frame
+ * workspace as scratch (call it between frames, on the same stream). */
+int uvl_forward_prompt(uvl_model_t* m, int batch, const float* d_template_tokens, const float* d_search_tokens,
+                       const float* d_vis_token, const float* d_txt_token, const int64_t* d_flag,
+                       const uint8_t* d_template_mask, const uint8_t* d_context_mask, float* d_prompt_out,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* hipGraph replay of the same call: capture once for fixed pointers/batch, then launch per frame. */
 int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out,
                       void* d_workspace, size_t workspace_bytes);

@@ -60,10 +60,13 @@ def run_case(name, case):
     t0 = time.time()
     sd = wg.make_state_dict(spec, case["seed"], include_unused=True)
     inp = case_inputs(case)
-    ref = R.run_reference(spec, sd, inp)
+    tem_mask, ctx_mask = O.box_masks(spec, case["batch"], seed=case["in_seed"])
+    ref = R.run_reference(spec, sd, inp, prompt_masks=(tem_mask, ctx_mask))
     taps = {}
     mine = O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"], taps)
     dev = {k: float(np.abs(ref[k] - mine[k]).max()) for k in O.OUTPUT_KEYS}
+    mine_prompt = O.forward_prompt_init(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], tem_mask, ctx_mask, inp["flag"])
+    dev["prompt_init"] = float(np.abs(ref["prompt_init"] - mine_prompt).max())
     out = {"meta": np.frombuffer(json.dumps({
         "name": name, "spec": spec.to_dict(), "weight_seed": case["seed"], "input_seed": case["in_seed"],
         "batch": case["batch"], "flags": case["flags"], "zero_text": bool(case.get("zero_text")),
@@ -81,6 +84,7 @@ def run_case(name, case):
         if case.get("full"):
             out["ref." + k] = ref[k].astype(np.float32)
     out["ref.flag"] = ref["flag"].astype(np.int64)
+    out["ref.prompt_init"] = ref["prompt_init"].astype(np.float32)      # forward_prompt_init with oracle.box_masks(seed=in_seed)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     np.savez_compressed(path, **out)

@@ -149,8 +149,9 @@ def release_reference_modules():
     _purge_lib_modules()
 
 
-def run_reference(spec, sd_np, inputs, tap_layers=False):
-    """Load numpy weights into the real reference and run forward_test; returns dict of numpy arrays."""
+def run_reference(spec, sd_np, inputs, tap_layers=False, prompt_masks=None):
+    """Load numpy weights into the real reference and run forward_test; returns dict of numpy arrays.
+    prompt_masks=(template_mask, context_mask) additionally runs forward_prompt_init -> res['prompt_init']."""
     import torch
     model, cfg, NestedTensor = build_reference_model(spec)
     ref_sd = model.state_dict()
@@ -172,9 +173,22 @@ def run_reference(spec, sd_np, inputs, tap_layers=False):
         text = NestedTensor(torch.from_numpy(inputs["ids"]), torch.from_numpy(inputs["mask"]))
         out = model.forward_test(torch.from_numpy(inputs["template"]), torch.from_numpy(inputs["search"]), text,
                                  torch.from_numpy(inputs["prompt"]), torch.from_numpy(inputs["flag"]))
+        prompt_init = None
+        if prompt_masks is not None:
+            orig_cuda = torch.Tensor.cuda
+            torch.Tensor.cuda = lambda self, *a, **k: self          # heads/utils.py:96 hard-codes .cuda()
+            try:
+                text2 = NestedTensor(torch.from_numpy(inputs["ids"]), torch.from_numpy(inputs["mask"]))
+                prompt_init = model.forward_prompt_init(torch.from_numpy(inputs["template"]), torch.from_numpy(inputs["search"]), text2,
+                                                        torch.from_numpy(prompt_masks[0]), torch.from_numpy(prompt_masks[1]),
+                                                        torch.from_numpy(inputs["flag"])).detach().numpy().copy()
+            finally:
+                torch.Tensor.cuda = orig_cuda
     for h in hooks:
         h.remove()
     res = {k: v.detach().numpy().copy() for k, v in out.items() if hasattr(v, "detach")}
+    if prompt_init is not None:
+        res["prompt_init"] = prompt_init
     res.update(taps)
     release_reference_modules()
     return res

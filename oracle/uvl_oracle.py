@@ -296,5 +296,77 @@ def forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps=None
     return head_forward(sd, spec, out, prompt.astype(f32))
 
 
+# --------------------------------------------------------------------------
+# prompter ("next" row SURVEY.md 8f-1): DistributionBasedCrossAttention
+# --------------------------------------------------------------------------
+def prompter_forward(sd, tem, tem_mask, ctx, ctx_mask, token, flag):
+    """DistributionBasedCrossAttention.forward (heads/utils.py:82-99) with distribute_attn (:58-79) and
+    divide_background (:45-56), eval mode.  tem [B,nz,D], ctx [B,S,D], masks bool (True = target cell),
+    token [B,D], flag [B] -> prompt [B,3,D] = (target, distractor, background) tokens."""
+    pr = "box_head.prompter."
+    B = tem.shape[0]
+    qe = sd[pr + "query_embed.weight"]
+    src_ = np.broadcast_to(qe[None], (B,) + qe.shape).astype(f32).copy()
+    src_[:, 0] = src_[:, 0] + token
+    tgt = np.concatenate([tem, ctx], axis=1).astype(f32)
+    tgt_mask = np.concatenate([tem_mask, ctx_mask], axis=1).astype(bool)[:, None, :]
+    tau = np.exp(sd[pr + "logit_scale"]).astype(f32)
+    sim = (l2_normalize(token)[:, None, :] @ l2_normalize(tgt).transpose(0, 2, 1)) * tau          # [B,1,L]
+    NEG = f32(-1e20)
+    tgt_score = softmax(np.where(~tgt_mask, NEG, sim).astype(f32), -1)
+    tgt_token = tgt_score @ tgt
+    bgd_logit = np.where(tgt_mask, NEG, sim).astype(f32)
+    bgd_score = softmax(bgd_logit, -1)
+    # divide_background: ascending sort, cumulative mass < 0.25 is "pure background"
+    values = np.sort(bgd_score, axis=-1)
+    cmask = np.cumsum(values, axis=-1, dtype=f32) < f32(0.25)
+    thr = np.where(cmask, f32(1.0), values).min(-1, keepdims=True)
+    dis_mask = bgd_score >= thr
+    bgd2 = softmax(np.where(dis_mask, NEG, bgd_logit).astype(f32), -1)
+    dis = softmax(np.where(~dis_mask, NEG, bgd_logit).astype(f32), -1)
+    bgd_token = bgd2 @ tgt
+    dis_token = dis @ tgt
+    src = np.concatenate([tgt_token, dis_token, bgd_token], axis=1).astype(f32) + src_
+    h = gelu(linear(src, sd[pr + "mlp.fc1.weight"], sd[pr + "mlp.fc1.bias"]))
+    src = linear(h, sd[pr + "mlp.fc2.weight"], sd[pr + "mlp.fc2.bias"]) + src
+    grp = np.stack([src, src_, src], axis=1)
+    return grp[np.arange(B), np.asarray(flag).reshape(-1)].astype(f32)
+
+
+def forward_prompt(sd, spec, out, tem_mask, ctx_mask):
+    """ModalityAdaptiveBoxHead.forward_prompt (head:96-106) / UVLTrack.forward_prompt (uvltrack.py:33-38)."""
+    sd = {k: (np.asarray(v, dtype=f32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in sd.items()}
+    flag = np.asarray(out["flag"]).reshape(-1)
+    vt, tt = out["vis_token"], out["txt_token"]
+    grp = np.concatenate([vt, tt, (vt + tt) / f32(2.0)], axis=1)
+    token = grp[np.arange(flag.shape[0]), flag]
+    return prompter_forward(sd, out["template"], tem_mask, out["search"], ctx_mask, token, flag)
+
+
+def forward_prompt_init(sd, spec, template, search, ids, tmask, tem_mask, ctx_mask, flag):
+    """UVLTrack.forward_prompt_init (uvltrack.py:26-31): backbone, then the prompter."""
+    sdn = {k: (np.asarray(v, dtype=f32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in sd.items()}
+    out = backbone_forward(sdn, spec, template.astype(f32), search.astype(f32), np.asarray(ids), np.asarray(tmask),
+                           np.asarray(flag).reshape(-1, 1))
+    return forward_prompt(sdn, spec, out, tem_mask, ctx_mask)
+
+
+def box_masks(spec, batch, seed=0):
+    """Synthetic target-cell masks in the style of the tracker's anno2mask (tracker:183-194): the cells whose centre
+    lies inside a box, plus the box-centre cell."""
+    rng = np.random.RandomState(1234 + seed)
+
+    def one(g):
+        m = np.zeros((batch, g, g), bool)
+        for b in range(batch):
+            cx, cy = rng.uniform(0.3, 0.7, 2) * g
+            w, h = rng.uniform(0.2, 0.5, 2) * g
+            c = np.arange(g) + 0.5
+            m[b] = ((c > cy - h / 2) & (c < cy + h / 2))[:, None] & ((c > cx - w / 2) & (c < cx + w / 2))[None, :]
+            m[b, int(cy), int(cx)] = True
+        return m.reshape(batch, g * g)
+    return one(spec.template_size // 16), one(spec.feat_sz)
+
+
 OUTPUT_KEYS = ("search", "template", "text", "vis_token", "txt_token", "logits", "cls_score",
                "cls_score_test", "bbox_map", "pred_boxes", "cont_score")

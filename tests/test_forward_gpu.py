@@ -18,7 +18,7 @@ def _engine(meta, spec):
     if key not in _engines:
         _engines.clear()                       # one big model resident at a time
         eng = HipEngine(spec, torch.device("cuda:0"), max_batch=8)
-        eng.load_state_dict(rebuild_weights(meta, spec))
+        eng.load_state_dict(rebuild_weights(meta, spec, include_unused=True))
         _engines[key] = eng
     return _engines[key]
 
@@ -37,6 +37,26 @@ def test_forward_matches_reference_fixture(name):
     got = _run(_engine(meta, spec), inp)
     ok, rep = compare_outputs(got, ref, depth=spec.depth)
     assert ok, "\n" + fmt_report(rep)
+
+
+@pytest.mark.parametrize("name", [c for c in list_cases() if not c.startswith("l_")])
+def test_prompter_matches_reference_fixture(name):
+    """forward_prompt_init = backbone + prompter against the reference's output for the same box masks."""
+    from oracle import uvl_oracle as O
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    tem_mask, ctx_mask = O.box_masks(spec, meta["batch"], seed=meta["input_seed"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), torch.zeros_like(t(inp["prompt"])), t(inp["flag"]))
+    prompt = eng.forward_prompt(out, t(tem_mask), t(ctx_mask))
+    torch.cuda.synchronize()
+    got = prompt.cpu().numpy()
+    want = ref["prompt_init"]
+    assert got.shape == want.shape
+    err = np.abs(got - want).max()
+    tol = 0.03 * max(1.0, spec.depth / 12.0) * np.abs(want).max()
+    assert np.isfinite(got).all() and err <= tol, "prompt err %g > %g (abs-max %g)" % (err, tol, np.abs(want).max())
 
 
 def test_forward_matches_oracle_per_sample_batch1():

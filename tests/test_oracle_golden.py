@@ -20,6 +20,8 @@ def _check(name):
         if k == "flag":
             assert (out["flag"] == v).all()
             continue
+        if k == "prompt_init":          # covered by test_oracle_prompter_matches_reference
+            continue
         if k.endswith(".slice"):
             got = out[k[:-6]][:, :8, :32]
         else:
@@ -37,6 +39,23 @@ def test_oracle_matches_reference_tiny(name):
 @pytest.mark.parametrize("name", [c for c in BIG if c.startswith("b_")])
 def test_oracle_matches_reference_base(name):
     _check(name)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_prompter_matches_reference(name):
+    """forward_prompt_init (backbone + DistributionBasedCrossAttention) against the reference's own output."""
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    sd = rebuild_weights(meta, spec, include_unused=True)
+    tem_mask, ctx_mask = O.box_masks(spec, meta["batch"], seed=meta["input_seed"])
+    got = O.forward_prompt_init(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], tem_mask, ctx_mask, inp["flag"])
+    assert got.shape == ref["prompt_init"].shape == (meta["batch"], 3, spec.dim)
+    np.testing.assert_allclose(got, ref["prompt_init"], atol=ATOL, rtol=0)
+    # flag 1 (grounding) returns the un-updated queries: query_embed (+ token on row 0), independent of the masks
+    for b, fl in enumerate(meta["flags"]):
+        if fl == 1:
+            other = O.forward_prompt_init(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], ~tem_mask, ~ctx_mask, inp["flag"])
+            np.testing.assert_array_equal(other[b], got[b])
 
 
 def test_mask_semantics_text_never_leaks_in_bbox_mode():

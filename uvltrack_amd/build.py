@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libuvltrack_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "uvl_api.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "prompter.hip", "uvl_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1",      # accumulators stay in VGPRs (unified file on gfx950): no v_accvgpr moves around the softmax
          "-I", INCLUDE, "-I", CSRC]
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=5) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)

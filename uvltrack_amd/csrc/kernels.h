@@ -100,6 +100,19 @@ struct HeadTailParams {
 };
 hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s);
 
+// The prompter (DistributionBasedCrossAttention, heads/utils.py:23-99): token sums before the MLP, and the flag switch.
+struct PrompterParams {
+    const float *tem = nullptr, *ctx = nullptr, *vis = nullptr, *txt = nullptr;     // [B,nz,D], [B,S,D], [B,1,D], [B,1,D] f32
+    const uint8_t *tem_mask = nullptr, *ctx_mask = nullptr;                         // [B,nz], [B,S]  1 = target cell
+    const int64_t* flag = nullptr;
+    const float *query_embed = nullptr, *logit_scale = nullptr;
+    int B = 0, nz = 0, S = 0, D = 0;
+    float *src = nullptr, *src0 = nullptr;                                          // [B,3,D] f32: tokens + src_, and src_
+    bf16_t* src_bf16 = nullptr;                                                     // [3B, D] MLP operand
+};
+hipError_t launch_prompter_tokens(const PrompterParams& p, hipStream_t s);
+hipError_t launch_prompter_select(const float* src, const float* src0, const int64_t* flag, float* out, int B, int n_per_sample, hipStream_t s);
+
 // out = relu(sum of split-K slabs) as bf16 (conv towers)
 hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_t* out, size_t n, hipStream_t s);
 

@@ -80,6 +80,10 @@ struct uvl_model {
     std::vector<BertLayerW> bert;
     ConvLayerW conv[4];
     float *w1 = nullptr, *b1 = nullptr;
+    // prompter (optional: only forward_prompt needs it)
+    bool has_prompter = false;
+    const float *pr_logit_scale = nullptr, *pr_query = nullptr, *pr_b1 = nullptr, *pr_b2 = nullptr;
+    bf16_t *pr_w1 = nullptr, *pr_w2 = nullptr;
     // streams / events
     hipStream_t aux = nullptr, pf = nullptr;     // text-branch stream, weight-prefetch stream
     std::vector<hipEvent_t> ev_pf;
@@ -157,9 +161,16 @@ extern "C" void uvl_destroy(uvl_model_t* m) {
     delete m;
 }
 
+static bool name_is_prompter_used(const std::string& n) {
+    static const char* used[] = {"box_head.prompter.logit_scale", "box_head.prompter.query_embed.weight", "box_head.prompter.mlp.fc1.weight",
+                                 "box_head.prompter.mlp.fc1.bias", "box_head.prompter.mlp.fc2.weight", "box_head.prompter.mlp.fc2.bias"};
+    for (const char* u : used) if (n == u) return true;
+    return false;
+}
 static bool name_is_ignored(const std::string& n) {
-    return n.find("box_head.prompter.") == 0 || n.find("backbone.bert.pooler.") == 0 || n.find("backbone.vit.norm.") == 0 ||
-           n.find("num_batches_tracked") != std::string::npos;
+    // prompter.{q,kv,proj,norm} exist in the checkpoint but are never used by the reference either (heads/utils.py:31-40)
+    return (n.find("box_head.prompter.") == 0 && !name_is_prompter_used(n)) || n.find("backbone.bert.pooler.") == 0 ||
+           n.find("backbone.vit.norm.") == 0 || n.find("num_batches_tracked") != std::string::npos;
 }
 
 static bool name_is_known(const uvl_model* m, const std::string& n) {
@@ -169,6 +180,7 @@ static bool name_is_known(const uvl_model* m, const std::string& n) {
                                   "backbone.bert.embeddings.token_type_embeddings.weight", "backbone.bert.embeddings.LayerNorm.weight",
                                   "backbone.bert.embeddings.LayerNorm.bias", "box_head.logit_scale", "box_head.coodinate"};
     for (const char* f : fixed) if (n == f) return true;
+    if (name_is_prompter_used(n)) return true;
     if (n.find("backbone.vit.blocks.") == 0 || n.find("backbone.bert.encoder.layer.") == 0 || n.find("box_head.conv_") == 0) return true;
     (void)m;
     return false;
@@ -325,6 +337,15 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
             off += rows[t];
         }
     }
+    m->has_prompter = m->raw.count("box_head.prompter.mlp.fc1.weight") && m->raw.count("box_head.prompter.mlp.fc2.weight") &&
+                      m->raw.count("box_head.prompter.query_embed.weight") && m->raw.count("box_head.prompter.logit_scale") &&
+                      m->raw.count("box_head.prompter.mlp.fc1.bias") && m->raw.count("box_head.prompter.mlp.fc2.bias");
+    if (m->has_prompter) {
+        m->pr_logit_scale = P.f32("box_head.prompter.logit_scale", 1);
+        m->pr_query = P.f32("box_head.prompter.query_embed.weight", 3 * D);
+        m->pr_w1 = P.bf16("box_head.prompter.mlp.fc1.weight", Fn * D); m->pr_b1 = P.f32("box_head.prompter.mlp.fc1.bias", Fn);
+        m->pr_w2 = P.bf16("box_head.prompter.mlp.fc2.weight", D * Fn); m->pr_b2 = P.f32("box_head.prompter.mlp.fc2.bias", D);
+    }
     m->logit_scale_head = P.f32("box_head.logit_scale", 1);
     m->coord = P.f32("box_head.coodinate", 2 * (size_t)m->S);
     if (P.err) return P.err;
@@ -342,6 +363,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
     }
     for (int l = 0; l < 4; ++l)
         for (int t = 0; t < 4; ++t) P.drop(std::string("box_head.") + towers[t] + "." + std::to_string(l) + ".0.weight");
+    if (m->has_prompter) { P.drop("box_head.prompter.mlp.fc1.weight"); P.drop("box_head.prompter.mlp.fc2.weight"); }
     for (int k = 0; k < 3; ++k) {
         if (m->graph_exec3[k]) { hipGraphExecDestroy(m->graph_exec3[k]); m->graph_exec3[k] = nullptr; }
         if (m->graph3[k]) { hipGraphDestroy(m->graph3[k]); m->graph3[k] = nullptr; }
@@ -820,6 +842,42 @@ extern "C" int uvl_graph_launch(uvl_model_t* m, void* stream) {
     HIPCHK(hipGraphLaunch(m->graph_exec3[1], s));
     HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
     HIPCHK(hipGraphLaunch(m->graph_exec3[2], s));
+    return UVL_OK;
+}
+
+// ---- prompter (UVLTrack.forward_prompt, uvltrack.py:33-38 -> head:96-106 -> heads/utils.py:82-99) ---------------
+extern "C" int uvl_forward_prompt(uvl_model_t* m, int batch, const float* d_template_tokens, const float* d_search_tokens,
+                                  const float* d_vis_token, const float* d_txt_token, const int64_t* d_flag,
+                                  const uint8_t* d_template_mask, const uint8_t* d_context_mask, float* d_prompt_out,
+                                  void* d_ws, size_t ws_bytes, void* stream) {
+    if (!m || !d_template_tokens || !d_search_tokens || !d_vis_token || !d_txt_token || !d_flag || !d_template_mask || !d_context_mask || !d_prompt_out)
+        return fail(UVL_EINVAL, "uvl_forward_prompt: null argument");
+    if (!m->finalized) return fail(UVL_ESTATE, "uvl_finalize_weights has not been called");
+    if (!m->has_prompter) return fail(UVL_ESTATE, "prompter weights (box_head.prompter.{logit_scale,query_embed,mlp.*}) were not loaded");
+    const int B = batch;
+    if (B <= 0 || B > m->cfg.max_batch) return fail(UVL_EINVAL, "batch %d outside [1, %d]", B, m->cfg.max_batch);
+    const Workspace w = carve(m, B, (char*)d_ws);
+    if (!d_ws || ws_bytes < w.total || (uintptr_t)d_ws % 256) return fail(UVL_EINVAL, "bad workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = m->D, Fn = m->ffn;
+    // scratch inside the (idle between frames) frame workspace: src / src_ in X, bf16 operand in Xn, MLP hidden in Hb
+    float* src = w.X;
+    float* src0 = w.X + (size_t)B * 3 * D;
+    PrompterParams p;
+    p.tem = d_template_tokens; p.ctx = d_search_tokens; p.vis = d_vis_token; p.txt = d_txt_token;
+    p.tem_mask = d_template_mask; p.ctx_mask = d_context_mask; p.flag = d_flag;
+    p.query_embed = m->pr_query; p.logit_scale = m->pr_logit_scale; p.B = B; p.nz = m->nz; p.S = m->S; p.D = D;
+    p.src = src; p.src0 = src0; p.src_bf16 = w.Xn;
+    HIPCHK(launch_prompter_tokens(p, s));
+    {   // src = mlp(src) + src  (utils.py:94)
+        GemmParams g;
+        g.A = w.Xn; g.lda = D; g.W = m->pr_w1; g.ldw = D; g.bias = m->pr_b1; g.M = 3 * B; g.N = Fn; g.K = D; g.epi = 0; g.C = w.Hb; g.ldc = Fn; g.act = 1;
+        HIPCHK(launch_gemm(g, s));
+        GemmParams h;
+        h.A = w.Hb; h.lda = Fn; h.W = m->pr_w2; h.ldw = Fn; h.bias = m->pr_b2; h.M = 3 * B; h.N = D; h.K = Fn; h.epi = 1; h.C = src; h.ldc = D; h.accumulate = 1;
+        HIPCHK(launch_gemm(h, s));
+    }
+    HIPCHK(launch_prompter_select(src, src0, d_flag, d_prompt_out, B, 3 * D, s));
     return UVL_OK;
 }
 

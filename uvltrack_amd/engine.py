@@ -204,6 +204,35 @@ class HipEngine:
             return outs
         return step
 
+    def forward_prompt(self, out_dict, template_mask, context_mask) -> torch.Tensor:
+        """UVLTrack.forward_prompt (uvltrack.py:33-38) on a forward_test output dict; returns prompt [B,3,D]."""
+        need = ("template", "search", "vis_token", "txt_token", "flag")
+        miss = [k for k in need if k not in out_dict]
+        if miss:
+            raise KeyError("out_dict lacks %s" % miss)
+        s = self.spec
+        tem = out_dict["template"].to(torch.float32).contiguous()
+        ctx = out_dict["search"].to(torch.float32).contiguous()
+        vis = out_dict["vis_token"].to(torch.float32).contiguous()
+        txt = out_dict["txt_token"].to(torch.float32).contiguous()
+        flag = out_dict["flag"].reshape(-1).to(torch.int64).contiguous()
+        B = ctx.shape[0]
+        for t, w in ((tem, "template"), (ctx, "search"), (template_mask, "template_mask"), (context_mask, "context_mask")):
+            _require_cuda(t, w)
+        tm = (template_mask.reshape(B, -1) != 0).to(torch.uint8).contiguous()
+        cm = (context_mask.reshape(B, -1) != 0).to(torch.uint8).contiguous()
+        if tuple(tem.shape) != (B, s.nz, s.dim) or tuple(ctx.shape) != (B, s.nx, s.dim) or tm.shape[1] != s.nz or cm.shape[1] != s.nx:
+            raise ValueError("forward_prompt: tensor shapes do not match the model geometry")
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B)
+            n = self.lib.uvl_workspace_bytes(self.handle, B)
+            prompt = torch.empty(B, 3, s.dim, dtype=torch.float32, device=self.device)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            _native.check(self.lib.uvl_forward_prompt(self.handle, B, p(tem), p(ctx), p(vis), p(txt), p(flag), p(tm), p(cm), p(prompt),
+                                                      C.c_void_p(self._ws_ptr(ws)), n, self._stream()), "uvl_forward_prompt")
+        self._keep_prompt = (tem, ctx, vis, txt, flag, tm, cm)
+        return prompt
+
     def profile_entries(self):
         """Per-launch-site breakdown of the last profile=True forward."""
         n = self.lib.uvl_profile_count(self.handle)

@@ -137,10 +137,23 @@ class UVLTrack(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("only the per-frame path forward_test is implemented (training forward is out of scope)")
 
-    def forward_prompt_init(self, *a, **k):
-        raise NotImplementedError("the prompter (heads/utils.py:23-99) is a 'next' row of SURVEY.md section 8f, not built yet")
+    def forward_prompt(self, out_dict, template_mask, context_mask):
+        """Reference uvltrack.py:33-38: new (target, distractor, background) prompt from a forward_test output dict."""
+        eng = self._get_engine(out_dict["search"].device)
+        return eng.forward_prompt(out_dict, template_mask, context_mask)
 
-    forward_prompt = forward_prompt_init
+    def forward_prompt_init(self, template, search, text, template_mask, context_mask, flag):
+        """Reference uvltrack.py:26-31: backbone on (template, context crop), then the prompter.  The backbone pass reuses
+        forward_test with a zero prompt (its head outputs are simply not used)."""
+        if not search.is_cuda:
+            raise NativeLibraryError("forward_prompt_init needs tensors on a HIP device (got %s); there is no CPU fallback" % search.device)
+        eng = self._get_engine(search.device)
+        ids, mask = text.tensors, text.mask
+        if mask is None:
+            mask = torch.ones_like(ids)
+        zero_prompt = torch.zeros(search.shape[0], 3, self.spec.dim, device=search.device)
+        out = eng.forward(template, search, ids, mask, zero_prompt, flag)
+        return eng.forward_prompt(out, template_mask, context_mask)
 
 
 def build_backbone(cfg):
