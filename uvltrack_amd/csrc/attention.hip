@@ -14,9 +14,9 @@
 //     and again on the fragment reads
 //   * scores are computed TRANSPOSED, S^T = K Q^T, so lane (q = lane&31) holds 16 of the 32 keys of its query
 //     column per 32-key block: row max / row sum are lane-local plus ONE cross-half exchange (__shfl_xor 32)
-//   * P^T feeds the second MFMA as the B operand with no data movement at all: the contraction slot of lane-half g,
-//     element e is bound to key (16t + 8(e>>2) + 4g + (e&3)), and the V^T A-operand is read from LDS in that same
-//     order (two ds_read_b64 per fragment)
+//   * P^T feeds the second MFMA as the B operand with no data movement at all: the K rows are fed to the first MFMA in a
+//     permuted order (bits 2,3 of the row swapped) so that the 8 score registers a lane-half owns per 16-key step ARE
+//     8 contiguous keys; the matching V^T A-operand is then one conflict-free ds_read_b128
 //   * O^T = V^T P^T accumulates [d][q]; the rescale factor and 1/l are per-lane scalars
 //   * softmax runs in the log2 domain: p = exp2(s * (log2e/8) + add - m), one v_fma + one v_exp per score when the
 //     tile carries no mask (a per-tile flag is set while the tile lands); the running max is only raised, and the
@@ -140,11 +140,18 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
 
     // lane-dependent LDS offsets of the fragments (tile-independent): K chunk 2kk+half of row lane&31 (+4096 for the
     // second 32-key block), V^T chunks 0..7 of row lane&31 (+4096 for the second 32 d-rows), 8-byte half = lane half
-    int koff[4], voff[8];
+    // The QK^T A-operand of lane m reads K row perm(m) = m with bits 2 and 3 swapped.  S^T register r of lane-half g then
+    // holds key 16(r>>3) + 8g + (r&7) of its 32-key block, i.e. every P fragment (registers 8t..8t+7) is 8 CONTIGUOUS
+    // keys and the matching V^T A-fragment is ONE conflict-free ds_read_b128 (chunk 4jb + 2t + g of row d).
+    const int m31 = lane & 31;
+    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
+    int koff[4], voff2[2][2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) koff[kk] = swz128(lane & 31, 2 * kk + half);
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = swz128(kperm, 2 * kk + half);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) voff[c] = swz128(lane & 31, c) + 8 * half;
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) voff2[jb][t] = swz128(m31, 4 * jb + 2 * t + half);
 
     f32x16 o[2];
 #pragma unroll
@@ -193,8 +200,8 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const float4 a4 = *reinterpret_cast<const float4*>(sA + 32 * jb + 8 * gq + 4 * half);
+                    for (int gq = 0; gq < 4; ++gq) {               // registers 4gq..4gq+3 = keys 16(gq>>1) + 8g + 4(gq&1) + 0..3
+                        const float4 a4 = *reinterpret_cast<const float4*>(sA + 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1));
                         const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -250,13 +257,10 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
                     union { uint32_t u[4]; bf16x8 v; } pf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t + 2 * e], s[jb][8 * t + 2 * e + 1]);
-                    const int ca = 4 * jb + 2 * t;                     // keys base+4g..+3 live in 16-byte chunk ca, base+8+4g.. in ca+1
 #pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        union { uint2 u[2]; bf16x8 v; } vf;
-                        vf.u[0] = *reinterpret_cast<const uint2*>(sV + db * 4096 + voff[ca]);
-                        vf.u[1] = *reinterpret_cast<const uint2*>(sV + db * 4096 + voff[ca + 1]);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+                    for (int db = 0; db < 2; ++db) {                   // V^T rows 32db + m, keys 32jb + 16t + 8g .. +7: one chunk
+                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + db * 4096 + voff2[jb][t]);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
                     }
                 }
         }
