@@ -126,6 +126,15 @@ int uvl_forward_prompt(uvl_model_t* m, int batch, const float* d_template_tokens
                        const uint8_t* d_template_mask, const uint8_t* d_context_mask, float* d_prompt_out,
                        void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Per-frame post-processing of the tracker on the device (lib/test/tracker/uvltrack.py:116-125: argmax of
+ * cls_score_test * hann window * softmax(cont_score)[0]; box scaled by search_size / resize_factor; map_box_back :167-173;
+ * clip_box lib/utils/box_ops.py:117-126 with `margin`).  d_cont_score may be NULL (TRAIN.CONT_WEIGHT == 0).
+ * d_window [S] f32 (np.outer(np.hanning(F), np.hanning(F))), d_state [B,4] previous box (x,y,w,h), d_resize_factor [B],
+ * d_image_hw [B,2] = (H, W).  Outputs: d_new_state [B,4]; optional d_score [B], d_box_net [B,4], d_index [B]. */
+int uvl_decode(uvl_model_t* m, int batch, const float* d_cls_score_test, const float* d_cont_score, const float* d_bbox_map,
+               const float* d_window, const float* d_state, const float* d_resize_factor, const float* d_image_hw,
+               float margin, float* d_new_state, float* d_score, float* d_box_net, int64_t* d_index, void* stream);
+
 /* hipGraph replay of the same call: capture once for fixed pointers/batch, then launch per frame. */
 int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out,
                       void* d_workspace, size_t workspace_bytes);

@@ -368,5 +368,51 @@ def box_masks(spec, batch, seed=0):
     return one(spec.template_size // 16), one(spec.feat_sz)
 
 
+# --------------------------------------------------------------------------
+# tracker decode ("next" row SURVEY.md 8f-2): lib/test/tracker/uvltrack.py:116-125,167-173 + box_ops.clip_box
+# --------------------------------------------------------------------------
+def hann_window(feat_sz):
+    """window_prior (tracker:64-68): np.outer(np.hanning(F), np.hanning(F)).flatten()."""
+    h = np.hanning(feat_sz)
+    return np.outer(h, h).flatten().astype(f32)
+
+
+def clip_box(box, H, W, margin=0):
+    """lib/utils/box_ops.py:117-126."""
+    x1, y1, w, h = box
+    x2, y2 = x1 + w, y1 + h
+    x1 = min(max(0, x1), W - margin)
+    x2 = min(max(margin, x2), W)
+    y1 = min(max(0, y1), H - margin)
+    y2 = min(max(margin, y2), H)
+    return [x1, y1, max(margin, x2 - x1), max(margin, y2 - y1)]
+
+
+def tracker_decode(cls_score_test, cont_score, bbox_map, window, state, resize_factor, image_hw, search_size, has_cont=True, margin=10):
+    """Per-sample post-processing of UVLTrack.track (tracker:116-125): argmax of cls * hann * softmax(cont)[0], scale the
+    box to the crop, map it back around the previous centre (map_box_back, tracker:167-173) and clip it.
+    Returns (new_state [B,4] xywh, score [B], pred_box_net [B,4], idx [B])."""
+    B = cls_score_test.shape[0]
+    new_state, scores, nets, idxs = [], [], [], []
+    for b in range(B):
+        pred_boxes = bbox_map[b].reshape(-1, 4)
+        pred_cls = cls_score_test[b].reshape(-1)
+        pred_cont = softmax(cont_score[b], -1)[:, 0] if has_cont else np.ones_like(pred_cls)
+        merge = pred_cls * window * pred_cont
+        i = int(np.argmax(merge))
+        net = pred_boxes[i]
+        score = float((pred_cls * pred_cont)[i])
+        cx, cy, w, h = (net.astype(np.float64) * search_size / float(resize_factor[b])).tolist()
+        sx, sy, sw, sh = [float(v) for v in state[b]]
+        cx_prev, cy_prev = sx + 0.5 * sw, sy + 0.5 * sh
+        half_side = 0.5 * search_size / float(resize_factor[b])
+        box = [cx + (cx_prev - half_side) - 0.5 * w, cy + (cy_prev - half_side) - 0.5 * h, w, h]
+        new_state.append(clip_box(box, float(image_hw[b][0]), float(image_hw[b][1]), margin=margin))
+        scores.append(score)
+        nets.append(net)
+        idxs.append(i)
+    return np.asarray(new_state, f32), np.asarray(scores, f32), np.asarray(nets, f32), np.asarray(idxs, np.int64)
+
+
 OUTPUT_KEYS = ("search", "template", "text", "vis_token", "txt_token", "logits", "cls_score",
                "cls_score_test", "bbox_map", "pred_boxes", "cont_score")

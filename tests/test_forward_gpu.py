@@ -59,6 +59,30 @@ def test_prompter_matches_reference_fixture(name):
     assert np.isfinite(got).all() and err <= tol, "prompt err %g > %g (abs-max %g)" % (err, tol, np.abs(want).max())
 
 
+def test_decode_matches_oracle():
+    """On-device tracker decode against the numpy restatement of tracker:116-125 on the same forward outputs."""
+    from oracle import uvl_oracle as O
+    meta, spec, ref = load_case("b_z128_x256")
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
+    B = meta["batch"]
+    window = O.hann_window(spec.feat_sz)
+    state = np.array([[100.0, 80.0, 60.0, 40.0], [5.0, 5.0, 30.0, 30.0], [600.0, 400.0, 80.0, 120.0]], np.float32)[:B]
+    resize = np.array([1.3, 0.9, 2.1], np.float32)[:B]
+    hw = np.array([[480.0, 640.0], [720.0, 1280.0], [480.0, 640.0]], np.float32)[:B]
+    new_state, score, net, idx = eng.decode(out, t(window), t(state), t(resize), t(hw))
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
+    e_state, e_score, e_net, e_idx = O.tracker_decode(got["cls_score_test"], got["cont_score"], got["bbox_map"], window, state, resize, hw,
+                                                      spec.search_size)
+    np.testing.assert_array_equal(idx.cpu().numpy(), e_idx)
+    np.testing.assert_allclose(new_state.cpu().numpy(), e_state, atol=2e-3, rtol=0)
+    np.testing.assert_allclose(score.cpu().numpy(), e_score, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(net.cpu().numpy(), e_net, atol=0, rtol=0)
+
+
 def test_forward_matches_oracle_per_sample_batch1():
     """Batch-1 calls (the tracker's shape) agree with the batched fixture run."""
     meta, spec, ref = load_case("tiny_mixed")

@@ -58,6 +58,32 @@ def test_oracle_prompter_matches_reference(name):
             np.testing.assert_array_equal(other[b], got[b])
 
 
+def test_oracle_clip_box_matches_reference_when_available():
+    """tracker decode row: clip_box is pinned against the reference's own function when /root/reference is present."""
+    from oracle import ref_import as R
+    if not R.reference_available():
+        pytest.skip("reference tree not present (GPU box)")
+    import importlib.util
+    import os
+    import re
+    import types
+    src = open(os.path.join(R.REF_ROOT, "lib", "utils", "box_ops.py")).read()
+    m = re.search(r"def clip_box\(.*?\n    return \[x1, y1, w, h\]\n", src, re.S)
+    assert m, "clip_box not found in the reference"
+    ns = {}
+    exec(compile(m.group(0), "ref_clip_box", "exec"), ns)            # run the reference's own function body, nothing is copied
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        box = (rng.uniform(-50, 700, 2).tolist() + rng.uniform(1, 300, 2).tolist())
+        H, W = rng.randint(100, 800, 2).tolist()
+        assert O.clip_box(list(box), H, W, margin=10) == ns["clip_box"](list(box), H, W, margin=10)
+
+
+def test_hann_window_shape_and_symmetry():
+    w = O.hann_window(16).reshape(16, 16)
+    assert w.shape == (16, 16) and np.allclose(w, w.T) and w[0].max() == 0.0 and abs(w.max() - np.hanning(16).max() ** 2) < 1e-7
+
+
 def test_mask_semantics_text_never_leaks_in_bbox_mode():
     """flag 0 masks every text key (extractor.py:43-50): visual outputs must not depend on the text ids."""
     meta, spec, _ = load_case("tiny_mixed")

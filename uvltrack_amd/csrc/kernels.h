@@ -113,6 +113,15 @@ struct PrompterParams {
 hipError_t launch_prompter_tokens(const PrompterParams& p, hipStream_t s);
 hipError_t launch_prompter_select(const float* src, const float* src0, const int64_t* flag, float* out, int B, int n_per_sample, hipStream_t s);
 
+// Tracker decode (tracker:116-125,167-173; box_ops.clip_box): argmax(cls * hann * softmax(cont)[0]) -> box in image coordinates.
+struct DecodeParams {
+    const float *cls = nullptr, *cont = nullptr, *bbox_map = nullptr, *window = nullptr;   // [B,S], [B,S,cont_ch] or null, [B,S,4], [S]
+    const float *state = nullptr, *resize_factor = nullptr, *image_hw = nullptr;            // [B,4] xywh, [B], [B,2] (H, W)
+    int B = 0, S = 0, cont_ch = 3; float search_size = 256.f, margin = 10.f;
+    float *new_state = nullptr, *score = nullptr, *box_net = nullptr; int64_t* index = nullptr;
+};
+hipError_t launch_decode(const DecodeParams& p, hipStream_t s);
+
 // out = relu(sum of split-K slabs) as bf16 (conv towers)
 hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_t* out, size_t n, hipStream_t s);
 

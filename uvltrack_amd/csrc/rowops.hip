@@ -583,6 +583,75 @@ hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tracker decode on the device (lib/test/tracker/uvltrack.py:116-125,167-173 + box_ops.clip_box :117-126): replaces the
+// three .cpu() round trips per frame with one tiny kernel.  One workgroup per sample.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+    __shared__ float red_v[256];
+    __shared__ int red_i[256];
+    const int b = blockIdx.x;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int s = threadIdx.x; s < p.S; s += 256) {
+        float pc = 1.0f;
+        if (p.cont) {
+            const float* cs = p.cont + ((size_t)b * p.S + s) * p.cont_ch;
+            float mx = cs[0];
+            for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k]);
+            float den = 0.f;
+            for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k] - mx);
+            pc = __expf(cs[0] - mx) / den;
+        }
+        const float m = p.cls[(size_t)b * p.S + s] * p.window[s] * pc;
+        if (m > best) { best = m; best_i = s; }
+    }
+    red_v[threadIdx.x] = best;
+    red_i[threadIdx.x] = best_i;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const float ov = red_v[threadIdx.x + st];
+            const int oi = red_i[threadIdx.x + st];
+            if (ov > red_v[threadIdx.x] || (ov == red_v[threadIdx.x] && oi < red_i[threadIdx.x])) { red_v[threadIdx.x] = ov; red_i[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const int i = red_i[0] < p.S ? red_i[0] : 0;
+    const float* net = p.bbox_map + ((size_t)b * p.S + i) * 4;
+    float pc = 1.0f;
+    if (p.cont) {
+        const float* cs = p.cont + ((size_t)b * p.S + i) * p.cont_ch;
+        float mx = cs[0];
+        for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k]);
+        float den = 0.f;
+        for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k] - mx);
+        pc = __expf(cs[0] - mx) / den;
+    }
+    const float rf = p.resize_factor[b], sc = p.search_size / rf;
+    const float cx = net[0] * sc, cy = net[1] * sc, w = net[2] * sc, h = net[3] * sc;
+    const float* st = p.state + (size_t)b * 4;
+    const float half_side = 0.5f * p.search_size / rf;
+    float x1 = cx + (st[0] + 0.5f * st[2] - half_side) - 0.5f * w;       // map_box_back
+    float y1 = cy + (st[1] + 0.5f * st[3] - half_side) - 0.5f * h;
+    const float H = p.image_hw[2 * b], W = p.image_hw[2 * b + 1], mg = p.margin;
+    float x2 = x1 + w, y2 = y1 + h;                                       // clip_box
+    x1 = fminf(fmaxf(0.f, x1), W - mg);
+    x2 = fminf(fmaxf(mg, x2), W);
+    y1 = fminf(fmaxf(0.f, y1), H - mg);
+    y2 = fminf(fmaxf(mg, y2), H);
+    float* o = p.new_state + (size_t)b * 4;
+    o[0] = x1; o[1] = y1; o[2] = fmaxf(mg, x2 - x1); o[3] = fmaxf(mg, y2 - y1);
+    if (p.score) p.score[b] = p.cls[(size_t)b * p.S + i] * pc;
+    if (p.box_net) for (int k = 0; k < 4; ++k) p.box_net[(size_t)b * 4 + k] = net[k];
+    if (p.index) p.index[b] = i;
+}
+hipError_t launch_decode(const DecodeParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(decode_kernel, dim3(p.B), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight prefetch: stream a weight blob through the memory-side cache ahead of the GEMM that will DMA it, so the
 // GEMM's tiles come from the Infinity Cache instead of HBM (batch-1 frames touch 274 MB of weights once each).
 // ------------------------------------------------------------------------------------------------

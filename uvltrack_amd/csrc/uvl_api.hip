@@ -881,6 +881,21 @@ extern "C" int uvl_forward_prompt(uvl_model_t* m, int batch, const float* d_temp
     return UVL_OK;
 }
 
+// ---- tracker decode (lib/test/tracker/uvltrack.py:116-125) ------------------------------------------------------
+extern "C" int uvl_decode(uvl_model_t* m, int batch, const float* d_cls_score_test, const float* d_cont_score, const float* d_bbox_map,
+                          const float* d_window, const float* d_state, const float* d_resize_factor, const float* d_image_hw,
+                          float margin, float* d_new_state, float* d_score, float* d_box_net, int64_t* d_index, void* stream) {
+    if (!m || !d_cls_score_test || !d_bbox_map || !d_window || !d_state || !d_resize_factor || !d_image_hw || !d_new_state || batch <= 0)
+        return fail(UVL_EINVAL, "uvl_decode: bad argument");
+    DecodeParams p;
+    p.cls = d_cls_score_test; p.cont = d_cont_score; p.bbox_map = d_bbox_map; p.window = d_window; p.state = d_state;
+    p.resize_factor = d_resize_factor; p.image_hw = d_image_hw; p.B = batch; p.S = m->S; p.cont_ch = m->cfg.softmax_one ? 3 : 2;
+    p.search_size = (float)m->cfg.search_size; p.margin = margin;
+    p.new_state = d_new_state; p.score = d_score; p.box_net = d_box_net; p.index = d_index;
+    HIPCHK(launch_decode(p, (hipStream_t)stream));
+    return UVL_OK;
+}
+
 // ---- per-kernel entry points -----------------------------------------------------------------------
 extern "C" int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
                           int accumulate, void* stream) {

@@ -233,6 +233,25 @@ class HipEngine:
         self._keep_prompt = (tem, ctx, vis, txt, flag, tm, cm)
         return prompt
 
+    def decode(self, out_dict, window, state, resize_factor, image_hw, margin: float = 10.0, has_cont: bool = True):
+        """Tracker post-processing on the device (tracker:116-125): returns (new_state [B,4] xywh, score [B], box_net [B,4], idx [B])."""
+        cls = out_dict["cls_score_test"].to(torch.float32).contiguous()
+        B = cls.shape[0]
+        cont = out_dict["cont_score"].to(torch.float32).contiguous() if has_cont else None
+        bbox = out_dict["bbox_map"].to(torch.float32).contiguous()
+        f = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
+        window, state, resize_factor, image_hw = f(window).reshape(-1), f(state).reshape(B, 4), f(resize_factor).reshape(B), f(image_hw).reshape(B, 2)
+        new_state = torch.empty(B, 4, device=self.device)
+        score = torch.empty(B, device=self.device)
+        net = torch.empty(B, 4, device=self.device)
+        idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        with torch.cuda.device(self.device):
+            _native.check(self.lib.uvl_decode(self.handle, B, p(cls), p(cont), p(bbox), p(window), p(state), p(resize_factor), p(image_hw),
+                                              C.c_float(margin), p(new_state), p(score), p(net), p(idx), self._stream()), "uvl_decode")
+        self._keep_decode = (cls, cont, bbox, window, state, resize_factor, image_hw)
+        return new_state, score, net, idx
+
     def profile_entries(self):
         """Per-launch-site breakdown of the last profile=True forward."""
         n = self.lib.uvl_profile_count(self.handle)
