@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
     constexpr int STAGE = KS * SLOT;
     constexpr int KV_PER_WAVE = (16 * KS) / NWAVES;      // K/V DMA instructions per wave per round (16 per slot)
     constexpr int LPW = KV_PER_WAVE + 1;                 // + one key_add DMA, issued only by the slot's owner wave (qw == 0)
-    static_assert((16 * KS) % NWAVES == 0 && LPW * (NS - 2) <= 63, "geometry");
+    constexpr int NSM2 = NS >= 2 ? NS - 2 : 0;           // NS == 1: "single shot" -- every key tile of the head is resident at once
+    static_assert((16 * KS) % NWAVES == 0 && LPW * NSM2 <= 63, "geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // NS * STAGE (>= the merge exchange area)
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -159,14 +160,15 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
     float m_run = -INFINITY, l_run = 0.f;                 // log2-domain running max, per-lane partial row sum
     constexpr float CS = 0.125f * ATTN_LOG2E;             // score scale folded with log2(e)
 
+    if (NS == 1) issue(0);                                // single shot: rounds == 1, all tiles requested at once
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < rounds) issue(t);
     for (int rd = 0; rd < rounds; ++rd) {
         const int ahead = rounds - 1 - rd;
-        if (ahead >= NS - 2) {                            // leave NS-2 rounds of this wave's own DMAs in flight
-            if (add_owner) attn_wait_vmcnt<LPW * (NS - 2)>();
-            else attn_wait_vmcnt<KV_PER_WAVE * (NS - 2)>();
+        if (NS >= 2 && ahead >= NS - 2) {                 // leave NS-2 rounds of this wave's own DMAs in flight
+            if (add_owner) attn_wait_vmcnt<LPW * NSM2>();
+            else attn_wait_vmcnt<KV_PER_WAVE * NSM2>();
         } else if (NS > 3 && ahead == 1) {
             if (add_owner) attn_wait_vmcnt<LPW>();
             else attn_wait_vmcnt<KV_PER_WAVE>();
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
         fixup(rd);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fix-up's LDS writes are done before the barrier
         __builtin_amdgcn_s_barrier();
-        if (rd + NS - 1 < rounds) issue(rd + NS - 1);     // its stage was last read in round rd-1
+        if (NS >= 2 && rd + NS - 1 < rounds) issue(rd + NS - 1);     // its stage was last read in round rd-1
         if (rd * KS + ks < nt) {
             const char* sK = smem + (rd % NS) * STAGE + ks * SLOT;
             const char* sV = sK + K_BYTES;
@@ -305,10 +307,9 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
         }
         lsum += __shfl_xor(lsum, 32, 64);
         const float inv = 1.0f / lsum;
-        constexpr int RPW = 32 / KS;                                   // accumulator registers merged by this wave
-#pragma unroll
-        for (int g4 = 0; g4 < RPW / 4; ++g4) {
-            const int r0 = ks * RPW + 4 * g4;                          // r0..r0+3: four consecutive d of one row group
+        // 8 groups of 4 accumulator registers (4 consecutive d of one row group); wave ks merges groups ks, ks+KS, ...
+        for (int g4 = ks; g4 < 8; g4 += KS) {
+            const int r0 = 4 * g4;
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -359,6 +360,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         const long wg4 = (long)((p.N + 127) / 128) * p.H * p.B;
         const int nt = (p.N + 63) / 64;
         if (wg4 >= 256 || nt < 2) cfg = 0;
+        else if (nt >= 5 && nt <= 6) cfg = 5;        // batch-1 latency shape: one wave per key tile, every tile in flight at once
+        else if (nt >= 7 && nt <= 9) cfg = 6;
         else if (nt >= 4) cfg = 2;
         else cfg = 1;
     }
@@ -368,6 +371,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 2: return launch_attn_cfg<1, 4, 2>(p, s);
         case 3: return launch_attn_cfg<4, 1, 3>(p, s);
         case 4: return launch_attn_cfg<1, 4, 3>(p, s);
+        case 5: return launch_attn_cfg<1, 6, 1>(p, s);     // single shot, up to 6 key tiles (N <= 384)
+        case 6: return launch_attn_cfg<1, 9, 1>(p, s);     // single shot, up to 9 key tiles (N <= 576): 150 KB of LDS
     }
     return hipErrorInvalidValue;
 }
