@@ -207,37 +207,56 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 __device__ uint32_t g_zero_page[64];      // 256 zero bytes: DMA source of out-of-image conv taps (zero padding)
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmParams p) {
     constexpr int BK = 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int ROWS = BM + BN;                    // stage = A rows then W rows, 128 B each
     constexpr int STAGE = ROWS * 128;
-    constexpr int LPT = ROWS / 32;                   // DMA instructions per wave per tile (each fills 8 rows)
-    constexpr int LPT_A = BM / 32;                   // the first LPT_A instructions of a wave fill A rows, the rest W rows
-    static_assert(WGM * WGN == 4 && BM % 32 == 0 && LPT * (NS - 2) <= 63, "geometry");
+    constexpr int NW = WGM * WGN;                    // waves per workgroup: 4 (tiles up to 128x128) or 8 (256-wide tiles)
+    constexpr int LPT = ROWS / (8 * NW);             // DMA instructions per wave per tile (each fills 8 rows)
+    constexpr int LPT_A = BM / (8 * NW);             // the first LPT_A instructions of a wave fill A rows, the rest W rows
+    static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && LPT * (NS - 2) <= 63, "geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int g = CONV ? blockIdx.z : 0;             // conv tower (group)
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
+    // Workgroup b runs on XCD b % 8 (dispatch order; affects speed only), and every XCD has its own L2.
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int nt = (idx / MT) * 8 + xcd, mt = idx % MT;
-    if (nt >= NT) return;
+    int nt, mt;
+    if (p.group_m == 0) {
+        // small M: an XCD owns whole N panels, so every weight byte enters exactly one L2; the few A rows are shared by all
+        nt = (idx / MT) * 8 + xcd;
+        mt = idx % MT;
+        if (nt >= NT) return;
+    } else {
+        // large M: A is the bigger operand.  Tiles are ordered in groups of group_m M-tiles x all N-tiles (M fastest), the
+        // order is cut into 8 contiguous runs, one per XCD: the ~64 tiles resident on an XCD form a near-square patch, so
+        // its L2 holds group_m A tiles + a few W panels instead of re-streaming all of A once per N panel.
+        const int T = MT * NT, base = T >> 3, rem = T & 7;
+        const int cnt = base + (xcd < rem ? 1 : 0);
+        if (idx >= cnt) return;
+        const int L = xcd * base + (xcd < rem ? xcd : rem) + idx;
+        const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
+        const int gm = min(p.group_m, MT - gi * p.group_m);
+        nt = within / gm;
+        mt = gi * p.group_m + (within - nt * gm);
+    }
     const int m0 = mt * BM, n0 = nt * BN;
 
     // split-K: blockIdx.y owns the K range [sk*K/splitk, (sk+1)*K/splitk) and writes its own f32 partial slab
     const int sk = blockIdx.y;
     const int kspan = p.K / p.splitk;
     const int kbase = sk * kspan;
-    // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + 4*i), +8)
+    // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + NW*i), +8)
     const bf16_t* src[LPT];
     int a_i[LPT_A], a_j[LPT_A];                              // conv: pixel of the A row this lane fetches
     const int convF = p.conv_F, cin_g = p.cin_g, lda = p.lda;
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        const int r = 8 * (wave + 4 * i) + (lane >> 3);
+        const int r = 8 * (wave + NW * i) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);        // logical 16-byte chunk that belongs at this physical slot
         if (i < LPT_A) {
             int gm = m0 + r;
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
                 gp = src[i] + kt * BK;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
         }
     };
 
@@ -324,9 +343,16 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmParams p) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false>
-static hipError_t launch_glds(const GemmParams& p, hipStream_t s) {
+static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
-    const int nblk = 8 * ((NT + 7) / 8) * MT;
+    p.group_m = 0;
+    if (!CONV) {
+        if (g_tune_gemm_gm == -1) { const char* e = getenv("UVL_GEMM_GM"); g_tune_gemm_gm = e ? atoi(e) : -2; }
+        if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
+        else if (MT >= 16) p.group_m = 8;
+    }
+    const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * 128;
     auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV>;
     static bool attr_done = false;
@@ -338,7 +364,7 @@ static hipError_t launch_glds(const GemmParams& p, hipStream_t s) {
     static char name[64];
     if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
     g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
 }
 
@@ -369,6 +395,7 @@ static bool use_v1() {
 
 // tuning override for tools/gemm_bench.py: -1 = heuristic, otherwise index into the config table below
 int g_tune_gemm_cfg = -1;
+int g_tune_gemm_gm = -1;
 
 template <int EPI>
 static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) {
@@ -384,6 +411,12 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 8: return launch_glds<128, 64, 2, 2, EPI, 3>(p, s);
         case 9: return launch_glds<128, 64, 2, 2, EPI, 2>(p, s);
         case 10: return launch_glds<64, 128, 2, 2, EPI, 2>(p, s);
+        // 8-wave workgroups, one per CU: the L2->LDS fill rate (not MFMA) bounds the 128-wide tiles at large M
+        case 11: return launch_glds<256, 256, 2, 4, EPI, 2>(p, s);
+        case 12: return launch_glds<256, 128, 2, 4, EPI, 2>(p, s);
+        case 13: return launch_glds<256, 128, 4, 2, EPI, 3>(p, s);
+        case 14: return launch_glds<128, 256, 2, 4, EPI, 3>(p, s);
+        case 15: return launch_glds<256, 128, 4, 2, EPI, 2>(p, s);
     }
     return hipErrorInvalidValue;
 }
@@ -404,7 +437,8 @@ template <int EPI, bool CONV>
 static hipError_t launch_epi(const GemmParams& p, int groups, hipStream_t s) {
     if (!CONV && groups == 1 && p.N % 64 == 0 && !use_v1()) {
         int cfg = pick_plain_cfg(p);
-        if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10) && p.N % 128 != 0) cfg = 0;
+        if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15) && p.N % 128 != 0) cfg = 0;
+        if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
         return launch_plain_cfg<EPI>(cfg, p, s);
     }
     if (p.N % 64 != 0) {

@@ -9,6 +9,7 @@ namespace uvl {
 // name of the kernel instantiation the last launcher picked (for per-kernel profiles)
 extern thread_local const char* g_last_kernel;
 extern int g_tune_attn_cfg;      // tools/attn_bench.py override of the attention configuration (-1 = heuristic)
+extern int g_tune_gemm_gm;       // override of the grouped tile order (-1 = heuristic, 0 = panel map, g = group of g M-tiles)
 extern int g_tune_gemm_cfg;      // tools/gemm_bench.py override of the plain-GEMM tile configuration (-1 = heuristic)
 
 struct GemmParams {
@@ -27,6 +28,8 @@ struct GemmParams {
     int splitk = 1; size_t part_stride = 0;      // split-K: slab sk of C (f32, + sk*part_stride elements) holds partial sums of K-range sk
     int conv_F = 0, cin_g = 0;                   // conv mode: feature-map side, input channels per group
     int a_goff[4] = {0, 0, 0, 0};                // conv mode: channel offset of each group's input inside a row
+    int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
+                                                 // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 
