@@ -38,6 +38,19 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact erf GELU: 0.5 x (1 + erf(x / sqrt(2)))  (nn.GELU default; bert_backbone.py:118-124)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Same function for the GEMM epilogues, where it runs once per output element: erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the bf16 rounding of the result), one v_rcp + one v_exp instead of libm's branchy erff.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+    const float erf_abs = 1.0f - poly * t * e;                 // erf(|x| / sqrt 2)
+    return 0.5f * x + 0.5f * fabsf(x) * erf_abs;               // 0.5 x (1 + sign(x) erf(|x|/sqrt 2))
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // MFMA 32x32x16 bf16 C/D fragment: register r of lane l holds

@@ -73,6 +73,60 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
 }
 
+// Epilogue of the pipelined kernel, which computes the tile TRANSPOSED (W fragments feed the MFMA row operand, A
+// fragments the column operand): lane l holds output row m = l & 31 and, per register quad q = r >> 2, the four
+// consecutive columns n = 8 q + 4 (l >> 5) + (r & 3).  Row-major outputs are therefore written 8 (bf16) or 16 (f32)
+// bytes per lane instead of one element, and all per-row index arithmetic happens once per lane.
+template <int TM, int TN, int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int g, int sk) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WM + i * 32 + (lane & 31);
+        if (row >= p.M) continue;
+        int b = 0, rem = row;
+        if (EPI != EPI_BF16) {
+            b = row / p.rpb;
+            rem = row - b * p.rpb;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (p.bias && sk == 0) v += *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.N + col);
+                if (EPI == EPI_BF16) {
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    uint2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + (size_t)g * p.N + col) = o;
+                } else if (EPI == EPI_F32) {
+                    if (p.addtab) v += *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
+                    float* dst = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    const int which = col / p.D, cc = col - which * p.D;
+                    const int hh = cc >> 6, dd = cc & 63;
+                    const size_t bh = (size_t)b * p.H + hh;
+                    if (which < 2) {
+                        uint2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<uint2*>((which == 0 ? p.q : p.k) + (bh * p.Npad + rem) * 64 + dd) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p.vt[(bh * 64 + dd + e) * p.Npad + rem] = f2bf(v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     constexpr int BK = 64;
@@ -336,10 +390,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue_t
         }
     }
-    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, g, sk);
+    gemm_epilogue_t<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, g, sk);
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false>
