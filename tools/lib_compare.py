@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
-CFGS = (6, 9, 10, 11, 12, 14, 15)
-GMS = (0, 4, 8, 16)
+CFGS = (4, 7, 9, 10, 6, 11)
+GMS = (0, 8)
 
 
 def p(t):

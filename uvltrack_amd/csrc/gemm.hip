@@ -478,13 +478,19 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
 static int pick_plain_cfg(const GemmParams& p) {
     if (g_tune_gemm_cfg == -1) { const char* e = getenv("UVL_GEMM_CFG"); g_tune_gemm_cfg = e ? atoi(e) : -2; }
     if (g_tune_gemm_cfg >= 0) return g_tune_gemm_cfg;
-    // measured on MI355X (tools/gemm_bench.py, profiles/): co-resident workgroups matter more than ring depth, so
-    // the 2-stage ring wins everywhere; small M keeps 64x64 tiles for parallelism, large M takes 64x128 / 128x64
-    const long t64 = (long)((p.M + 63) / 64) * (p.N / 64);
-    if (t64 < 1024) return 4;                       // 64x64, 3 stages: batch-1 panels stream from HBM, one more tile in flight pays
-    if (t64 < 2048) return 7;                       // 64x64, 2 stages
-    if (p.N % 128 == 0) return 10;                  // 64x128, 2 stages
-    return 9;                                       // 128x64, 2 stages
+    // measured on MI355X (tools/gemm_bench.py, tools/lib_compare.py, profiles/): co-resident workgroups matter more than
+    // ring depth, so the 2-stage ring wins once there are enough tiles; few tiles keep 64x64 for parallelism
+    const int mt64 = (p.M + 63) / 64;
+    const long t64 = (long)mt64 * (p.N / 64);
+    const bool n128 = p.N % 128 == 0;
+    if (mt64 < 16) {                                // one or two sequences: weight panels stream from HBM
+        if (t64 < 1024) return 4;                   // 64x64, 3 stages: one more tile in flight pays
+        if (t64 < 2048) return 7;                   // 64x64, 2 stages
+        return n128 ? 10 : 9;
+    }
+    if (t64 < 768) return 4;
+    if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
+    return n128 ? 6 : 9;                            // 128x128, 2 stages
 }
 
 template <int EPI, bool CONV>
