@@ -75,51 +75,88 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 
 // Epilogue of the pipelined kernel, which computes the tile TRANSPOSED (W fragments feed the MFMA row operand, A
 // fragments the column operand): lane l holds output row m = l & 31 and, per register quad q = r >> 2, the four
-// consecutive columns n = 8 q + 4 (l >> 5) + (r & 3).  Row-major outputs are therefore written 8 (bf16) or 16 (f32)
-// bytes per lane instead of one element, and all per-row index arithmetic happens once per lane.
-template <int TM, int TN, int WM, int WN, int EPI>
-__device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int g, int sk) {
+// consecutive columns n = 8 q + 4 (l >> 5) + (r & 3).  Bias / activation are applied in registers, then each wave
+// transposes 32 rows at a time through its own slice of the (now idle) LDS ring and writes them back row-major, 16 bytes
+// per lane: every store instruction covers whole 128-byte lines (measured on the fc1 shape at M = 17.7k,
+// tools/probes/gemm_probe.hip: 112 us, against 124 us for element-per-lane stores and 141 us for 8 bytes per lane on
+// 32 different rows).  V^T of the QKV projection is token-contiguous and is stored straight from registers.
+template <int TM, int TN, int WM, int WN, int EPI, int NW>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
+                                                  int lane, int wave, int g, int sk) {
+    constexpr int ES = (EPI == EPI_F32) ? 4 : 2;               // output element size
+    constexpr int RS = WN * ES + 16;                            // padded LDS row stride
+    constexpr int LPR = WN * ES / 16;                           // lanes per row on the way out
+    constexpr int RPI = 64 / LPR;                               // rows per store instruction
+    const int colw = n0 + wn * WN;                              // first column of this wave's sub-tile
+    const bool vpart = EPI == EPI_QKV && colw >= 2 * p.D;       // wave-uniform: D % 64 == 0 and WN divides 64
+    __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
+    char* cw = smem + wave * (32 * RS);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * WM + i * 32 + (lane & 31);
-        if (row >= p.M) continue;
-        int b = 0, rem = row;
-        if (EPI != EPI_BF16) {
-            b = row / p.rpb;
-            rem = row - b * p.rpb;
+        const int rowl = m0 + wm * WM + i * 32 + (lane & 31);
+        if (vpart) {
+            if (rowl < p.M) {
+                const int b = rowl / p.rpb, rem = rowl - b * p.rpb;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = colw + j * 32 + 8 * q + 4 * (lane >> 5);
+                        const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
+                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][4 * q + e] + bv[e]);
+                    }
+            }
+            continue;
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                const int cl = j * 32 + 8 * q + 4 * (lane >> 5);
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (p.bias && sk == 0) v += *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.N + col);
-                if (EPI == EPI_BF16) {
-                    if (p.act == 1) {
+                if (p.bias && sk == 0) v += *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.N + colw + cl);
+                if (EPI == EPI_F32) {
+                    *reinterpret_cast<f32x4*>(cw + (lane & 31) * RS + cl * 4) = v;
+                } else {
+                    if (EPI == EPI_BF16 && p.act == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
-                    } else if (p.act == 2) {
+                    } else if (EPI == EPI_BF16 && p.act == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     uint2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + (size_t)g * p.N + col) = o;
-                } else if (EPI == EPI_F32) {
+                    *reinterpret_cast<uint2*>(cw + (lane & 31) * RS + cl * 2) = o;
+                }
+            }
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int r = it * RPI + lane / LPR, c16 = lane % LPR;
+            const int row = m0 + wm * WM + i * 32 + r;
+            const int col = colw + c16 * (16 / ES);
+            if (EPI == EPI_F32) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
+                if (row < p.M) {
+                    const int b = row / p.rpb, rem = row - b * p.rpb;
                     if (p.addtab) v += *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
                     float* dst = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
                     if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
                     *reinterpret_cast<f32x4*>(dst) = v;
-                } else {
-                    const int which = col / p.D, cc = col - which * p.D;
-                    const int hh = cc >> 6, dd = cc & 63;
-                    const size_t bh = (size_t)b * p.H + hh;
-                    if (which < 2) {
-                        uint2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *reinterpret_cast<uint2*>((which == 0 ? p.q : p.k) + (bh * p.Npad + rem) * 64 + dd) = o;
+                }
+            } else {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(cw + r * RS + c16 * 16);
+                if (row < p.M) {
+                    if (EPI == EPI_BF16) {
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + (size_t)g * p.N + col) = v;
                     } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) p.vt[(bh * 64 + dd + e) * p.Npad + rem] = f2bf(v[e]);
+                        const int b = row / p.rpb, rem = row - b * p.rpb;
+                        const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
+                        const int hh = cc >> 6, dd = cc & 63;
+                        *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;
                     }
                 }
             }
@@ -390,10 +427,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue_t
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue_lds
         }
     }
-    gemm_epilogue_t<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, g, sk);
+    static_assert(32 * (WN * 4 + 16) * NW <= NS * STAGE, "epilogue staging fits in the ring");
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk);
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false>
