@@ -439,11 +439,9 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
     p.group_m = 0;
-    if (!CONV) {
-        if (g_tune_gemm_gm == -1) { const char* e = getenv("UVL_GEMM_GM"); g_tune_gemm_gm = e ? atoi(e) : -2; }
-        if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
-        else if (MT >= 16) p.group_m = 8;
-    }
+    if (g_tune_gemm_gm == -1) { const char* e = getenv("UVL_GEMM_GM"); g_tune_gemm_gm = e ? atoi(e) : -2; }
+    if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
+    else if (MT >= 16) p.group_m = 8;
     const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * 128;
     auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV>;
@@ -557,6 +555,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.conv_F > 0) {
         if (p.cin_g % 64 != 0) return hipErrorInvalidValue;
         if (!use_v1() && p.N % 64 == 0) {          // implicit GEMM on the LDS-DMA pipeline (optionally split-K into f32 slabs)
+            if (p.epi == EPI_BF16 && p.N % 128 == 0 && (long)(p.M / 128) * (p.N / 128) * groups >= 256)
+                return launch_glds<128, 128, 2, 2, EPI_BF16, 2, true>(p, s);   // batched frames: at least one 128x128 tile per CU
             if (p.epi == EPI_BF16) return launch_glds<64, 64, 2, 2, EPI_BF16, 3, true>(p, s);
             if (p.epi == EPI_F32) return launch_glds<64, 64, 2, 2, EPI_F32, 3, true>(p, s);
             return hipErrorInvalidValue;

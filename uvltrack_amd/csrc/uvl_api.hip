@@ -699,6 +699,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     const bf16_t* cin[4] = {w.G0, w.G1, w.G2, w.G3};
     bf16_t* cout[4] = {w.G1, w.G2, w.G3, w.G4};
     const int in_ld[4] = {g0_ld, 4 * C, 2 * C, C};
+    static const char* const conv_site[4] = {"conv3x3.0", "conv3x3.1", "conv3x3.2", "conv3x3.3"};
     for (int l = 0; l < 4; ++l) {
         const ConvLayerW& cw = m->conv[l];
         GemmParams p;
@@ -715,12 +716,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 if (nk % c == 0 && nk / c >= 6 && tiles * c <= 768) sk = c;
         if (sk > 1) {
             p.epi = 1; p.C = w.ConvPart; p.splitk = sk; p.part_stride = (size_t)p.M * p.ldc;
-            RUN_GEMM(L, s, p, "conv3x3");
+            RUN_GEMM(L, s, p, conv_site[l]);
             struct RCtx { const float* slabs; int sk; size_t stride; bf16_t* out; size_t n; } rc{w.ConvPart, sk, p.part_stride, cout[l], p.part_stride};
             L.run(s, "conv_fold", 0, 0, [](void* c, hipStream_t st) { auto* x = (RCtx*)c; return launch_slab_relu(x->slabs, x->sk, x->stride, x->out, x->n, st); }, &rc);
         } else {
             p.epi = 0; p.C = cout[l]; p.act = 2;
-            RUN_GEMM(L, s, p, "conv3x3");
+            RUN_GEMM(L, s, p, conv_site[l]);
         }
     }
     {
