@@ -135,6 +135,33 @@ int uvl_decode(uvl_model_t* m, int batch, const float* d_cls_score_test, const f
                const float* d_window, const float* d_state, const float* d_resize_factor, const float* d_image_hw,
                float margin, float* d_new_state, float* d_score, float* d_box_net, int64_t* d_index, void* stream);
 
+/* Per-frame pre-processing on the device.  Replaces `sample_target(im, bb, factor, output_sz)`
+ * (lib/train/data/processing_utils.py:159-243: square crop of side ceil(sqrt(w*h)*factor) around the box, zero border,
+ * cv2.resize to output_sz, attention mask of the border) followed by `Preprocessor_wo_mask.process`
+ * (lib/test/tracker/tracker_utils.py:20-29: (x/255 - mean)/std, HWC -> NCHW), as called at
+ * lib/test/tracker/uvltrack.py:89-101,110-112.  d_image: uint8 HWC frame on the device (row_stride_bytes >= 3*width).
+ * Outputs (each optional, at least one): d_patch_hwc [out,out,3] uint8 (what sample_target returns), d_norm_chw
+ * [3,out,out] f32 (what the preprocessor returns, the layout uvl_forward_test consumes), d_att_mask [out,out] 0/1.
+ * The resize follows OpenCV's 8-bit INTER_LINEAR fixed-point arithmetic (see oracle/preprocess_oracle.py).
+ * `geometry_out` (host, optional) receives the crop geometry incl. resize_factor = output_sz / crop_sz. */
+typedef struct uvl_crop_geometry {
+    int32_t crop_sz, x1, y1, x1_pad, x2_pad, y1_pad, y2_pad;
+    float resize_factor;
+} uvl_crop_geometry;
+int uvl_crop_geometry_of(const float box_xywh[4], float search_area_factor, int output_sz, int height, int width,
+                         uvl_crop_geometry* geometry_out);      /* host arithmetic only (processing_utils.py:173-193) */
+int uvl_sample_target(const uint8_t* d_image, int height, int width, int row_stride_bytes, const float box_xywh[4],
+                      float search_area_factor, int output_sz, uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask,
+                      uvl_crop_geometry* geometry_out, void* stream);
+/* Same, when only a window of the frame was uploaded: d_window holds frame pixels [win_y0, win_y0+win_height) x
+ * [win_x0, win_x0+win_width) and must cover the part of the crop that lies inside the frame (uvl_crop_geometry_of tells
+ * the host which part that is, so it can upload ~crop_sz^2 * 3 bytes instead of the frame). */
+int uvl_sample_target_window(const uint8_t* d_window, int win_x0, int win_y0, int win_width, int win_height, int row_stride_bytes,
+                             int frame_height, int frame_width, const float box_xywh[4], float search_area_factor, int output_sz,
+                             uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, uvl_crop_geometry* geometry_out, void* stream);
+/* Preprocessor_wo_mask.process alone, on an already cropped uint8 HWC patch. */
+int uvl_normalize_u8(const uint8_t* d_patch_hwc, int height, int width, float* d_norm_chw, void* stream);
+
 /* hipGraph replay of the same call: capture once for fixed pointers/batch, then launch per frame. */
 int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl_outputs* out,
                       void* d_workspace, size_t workspace_bytes);

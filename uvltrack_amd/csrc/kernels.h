@@ -125,6 +125,19 @@ struct DecodeParams {
 };
 hipError_t launch_decode(const DecodeParams& p, hipStream_t s);
 
+// sample_target + Preprocessor_wo_mask on the uint8 frame (processing_utils.py:159-243, tracker_utils.py:20-29); see preprocess.hip
+struct PreprocParams {
+    const uint8_t* img = nullptr; int H = 0, W = 0, stride = 0;          // HWC uint8 frame (or a window of it), `stride` bytes per row
+    int ox = 0, oy = 0;                                                   // frame coordinates of img's pixel (0,0) when img is a window
+    int crop_sz = 0, x1 = 0, y1 = 0, x1_pad = 0, x2_pad = 0, y1_pad = 0, y2_pad = 0;   // crop geometry (host, integer)
+    int out = 0;                                                          // output side
+    uint8_t* patch = nullptr;                                             // [out,out,3] uint8, optional
+    float* norm = nullptr;                                                // [3,out,out] f32 normalised, optional
+    uint8_t* att = nullptr;                                               // [out,out] 0/1 attention mask of the padded area, optional
+};
+hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);
+hipError_t launch_normalize_u8(const uint8_t* src, float* dst, int n_pix, hipStream_t s);
+
 // out = relu(sum of split-K slabs) as bf16 (conv towers)
 hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_t* out, size_t n, hipStream_t s);
 

@@ -898,6 +898,69 @@ extern "C" int uvl_decode(uvl_model_t* m, int batch, const float* d_cls_score_te
     return UVL_OK;
 }
 
+// ---- pre-processing --------------------------------------------------------------------
+// Crop geometry of sample_target (processing_utils.py:173-193): plain integer / double arithmetic on the host, Python's
+// round() is round-half-to-even = nearbyint in the default rounding mode.
+extern "C" int uvl_crop_geometry_of(const float box_xywh[4], float search_area_factor, int output_sz, int height, int width, uvl_crop_geometry* g) {
+    if (!box_xywh || !g || height <= 0 || width <= 0) return fail(UVL_EINVAL, "uvl_crop_geometry_of: bad argument");
+    const double x = box_xywh[0], y = box_xywh[1], w = box_xywh[2], h = box_xywh[3];
+    const double c = std::ceil(std::sqrt(w * h) * (double)search_area_factor);
+    if (!(c >= 1.0) || c > 1e8) return fail(UVL_EINVAL, "uvl_crop_geometry_of: too small (or absurd) bounding box");
+    g->crop_sz = (int)c;
+    g->x1 = (int)std::nearbyint(x + 0.5 * w - c * 0.5);
+    g->y1 = (int)std::nearbyint(y + 0.5 * h - c * 0.5);
+    const int x2 = g->x1 + g->crop_sz, y2 = g->y1 + g->crop_sz;
+    g->x1_pad = std::max(0, -g->x1);
+    g->x2_pad = std::max(x2 - width + 1, 0);
+    g->y1_pad = std::max(0, -g->y1);
+    g->y2_pad = std::max(y2 - height + 1, 0);
+    g->resize_factor = output_sz > 0 ? (float)((double)output_sz / c) : 1.0f;
+    if (g->x1 + g->x1_pad >= x2 - g->x2_pad || g->y1 + g->y1_pad >= y2 - g->y2_pad)
+        return fail(UVL_EINVAL, "uvl_crop_geometry_of: the crop does not intersect the image");
+    return UVL_OK;
+}
+
+static int sample_target_impl(const uint8_t* d_buf, int ox, int oy, int bw, int bh, int row_stride_bytes, int height, int width,
+                              const float box_xywh[4], float search_area_factor, int output_sz, uint8_t* d_patch_hwc, float* d_norm_chw,
+                              uint8_t* d_att_mask, uvl_crop_geometry* geometry_out, void* stream) {
+    if (!d_buf || output_sz <= 0 || bw <= 0 || bh <= 0 || row_stride_bytes < 3 * bw) return fail(UVL_EINVAL, "uvl_sample_target: bad argument");
+    if (!d_patch_hwc && !d_norm_chw && !d_att_mask) return fail(UVL_EINVAL, "uvl_sample_target: no output requested");
+    uvl_crop_geometry g;
+    const int rc = uvl_crop_geometry_of(box_xywh, search_area_factor, output_sz, height, width, &g);
+    if (rc) return rc;
+    // the kept part of the crop, [x1+x1_pad, x2-x2_pad) x [y1+y1_pad, y2-y2_pad), must lie inside the buffer
+    const int kx0 = g.x1 + g.x1_pad, kx1 = g.x1 + g.crop_sz - g.x2_pad, ky0 = g.y1 + g.y1_pad, ky1 = g.y1 + g.crop_sz - g.y2_pad;
+    if (kx0 < ox || ky0 < oy || kx1 > ox + bw || ky1 > oy + bh) return fail(UVL_EINVAL, "uvl_sample_target: the window does not cover the crop");
+    PreprocParams p;
+    p.img = d_buf; p.H = height; p.W = width; p.stride = row_stride_bytes; p.ox = ox; p.oy = oy;
+    p.crop_sz = g.crop_sz; p.x1 = g.x1; p.y1 = g.y1; p.x1_pad = g.x1_pad; p.x2_pad = g.x2_pad; p.y1_pad = g.y1_pad; p.y2_pad = g.y2_pad;
+    p.out = output_sz; p.patch = d_patch_hwc; p.norm = d_norm_chw; p.att = d_att_mask;
+    HIPCHK(launch_preprocess(p, (hipStream_t)stream));
+    if (geometry_out) *geometry_out = g;
+    return UVL_OK;
+}
+
+extern "C" int uvl_sample_target(const uint8_t* d_image, int height, int width, int row_stride_bytes, const float box_xywh[4],
+                                 float search_area_factor, int output_sz, uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask,
+                                 uvl_crop_geometry* geometry_out, void* stream) {
+    return sample_target_impl(d_image, 0, 0, width, height, row_stride_bytes, height, width, box_xywh, search_area_factor, output_sz,
+                              d_patch_hwc, d_norm_chw, d_att_mask, geometry_out, stream);
+}
+
+extern "C" int uvl_sample_target_window(const uint8_t* d_window, int win_x0, int win_y0, int win_width, int win_height, int row_stride_bytes,
+                                        int frame_height, int frame_width, const float box_xywh[4], float search_area_factor, int output_sz,
+                                        uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, uvl_crop_geometry* geometry_out,
+                                        void* stream) {
+    return sample_target_impl(d_window, win_x0, win_y0, win_width, win_height, row_stride_bytes, frame_height, frame_width, box_xywh,
+                              search_area_factor, output_sz, d_patch_hwc, d_norm_chw, d_att_mask, geometry_out, stream);
+}
+
+extern "C" int uvl_normalize_u8(const uint8_t* d_patch_hwc, int height, int width, float* d_norm_chw, void* stream) {
+    if (!d_patch_hwc || !d_norm_chw || height <= 0 || width <= 0) return fail(UVL_EINVAL, "uvl_normalize_u8: bad argument");
+    HIPCHK(launch_normalize_u8(d_patch_hwc, d_norm_chw, height * width, (hipStream_t)stream));
+    return UVL_OK;
+}
+
 // ---- per-kernel entry points -----------------------------------------------------------------------
 extern "C" int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
                           int accumulate, void* stream) {

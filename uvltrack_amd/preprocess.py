@@ -1,0 +1,142 @@
+"""Host side of the device pre-processing: the reference's `sample_target`
+(lib/train/data/processing_utils.py:159-243) and `Preprocessor_wo_mask` (lib/test/tracker/tracker_utils.py:20-29)
+with the same call signatures, backed by `uvl_sample_target` / `uvl_normalize_u8` of the HIP library.
+
+The frame is uploaded as uint8 (1 byte per pixel) -- or is already a CUDA uint8 tensor -- and the crop, zero border,
+bilinear resize and normalisation happen in one kernel.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _frame_on_device(im) -> torch.Tensor:
+    """HxWx3 uint8 numpy array or tensor -> contiguous CUDA uint8 tensor (an upload of 3 bytes per pixel at most)."""
+    if isinstance(im, np.ndarray):
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise ValueError("sample_target expects an HxWx3 uint8 image")
+        im = torch.from_numpy(np.ascontiguousarray(im))
+    if not torch.is_tensor(im) or im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+        raise ValueError("sample_target expects an HxWx3 uint8 image")
+    if not torch.cuda.is_available():
+        raise _native.NativeLibraryError("sample_target runs on the GPU only (no CPU fallback)")
+    return im.cuda(non_blocking=True).contiguous()
+
+
+def crop_geometry(target_bb, search_area_factor: float, output_sz: int, height: int, width: int) -> _native.UvlCropGeometry:
+    """The integer crop geometry of sample_target (processing_utils.py:173-193), computed by the library's host code."""
+    lib = _native.load()
+    box = (C.c_float * 4)(*[float(v) for v in (target_bb.tolist() if hasattr(target_bb, "tolist") else target_bb)])
+    g = _native.UvlCropGeometry()
+    _native.check(lib.uvl_crop_geometry_of(box, float(search_area_factor), int(output_sz or 0), int(height), int(width), C.byref(g)),
+                  "uvl_crop_geometry_of")
+    return g
+
+
+def sample_target_fused(im, target_bb, search_area_factor: float, output_sz: int, want_patch: bool = True, want_norm: bool = True,
+                        want_mask: bool = True, image_out: torch.Tensor = None):
+    """One launch: returns dict(patch uint8 [out,out,3] | None, image f32 [1,3,out,out] | None, att_mask bool [out,out] | None,
+    resize_factor, bbox [1,1,4], geometry).  `image_out` (contiguous CUDA f32 [1,3,out,out]) receives the normalised image in
+    place -- e.g. the `search` buffer a captured / pre-validated forward step reads."""
+    lib = _native.load()
+    frame = _frame_on_device(im)
+    H, W = int(frame.shape[0]), int(frame.shape[1])
+    out = int(output_sz)
+    dev = frame.device
+    patch = torch.empty((out, out, 3), dtype=torch.uint8, device=dev) if want_patch else None
+    norm = None
+    if image_out is not None:
+        if not (image_out.is_cuda and image_out.dtype == torch.float32 and image_out.is_contiguous() and image_out.numel() == 3 * out * out):
+            raise ValueError("image_out must be a contiguous CUDA float32 tensor of 3*out*out elements")
+        norm = image_out
+    elif want_norm:
+        norm = torch.empty((1, 3, out, out), dtype=torch.float32, device=dev)
+    att = torch.empty((out, out), dtype=torch.uint8, device=dev) if want_mask else None
+    bb = [float(v) for v in (target_bb.tolist() if hasattr(target_bb, "tolist") else target_bb)]
+    box = (C.c_float * 4)(*bb)
+    g = _native.UvlCropGeometry()
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    _native.check(lib.uvl_sample_target(ptr(frame), H, W, int(frame.stride(0)), box, float(search_area_factor), out, ptr(patch), ptr(norm),
+                                        ptr(att), C.byref(g), _stream()), "uvl_sample_target")
+    x, y, w, h = bb
+    cs = float(g.crop_sz)
+    bbox = torch.tensor([[[0.5 - w / cs / 2, 0.5 - h / cs / 2, w / cs, h / cs]]])
+    return dict(patch=patch, image=norm, att_mask=att.bool() if att is not None else None, resize_factor=out / cs, bbox=bbox, geometry=g,
+                _keep=frame)
+
+
+class WindowUploader:
+    """Uploads only the part of a host frame that a crop needs (about crop_sz^2 * 3 bytes instead of H*W*3) through a
+    pinned staging buffer, then runs the fused kernel on that window (`uvl_sample_target_window`)."""
+
+    def __init__(self, max_side: int = 2048, device="cuda"):
+        self.stage = torch.empty(max_side * max_side * 3, dtype=torch.uint8).pin_memory()     # flat: every window is one contiguous copy
+        self.dev = torch.empty(max_side * max_side * 3, dtype=torch.uint8, device=device)
+        self.max_side = max_side
+
+    def sample_target(self, im: np.ndarray, target_bb, search_area_factor: float, output_sz: int, image_out: torch.Tensor = None,
+                      want_patch: bool = False, want_mask: bool = False):
+        if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
+            raise ValueError("WindowUploader expects an HxWx3 uint8 numpy frame")
+        lib = _native.load()
+        H, W = im.shape[:2]
+        g = crop_geometry(target_bb, search_area_factor, output_sz, H, W)
+        x0, x1 = g.x1 + g.x1_pad, g.x1 + g.crop_sz - g.x2_pad
+        y0, y1 = g.y1 + g.y1_pad, g.y1 + g.crop_sz - g.y2_pad
+        ww, wh = x1 - x0, y1 - y0
+        if ww > self.max_side or wh > self.max_side:
+            raise ValueError("crop window %dx%d exceeds the staging buffer" % (ww, wh))
+        nbytes = wh * ww * 3
+        stage = self.stage[:nbytes]
+        np.copyto(stage.numpy().reshape(wh, ww, 3), im[y0:y1, x0:x1])   # host gather into pinned memory
+        dwin = self.dev[:nbytes]
+        dwin.copy_(stage, non_blocking=True)
+        out = int(output_sz)
+        dev = self.dev.device
+        patch = torch.empty((out, out, 3), dtype=torch.uint8, device=dev) if want_patch else None
+        att = torch.empty((out, out), dtype=torch.uint8, device=dev) if want_mask else None
+        norm = image_out if image_out is not None else torch.empty((1, 3, out, out), dtype=torch.float32, device=dev)
+        bb = [float(v) for v in (target_bb.tolist() if hasattr(target_bb, "tolist") else target_bb)]
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        gg = _native.UvlCropGeometry()
+        _native.check(lib.uvl_sample_target_window(ptr(dwin), x0, y0, ww, wh, ww * 3, H, W, (C.c_float * 4)(*bb),
+                                                   float(search_area_factor), out, ptr(patch), ptr(norm), ptr(att), C.byref(gg), _stream()),
+                      "uvl_sample_target_window")
+        return dict(patch=patch, image=norm, att_mask=att.bool() if att is not None else None, resize_factor=out / float(gg.crop_sz), geometry=gg)
+
+
+def sample_target(im, target_bb, search_area_factor, output_sz=None, mask=None, return_bbox=False):
+    """Drop-in for processing_utils.sample_target (the tracker's call sites: lib/test/tracker/uvltrack.py:89-90,98-99,110-111).
+    Returns (patch, resize_factor, att_mask[, bbox]) like the reference, with `patch` / `att_mask` as CUDA tensors
+    (uint8 [out,out,3] / bool [out,out]) instead of numpy arrays; feed `patch` to `Preprocessor_wo_mask.process`."""
+    if output_sz is None or mask is not None:
+        raise NotImplementedError("only the tracker's form sample_target(im, bb, factor, output_sz=..., mask=None) is built")
+    r = sample_target_fused(im, target_bb, search_area_factor, output_sz, want_patch=True, want_norm=False, want_mask=True)
+    if return_bbox:
+        return r["patch"], r["resize_factor"], r["att_mask"], r["bbox"]
+    return r["patch"], r["resize_factor"], r["att_mask"]
+
+
+class Preprocessor_wo_mask(object):
+    """tracker_utils.py:20-29: uint8 HxWx3 patch -> normalised float [1,3,H,W] on the GPU."""
+
+    def __init__(self):
+        self.mean = torch.tensor([0.485, 0.456, 0.406]).view((1, 3, 1, 1))
+        self.std = torch.tensor([0.229, 0.224, 0.225]).view((1, 3, 1, 1))
+
+    def process(self, img_arr):
+        lib = _native.load()
+        patch = _frame_on_device(img_arr)
+        H, W = int(patch.shape[0]), int(patch.shape[1])
+        out = torch.empty((1, 3, H, W), dtype=torch.float32, device=patch.device)
+        _native.check(lib.uvl_normalize_u8(C.c_void_p(patch.data_ptr()), H, W, C.c_void_p(out.data_ptr()), _stream()), "uvl_normalize_u8")
+        return out
