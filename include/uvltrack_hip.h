@@ -135,6 +135,15 @@ int uvl_decode(uvl_model_t* m, int batch, const float* d_cls_score_test, const f
                const float* d_window, const float* d_state, const float* d_resize_factor, const float* d_image_hw,
                float margin, float* d_new_state, float* d_score, float* d_box_net, int64_t* d_index, void* stream);
 
+/* UVLTrack.forward (lib/models/uvltrack/uvltrack.py:18-24) in eval mode -- the call of the tracker's grounding() at sequence
+ * init in NL mode (lib/test/tracker/uvltrack.py:45-62).  Same backbone as uvl_forward_test; the head takes
+ * its no-prompt branch (modality_adaptive_box_head.py:123-138): the prompter runs inline on the search tokens rolled by
+ * batch/2 (d_template_mask [B,nz], d_context_mask [B,S], 1 = target cell), `out->d_cont_score` is [B,S,2] and the computed
+ * prompt [B,3,D] ("prompts" of the reference's dict) goes to d_prompts_out.  out->d_search / d_template / d_vis_token /
+ * d_txt_token are required; in->d_prompt is ignored.  Needs the prompter weights. */
+int uvl_forward(uvl_model_t* m, const uvl_inputs* in, const uint8_t* d_template_mask, const uint8_t* d_context_mask,
+                const uvl_outputs* out, float* d_prompts_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Per-frame pre-processing on the device.  Replaces `sample_target(im, bb, factor, output_sz)`
  * (lib/train/data/processing_utils.py:159-243: square crop of side ceil(sqrt(w*h)*factor) around the box, zero border,
  * cv2.resize to output_sz, attention mask of the border) followed by `Preprocessor_wo_mask.process`

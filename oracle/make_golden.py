@@ -32,6 +32,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file
 
 FULL_KEYS = ("logits", "cls_score", "cls_score_test", "bbox_map", "pred_boxes", "cont_score", "vis_token", "txt_token")
 SLICE_KEYS = ("search", "template", "text")     # stored as [:, :8, :32]
+FWD_KEYS = ("cont_score", "bbox_map", "pred_boxes", "cls_score", "cls_score_test", "prompts")
 
 
 def cases():
@@ -67,6 +68,9 @@ def run_case(name, case):
     dev = {k: float(np.abs(ref[k] - mine[k]).max()) for k in O.OUTPUT_KEYS}
     mine_prompt = O.forward_prompt_init(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], tem_mask, ctx_mask, inp["flag"])
     dev["prompt_init"] = float(np.abs(ref["prompt_init"] - mine_prompt).max())
+    mine_fwd = O.forward(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], tem_mask, ctx_mask, inp["flag"])
+    for k in FWD_KEYS:
+        dev["fwd." + k] = float(np.abs(ref["fwd." + k] - mine_fwd[k]).max())
     out = {"meta": np.frombuffer(json.dumps({
         "name": name, "spec": spec.to_dict(), "weight_seed": case["seed"], "input_seed": case["in_seed"],
         "batch": case["batch"], "flags": case["flags"], "zero_text": bool(case.get("zero_text")),
@@ -85,6 +89,8 @@ def run_case(name, case):
             out["ref." + k] = ref[k].astype(np.float32)
     out["ref.flag"] = ref["flag"].astype(np.int64)
     out["ref.prompt_init"] = ref["prompt_init"].astype(np.float32)      # forward_prompt_init with oracle.box_masks(seed=in_seed)
+    for k in FWD_KEYS:                                                  # UVLTrack.forward (eval) with the same masks
+        out["ref.fwd." + k] = ref["fwd." + k].astype(np.float32)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     np.savez_compressed(path, **out)

@@ -174,6 +174,7 @@ def run_reference(spec, sd_np, inputs, tap_layers=False, prompt_masks=None):
         out = model.forward_test(torch.from_numpy(inputs["template"]), torch.from_numpy(inputs["search"]), text,
                                  torch.from_numpy(inputs["prompt"]), torch.from_numpy(inputs["flag"]))
         prompt_init = None
+        fwd = None
         if prompt_masks is not None:
             orig_cuda = torch.Tensor.cuda
             torch.Tensor.cuda = lambda self, *a, **k: self          # heads/utils.py:96 hard-codes .cuda()
@@ -182,6 +183,11 @@ def run_reference(spec, sd_np, inputs, tap_layers=False, prompt_masks=None):
                 prompt_init = model.forward_prompt_init(torch.from_numpy(inputs["template"]), torch.from_numpy(inputs["search"]), text2,
                                                         torch.from_numpy(prompt_masks[0]), torch.from_numpy(prompt_masks[1]),
                                                         torch.from_numpy(inputs["flag"])).detach().numpy().copy()
+                # UVLTrack.forward in eval mode (the grounding call, tracker:57): head on its no-prompt branch
+                text3 = NestedTensor(torch.from_numpy(inputs["ids"]), torch.from_numpy(inputs["mask"]))
+                fo = model.forward(torch.from_numpy(inputs["template"]), torch.from_numpy(inputs["search"]), text3,
+                                   torch.from_numpy(prompt_masks[0]), torch.from_numpy(prompt_masks[1]), torch.from_numpy(inputs["flag"]))
+                fwd = {k: fo[k].detach().numpy().copy() for k in ("cont_score", "bbox_map", "pred_boxes", "cls_score", "cls_score_test", "prompts")}
             finally:
                 torch.Tensor.cuda = orig_cuda
     for h in hooks:
@@ -189,6 +195,9 @@ def run_reference(spec, sd_np, inputs, tap_layers=False, prompt_masks=None):
     res = {k: v.detach().numpy().copy() for k, v in out.items() if hasattr(v, "detach")}
     if prompt_init is not None:
         res["prompt_init"] = prompt_init
+    if fwd is not None:
+        for k, v in fwd.items():
+            res["fwd." + k] = v
     res.update(taps)
     release_reference_modules()
     return res

@@ -248,13 +248,37 @@ def head_contrast(sd, spec, search, prompt):
     return np.concatenate([cs[:, :, :1], cs[:, :, 1:].max(-1, keepdims=True)], axis=-1).astype(f32)
 
 
-def head_forward(sd, spec, out, prompt):
-    """ModalityAdaptiveBoxHead.forward (head:62-94) + convert2bbox (head:108-119)."""
+def head_contrast_train(sd, spec, out, tem_mask, ctx_mask):
+    """ModalityAdaptiveBoxHead.contractive_learning with no prompt in the dict (head:123-138) -- the branch
+    UVLTrack.forward takes (grounding at sequence init, lib/test/tracker/uvltrack.py:57): the prompter runs inline on a
+    context rolled by half a batch and cont_score has TWO channels.  Returns (cont_score [B,S,2], prompt [B,3,D])."""
+    flag = np.asarray(out["flag"]).reshape(-1)
+    B = flag.shape[0]
+    vt, tt = out["vis_token"], out["txt_token"]
+    grp = np.concatenate([vt, tt, (vt + tt) / f32(2.0)], axis=1)
+    token = grp[np.arange(B), flag]
+    search = out["search"]
+    context = np.concatenate([search[B // 2:], search[:B // 2]], axis=0)
+    prompt = prompter_forward(sd, out["template"], tem_mask, context, ctx_mask, token, flag)
+    tau = np.exp(sd["box_head.logit_scale"]).astype(f32)
+    cs = tau * (l2_normalize(search) @ l2_normalize(prompt).transpose(0, 2, 1))
+    if spec.softmax_one:
+        zero = np.zeros_like(cs[:, :, :1])
+        mid = np.concatenate([cs[:, :, 1:], zero], axis=-1).max(-1, keepdims=True)
+    else:
+        mid = cs[:, :, 1:].max(-1, keepdims=True)
+    return np.concatenate([cs[:, :, :1], mid], axis=-1).astype(f32), prompt
+
+
+def head_forward(sd, spec, out, prompt, cont=None):
+    """ModalityAdaptiveBoxHead.forward (head:62-94) + convert2bbox (head:108-119).  `cont` given = the training-branch
+    cont_score of head_contrast_train."""
     flag = out["flag"]
     B = flag.shape[0]
     F = spec.feat_sz
     bid = np.arange(B)
-    cont = head_contrast(sd, spec, out["search"], prompt)
+    if cont is None:
+        cont = head_contrast(sd, spec, out["search"], prompt)
     x = out["search"].transpose(0, 2, 1).reshape(B, -1, F, F)
     if spec.cls_tokenize:
         vt, tt = out["vis_token"], out["txt_token"]
@@ -294,6 +318,16 @@ def forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps=None
     out = backbone_forward(sd, spec, template.astype(f32), search.astype(f32), np.asarray(ids), np.asarray(tmask),
                            np.asarray(flag).reshape(-1, 1), taps)
     return head_forward(sd, spec, out, prompt.astype(f32))
+
+
+def forward(sd, spec, template, search, ids, tmask, tem_mask, ctx_mask, flag):
+    """UVLTrack.forward (uvltrack.py:18-24) in eval mode: backbone, then the head on its no-prompt branch.  This is what the
+    tracker's grounding() runs at sequence init in NL mode (lib/test/tracker/uvltrack.py:45-62)."""
+    sd = {k: (np.asarray(v, dtype=f32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in sd.items()}
+    out = backbone_forward(sd, spec, template.astype(f32), search.astype(f32), np.asarray(ids), np.asarray(tmask),
+                           np.asarray(flag).reshape(-1, 1))
+    cont, prompt = head_contrast_train(sd, spec, out, np.asarray(tem_mask).astype(bool), np.asarray(ctx_mask).astype(bool))
+    return head_forward(sd, spec, out, prompt, cont=cont)
 
 
 # --------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def compare_outputs(got, ref, skip=(), depth=12):
     report, ok = {}, True
     scale = max(1.0, depth / 12.0)
     for k, v in ref.items():
-        if k in ("flag", "prompt_init") or k in skip or k.split(".")[0] in skip:
+        if k in ("flag", "prompt_init") or k.startswith("fwd.") or k in skip or k.split(".")[0] in skip:
             continue
         name = k[:-6] if k.endswith(".slice") else k
         if name not in got or name == "pred_boxes":

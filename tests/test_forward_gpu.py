@@ -59,6 +59,35 @@ def test_prompter_matches_reference_fixture(name):
     assert np.isfinite(got).all() and err <= tol, "prompt err %g > %g (abs-max %g)" % (err, tol, np.abs(want).max())
 
 
+@pytest.mark.parametrize("name", [c for c in list_cases() if not c.startswith("l_")])
+def test_forward_no_prompt_branch_matches_reference_fixture(name):
+    """UVLTrack.forward in eval mode (the grounding call) against the reference's outputs for the same masks:
+    inline prompter on the batch-rolled context, two-channel cont_score, then the usual head."""
+    from oracle import uvl_oracle as O
+    from tests.parity_util import ATOL, softmax_np
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    tem_mask, ctx_mask = O.box_masks(spec, meta["batch"], seed=meta["input_seed"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = eng.forward_full(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(tem_mask), t(ctx_mask), t(inp["flag"]))
+    torch.cuda.synchronize()
+    B = meta["batch"]
+    scale = max(1.0, spec.depth / 12.0)
+    assert tuple(out["cont_score"].shape) == (B, spec.nx, 2)
+    for k in ("cont_score", "bbox_map", "cls_score", "cls_score_test"):
+        got, want = out[k].cpu().numpy(), ref["fwd." + k]
+        err = np.abs(got - want).max()
+        assert np.isfinite(got).all() and err <= ATOL[k] * scale, "%s err %g" % (k, err)
+    got, want = out["prompts"].cpu().numpy(), ref["fwd.prompts"]
+    assert np.abs(got - want).max() <= 0.03 * scale * np.abs(want).max()
+    # pred_boxes, tie-aware: the reference score at our argmax is within the gate of the reference maximum
+    score = ref["fwd.cls_score_test"].reshape(B, -1) * softmax_np(ref["fwd.cont_score"])[:, :, 0]
+    idx = out["argmax"].cpu().numpy().reshape(-1)
+    assert (score.max(-1) - score[np.arange(B), idx]).max() <= 1e-2 * scale
+    assert np.abs(out["pred_boxes"].cpu().numpy()[:, 0] - ref["fwd.bbox_map"][np.arange(B), idx]).max() <= 1e-2 * scale
+
+
 def test_decode_matches_oracle():
     """On-device tracker decode against the numpy restatement of tracker:116-125 on the same forward outputs."""
     from oracle import uvl_oracle as O

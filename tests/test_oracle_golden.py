@@ -20,7 +20,7 @@ def _check(name):
         if k == "flag":
             assert (out["flag"] == v).all()
             continue
-        if k == "prompt_init":          # covered by test_oracle_prompter_matches_reference
+        if k == "prompt_init" or k.startswith("fwd."):     # covered by the prompter / UVLTrack.forward tests below
             continue
         if k.endswith(".slice"):
             got = out[k[:-6]][:, :8, :32]
@@ -56,6 +56,19 @@ def test_oracle_prompter_matches_reference(name):
         if fl == 1:
             other = O.forward_prompt_init(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], ~tem_mask, ~ctx_mask, inp["flag"])
             np.testing.assert_array_equal(other[b], got[b])
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_forward_matches_reference(name):
+    """UVLTrack.forward in eval mode (the grounding call; head on its no-prompt branch, cont_score with two channels)."""
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    sd = rebuild_weights(meta, spec, include_unused=True)
+    tem_mask, ctx_mask = O.box_masks(spec, meta["batch"], seed=meta["input_seed"])
+    out = O.forward(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], tem_mask, ctx_mask, inp["flag"])
+    assert out["cont_score"].shape == (meta["batch"], spec.nx, 2)
+    for k in ("cont_score", "bbox_map", "pred_boxes", "cls_score", "cls_score_test", "prompts"):
+        np.testing.assert_allclose(out[k], ref["fwd." + k], atol=ATOL, rtol=0, err_msg="%s/fwd.%s" % (name, k))
 
 
 def test_oracle_clip_box_matches_reference_when_available():

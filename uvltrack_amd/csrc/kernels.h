@@ -87,6 +87,8 @@ struct HeadPrepParams {
     const float* prompt = nullptr; const float* logit_scale = nullptr;
     const uint8_t* text_mask = nullptr; const int64_t* flag = nullptr;
     int softmax_one = 1, mean_mode = 0, cls_tokenize = 0, skip_text = 0;
+    int cont_only = 0;                           // 1: only cont_score, search rows read from o_search (compact [B,S,D]); x is not touched
+    int train_cont = 0;                          // 1: cont_score layout of the head's no-prompt branch, [B,S,2] (head:134-138)
     bf16_t* g0 = nullptr; int g0_ld = 0;
     float *o_search = nullptr, *o_template = nullptr, *o_text = nullptr, *o_vis = nullptr, *o_txt = nullptr, *o_cont = nullptr;
 };
@@ -110,6 +112,8 @@ struct PrompterParams {
     const int64_t* flag = nullptr;
     const float *query_embed = nullptr, *logit_scale = nullptr;
     int B = 0, nz = 0, S = 0, D = 0;
+    int ctx_roll = 0;                                                               // sample b reads the context tokens of sample (b + ctx_roll) % B
+                                                                                    // (head:132, the batch-rolled context of the no-prompt branch)
     float *src = nullptr, *src0 = nullptr;                                          // [B,3,D] f32: tokens + src_, and src_
     bf16_t* src_bf16 = nullptr;                                                     // [3B, D] MLP operand
 };

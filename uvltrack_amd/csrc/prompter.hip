@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void prompter_tokens_kernel(const PrompterPara
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fl = (int)p.flag[b];
     const float* tem = p.tem + (size_t)b * p.nz * D;
-    const float* ctx = p.ctx + (size_t)b * p.S * D;
+    const float* ctx = p.ctx + (size_t)((b + p.ctx_roll) % p.B) * p.S * D;
 
     // token = [vis, txt, (vis+txt)/2][flag]  (head:97-101)
     float tn = 0.f;

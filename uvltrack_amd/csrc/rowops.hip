@@ -386,11 +386,56 @@ hipError_t launch_contrast(const ContrastParams& p, hipStream_t s) {
 //     optionally a second copy scaled by the flag-selected token (CLS_TOKENIZE, head:64-69,74)
 //   * search rows: cont_score = tau * normalize(x) . normalize(prompt_k) with the SOFTMAX_ONE fold (head:140-148)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void write_cont(const HeadPrepParams& p, int b, int s, float c0, float c1, float c2) {
+    if (p.train_cont) {                          // no-prompt branch (head:134-138): two channels
+        float* o = p.o_cont + ((size_t)b * p.nx + s) * 2;
+        o[0] = c0;
+        o[1] = p.softmax_one ? fmaxf(fmaxf(c1, c2), 0.f) : fmaxf(c1, c2);
+    } else if (p.softmax_one) {                  // test branch (head:140-148)
+        float* o = p.o_cont + ((size_t)b * p.nx + s) * 3;
+        o[0] = c0;
+        o[1] = fmaxf(fmaxf(c1, c2), 0.f);
+        o[2] = 0.f;
+    } else {
+        float* o = p.o_cont + ((size_t)b * p.nx + s) * 2;
+        o[0] = c0;
+        o[1] = fmaxf(c1, c2);
+    }
+}
+
 __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) {
     extern __shared__ float sh[];              // [D] txt token, [D] cls-tokenize token
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = p.D;
+    if (p.cont_only) {                         // cont_score of the search rows against a prompt that was computed after the first pass
+        const int s = blockIdx.x * 4 + wave;
+        if (s >= p.nx) return;
+        const float* xr = p.o_search + ((size_t)b * p.nx + s) * D;
+        const float* pr = p.prompt + (size_t)b * 3 * D;
+        float xx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + c);
+            const float4 p0 = *reinterpret_cast<const float4*>(pr + c);
+            const float4 p1 = *reinterpret_cast<const float4*>(pr + D + c);
+            const float4 p2 = *reinterpret_cast<const float4*>(pr + 2 * D + c);
+            xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            d0 += a.x * p0.x + a.y * p0.y + a.z * p0.z + a.w * p0.w;
+            d1 += a.x * p1.x + a.y * p1.y + a.z * p1.z + a.w * p1.w;
+            d2 += a.x * p2.x + a.y * p2.y + a.z * p2.z + a.w * p2.w;
+            n0 += p0.x * p0.x + p0.y * p0.y + p0.z * p0.z + p0.w * p0.w;
+            n1 += p1.x * p1.x + p1.y * p1.y + p1.z * p1.z + p1.w * p1.w;
+            n2 += p2.x * p2.x + p2.y * p2.y + p2.z * p2.z + p2.w * p2.w;
+        }
+        xx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
+        n0 = fmaxf(sqrtf(wave_sum(n0)), 1e-12f);
+        n1 = fmaxf(sqrtf(wave_sum(n1)), 1e-12f);
+        n2 = fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+        const float tau = __expf(p.logit_scale[0]);
+        const float c0 = tau * wave_sum(d0) / (xx * n0), c1 = tau * wave_sum(d1) / (xx * n1), c2 = tau * wave_sum(d2) / (xx * n2);
+        if (lane == 0) write_cont(p, b, s, c0, c1, c2);
+        return;
+    }
     const float* xb = p.x + (size_t)b * p.nj * D;
     const int fl = (int)p.flag[b];
     float* txt_tok = sh;
@@ -421,7 +466,8 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) 
     const bool is_search = r >= 1 + p.nz && r < p.nv;
     const int s = r - 1 - p.nz;
     float xx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    const float* pr = p.prompt + (size_t)b * 3 * D;
+    const bool with_cont = p.prompt != nullptr && p.o_cont != nullptr;
+    const float* pr = with_cont ? p.prompt + (size_t)b * 3 * D : nullptr;
     for (int c = lane * 4; c < D; c += 256) {
         const float4 a = *reinterpret_cast<const float4*>(xr + c);
         if (dst) *reinterpret_cast<float4*>(dst + c) = a;
@@ -437,6 +483,7 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) 
                 w.y = pack_bf16x2(a.z * t.z, a.w * t.w);
                 *reinterpret_cast<uint2*>(g + D + c) = w;
             }
+            if (!with_cont) continue;
             const float4 p0 = *reinterpret_cast<const float4*>(pr + c);
             const float4 p1 = *reinterpret_cast<const float4*>(pr + D + c);
             const float4 p2 = *reinterpret_cast<const float4*>(pr + 2 * D + c);
@@ -449,7 +496,7 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) 
             n2 += p2.x * p2.x + p2.y * p2.y + p2.z * p2.z + p2.w * p2.w;
         }
     }
-    if (is_search && p.o_cont) {
+    if (is_search && with_cont) {
         xx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
         n0 = fmaxf(sqrtf(wave_sum(n0)), 1e-12f);
         n1 = fmaxf(sqrtf(wave_sum(n1)), 1e-12f);
@@ -458,23 +505,13 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) 
         const float c0 = tau * wave_sum(d0) / (xx * n0);
         const float c1 = tau * wave_sum(d1) / (xx * n1);
         const float c2 = tau * wave_sum(d2) / (xx * n2);
-        if (lane == 0) {
-            if (p.softmax_one) {
-                float* o = p.o_cont + ((size_t)b * p.nx + s) * 3;
-                o[0] = c0;
-                o[1] = fmaxf(fmaxf(c1, c2), 0.f);
-                o[2] = 0.f;
-            } else {
-                float* o = p.o_cont + ((size_t)b * p.nx + s) * 2;
-                o[0] = c0;
-                o[1] = fmaxf(c1, c2);
-            }
-        }
+        if (lane == 0) write_cont(p, b, s, c0, c1, c2);
     }
 }
 
 hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s) {
-    const int rows = p.skip_text ? p.nv : p.nj;
+    const int rows = p.cont_only ? p.nx : (p.skip_text ? p.nv : p.nj);
+    if (p.cont_only && (!p.o_search || !p.prompt || !p.o_cont)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(head_prep_kernel, dim3((rows + 3) / 4, p.B), dim3(256), 2 * p.D * sizeof(float), s, p);
     return hipGetLastError();
 }

@@ -471,8 +471,37 @@ static hipError_t tramp(void* ctx, hipStream_t s) { return F(*(const P_*)ctx, s)
 #define RUN_GEMM(L, s, p, what) (L).run((s), (what), 2.0 * (p).M * (p).N * (p).K * ((p).groups > 0 ? (p).groups : 1), \
     2.0 * ((double)(p).M * (p).K + (double)(p).N * (p).K * ((p).groups > 0 ? (p).groups : 1)), tramp<GemmParams, launch_gemm>, &(p))
 
+// The prompter on tokens that already sit in compact f32 buffers (heads/utils.py:82-99).  Scratch: src / src_ at the start of
+// X, the bf16 MLP operand in Xn, the MLP hidden in Hb -- all idle once the head input has been gathered.
+static int run_prompter(uvl_model* m, const Workspace& w, int B, const float* tem, const float* ctx, const float* vis, const float* txt,
+                        const int64_t* flag, const uint8_t* tem_mask, const uint8_t* ctx_mask, int ctx_roll, float* prompt_out, hipStream_t s) {
+    const int D = m->D, Fn = m->ffn;
+    float* src = w.X;
+    float* src0 = w.X + (size_t)B * 3 * D;
+    PrompterParams p;
+    p.tem = tem; p.ctx = ctx; p.vis = vis; p.txt = txt;
+    p.tem_mask = tem_mask; p.ctx_mask = ctx_mask; p.flag = flag; p.ctx_roll = ctx_roll;
+    p.query_embed = m->pr_query; p.logit_scale = m->pr_logit_scale; p.B = B; p.nz = m->nz; p.S = m->S; p.D = D;
+    p.src = src; p.src0 = src0; p.src_bf16 = w.Xn;
+    HIPCHK(launch_prompter_tokens(p, s));
+    {   // src = mlp(src) + src  (utils.py:94)
+        GemmParams g;
+        g.A = w.Xn; g.lda = D; g.W = m->pr_w1; g.ldw = D; g.bias = m->pr_b1; g.M = 3 * B; g.N = Fn; g.K = D; g.epi = 0; g.C = w.Hb; g.ldc = Fn; g.act = 1;
+        HIPCHK(launch_gemm(g, s));
+        GemmParams h;
+        h.A = w.Hb; h.lda = Fn; h.W = m->pr_w2; h.ldw = Fn; h.bias = m->pr_b2; h.M = 3 * B; h.N = D; h.K = Fn; h.epi = 1; h.C = src; h.ldc = D; h.accumulate = 1;
+        HIPCHK(launch_gemm(h, s));
+    }
+    HIPCHK(launch_prompter_select(src, src0, flag, prompt_out, B, 3 * D, s));
+    return UVL_OK;
+}
+
+// UVLTrack.forward (uvltrack.py:18-24): the head runs its no-prompt branch (head:123-138) -- prompter inline on a context
+// rolled by half a batch, two-channel cont_score.
+struct TrainBranch { const uint8_t* template_mask; const uint8_t* context_mask; float* prompts_out; };
+
 static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, hipStream_t s, Profiler* prof,
-                       int parts = PART_ALL) {
+                       int parts = PART_ALL, const TrainBranch* tb = nullptr) {
     if (!m || !in || !out) return fail(UVL_EINVAL, "null argument");
     if (!m->finalized) return fail(UVL_ESTATE, "uvl_finalize_weights has not been called");
     const int B = in->batch;
@@ -694,7 +723,16 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         p.g0 = w.G0; p.g0_ld = g0_ld;
         p.o_search = out->d_search; p.o_template = out->d_template; p.o_text = out->d_text; p.o_vis = out->d_vis_token; p.o_txt = out->d_txt_token;
         p.o_cont = cont;
+        if (tb) { p.prompt = nullptr; p.o_cont = nullptr; }      // first pass: token outputs + head input only
         L.run(s, "head_prep", 0, 0, tramp<HeadPrepParams, launch_head_prep>, &p);
+        if (tb && !L.err) {
+            const int rc = run_prompter(m, w, B, out->d_template, out->d_search, out->d_vis_token, out->d_txt_token, in->d_flag,
+                                        tb->template_mask, tb->context_mask, B / 2, tb->prompts_out, s);
+            if (rc) return rc;
+            HeadPrepParams c = p;
+            c.cont_only = 1; c.train_cont = 1; c.prompt = tb->prompts_out; c.o_cont = cont;
+            L.run(s, "head_prep", 0, 0, tramp<HeadPrepParams, launch_head_prep>, &c);
+        }
     }
     const bf16_t* cin[4] = {w.G0, w.G1, w.G2, w.G3};
     bf16_t* cout[4] = {w.G1, w.G2, w.G3, w.G4};
@@ -726,7 +764,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     }
     {
         HeadTailParams p;
-        p.g4 = w.G4; p.ld = C / 2; p.c8 = C / 8; p.w1 = m->w1; p.b1 = m->b1; p.cont = cont; p.cont_ch = m->cfg.softmax_one ? 3 : 2;
+        p.g4 = w.G4; p.ld = C / 2; p.c8 = C / 8; p.w1 = m->w1; p.b1 = m->b1; p.cont = cont; p.cont_ch = (m->cfg.softmax_one && !tb) ? 3 : 2;
         p.flag = in->d_flag; p.coord = m->coord; p.B = B; p.S = S; p.F = m->F; p.offset_sigmoid = m->cfg.offset_sigmoid; p.joint_cls = m->cfg.joint_cls;
         p.o_cls = out->d_cls_score; p.o_cls_test = out->d_cls_score_test; p.o_bbox_map = bbox; p.o_pred = out->d_pred_boxes; p.o_argmax = out->d_argmax;
         L.run(s, "head_tail", 0, 0, tramp<HeadTailParams, launch_head_tail>, &p);
@@ -860,27 +898,21 @@ extern "C" int uvl_forward_prompt(uvl_model_t* m, int batch, const float* d_temp
     if (B <= 0 || B > m->cfg.max_batch) return fail(UVL_EINVAL, "batch %d outside [1, %d]", B, m->cfg.max_batch);
     const Workspace w = carve(m, B, (char*)d_ws);
     if (!d_ws || ws_bytes < w.total || (uintptr_t)d_ws % 256) return fail(UVL_EINVAL, "bad workspace");
-    hipStream_t s = (hipStream_t)stream;
-    const int D = m->D, Fn = m->ffn;
-    // scratch inside the (idle between frames) frame workspace: src / src_ in X, bf16 operand in Xn, MLP hidden in Hb
-    float* src = w.X;
-    float* src0 = w.X + (size_t)B * 3 * D;
-    PrompterParams p;
-    p.tem = d_template_tokens; p.ctx = d_search_tokens; p.vis = d_vis_token; p.txt = d_txt_token;
-    p.tem_mask = d_template_mask; p.ctx_mask = d_context_mask; p.flag = d_flag;
-    p.query_embed = m->pr_query; p.logit_scale = m->pr_logit_scale; p.B = B; p.nz = m->nz; p.S = m->S; p.D = D;
-    p.src = src; p.src0 = src0; p.src_bf16 = w.Xn;
-    HIPCHK(launch_prompter_tokens(p, s));
-    {   // src = mlp(src) + src  (utils.py:94)
-        GemmParams g;
-        g.A = w.Xn; g.lda = D; g.W = m->pr_w1; g.ldw = D; g.bias = m->pr_b1; g.M = 3 * B; g.N = Fn; g.K = D; g.epi = 0; g.C = w.Hb; g.ldc = Fn; g.act = 1;
-        HIPCHK(launch_gemm(g, s));
-        GemmParams h;
-        h.A = w.Hb; h.lda = Fn; h.W = m->pr_w2; h.ldw = Fn; h.bias = m->pr_b2; h.M = 3 * B; h.N = D; h.K = Fn; h.epi = 1; h.C = src; h.ldc = D; h.accumulate = 1;
-        HIPCHK(launch_gemm(h, s));
-    }
-    HIPCHK(launch_prompter_select(src, src0, d_flag, d_prompt_out, B, 3 * D, s));
-    return UVL_OK;
+    return run_prompter(m, w, B, d_template_tokens, d_search_tokens, d_vis_token, d_txt_token, d_flag, d_template_mask, d_context_mask, 0,
+                        d_prompt_out, (hipStream_t)stream);
+}
+
+// ---- UVLTrack.forward (uvltrack.py:18-24), eval mode: what the tracker's grounding() calls (tracker:45-62) -------------------------
+extern "C" int uvl_forward(uvl_model_t* m, const uvl_inputs* in, const uint8_t* d_template_mask, const uint8_t* d_context_mask,
+                           const uvl_outputs* out, float* d_prompts_out, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!m || !in || !out || !d_template_mask || !d_context_mask || !d_prompts_out) return fail(UVL_EINVAL, "uvl_forward: null argument");
+    if (!m->finalized) return fail(UVL_ESTATE, "uvl_finalize_weights has not been called");
+    if (!m->has_prompter) return fail(UVL_ESTATE, "prompter weights (box_head.prompter.{logit_scale,query_embed,mlp.*}) were not loaded");
+    if (!out->d_search || !out->d_template || !out->d_vis_token || !out->d_txt_token)
+        return fail(UVL_EINVAL, "uvl_forward: outputs search / template / vis_token / txt_token are required (the inline prompter reads them)");
+    if (in->skip_text) return fail(UVL_EINVAL, "uvl_forward: skip_text is a forward_test option");
+    TrainBranch tb{d_template_mask, d_context_mask, d_prompts_out};
+    return run_forward(m, in, out, d_ws, ws_bytes, (hipStream_t)stream, nullptr, PART_ALL, &tb);
 }
 
 // ---- tracker decode (lib/test/tracker/uvltrack.py:116-125) ------------------------------------------------------

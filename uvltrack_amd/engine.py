@@ -204,6 +204,41 @@ class HipEngine:
             return outs
         return step
 
+    def forward_full(self, template, search, ids, mask, template_mask, context_mask, flag):
+        """UVLTrack.forward (uvltrack.py:18-24) in eval mode: the head's no-prompt branch (head:123-138) with the prompter inline.
+        Returns the output dict; `cont_score` is [B,S,2] and `prompts` the computed prompt [B,3,D]."""
+        if not self.weights_loaded:
+            raise _native.NativeLibraryError("weights have not been loaded")
+        s = self.spec
+        B = search.shape[0]
+        dummy = torch.zeros(B, 3, s.dim, dtype=torch.float32, device=self.device)
+        template, search, ids, mask, dummy, flag = self._canon_inputs(template, search, ids, mask, dummy, flag)
+        if ids is None:
+            raise ValueError("UVLTrack.forward needs the text input")
+        for t, w in ((template_mask, "template_mask"), (context_mask, "context_mask")):
+            _require_cuda(t, w)
+        tm = (template_mask.reshape(B, -1) != 0).to(torch.uint8).contiguous()
+        cm = (context_mask.reshape(B, -1) != 0).to(torch.uint8).contiguous()
+        if tm.shape[1] != s.nz or cm.shape[1] != s.nx:
+            raise ValueError("forward: mask shapes do not match the model geometry")
+        if B > self.max_batch:
+            raise ValueError("batch %d exceeds max_batch %d" % (B, self.max_batch))
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B)
+            outs = self.alloc_outputs(B)
+            outs["cont_score"] = torch.empty(B, s.nx, 2, dtype=torch.float32, device=self.device)
+            prompts = torch.empty(B, 3, s.dim, dtype=torch.float32, device=self.device)
+            i, o = self._pack_io(template, search, ids, mask, dummy, flag, outs, False)
+            n = self.lib.uvl_workspace_bytes(self.handle, B)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            _native.check(self.lib.uvl_forward(self.handle, C.byref(i), p(tm), p(cm), C.byref(o), p(prompts), C.c_void_p(self._ws_ptr(ws)), n,
+                                               self._stream()), "uvl_forward")
+        outs["flag"] = flag
+        outs["prompts"] = prompts
+        outs["template_mask"], outs["context_mask"] = template_mask, context_mask
+        self._keep = (template, search, ids, mask, tm, cm, dummy)
+        return outs
+
     def forward_prompt(self, out_dict, template_mask, context_mask) -> torch.Tensor:
         """UVLTrack.forward_prompt (uvltrack.py:33-38) on a forward_test output dict; returns prompt [B,3,D]."""
         need = ("template", "search", "vis_token", "txt_token", "flag")

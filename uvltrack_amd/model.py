@@ -134,8 +134,19 @@ class UVLTrack(nn.Module):
         out.pop("argmax", None)
         return out
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("only the per-frame path forward_test is implemented (training forward is out of scope)")
+    def forward(self, template, search, text, template_mask, context_mask, flag):
+        """Reference uvltrack.py:18-24 in eval mode -- the tracker's grounding call (lib/test/tracker/uvltrack.py:57).  The
+        head takes its no-prompt branch: `cont_score` is [B,S,2], `prompts` the inline prompter's output.  Training
+        (autograd, BatchNorm batch statistics, DropPath) is out of scope: eval semantics only."""
+        if not search.is_cuda:
+            raise NativeLibraryError("forward needs tensors on a HIP device (got %s); there is no CPU fallback" % search.device)
+        eng = self._get_engine(search.device)
+        ids, mask = text.tensors, text.mask
+        if mask is None:
+            mask = torch.ones_like(ids)
+        out = eng.forward_full(template, search, ids, mask, template_mask, context_mask, flag)
+        out.pop("argmax", None)
+        return out
 
     def forward_prompt(self, out_dict, template_mask, context_mask):
         """Reference uvltrack.py:33-38: new (target, distractor, background) prompt from a forward_test output dict."""
