@@ -168,6 +168,12 @@ int uvl_sample_target(const uint8_t* d_image, int height, int width, int row_str
 int uvl_sample_target_window(const uint8_t* d_window, int win_x0, int win_y0, int win_width, int win_height, int row_stride_bytes,
                              int frame_height, int frame_width, const float box_xywh[4], float search_area_factor, int output_sz,
                              uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, uvl_crop_geometry* geometry_out, void* stream);
+/* grounding_resize (lib/train/data/processing_utils.py:60-141; tracker:48): the whole frame resized with its aspect ratio
+ * kept (long side = output_sz, OpenCV INTER_LINEAR -- see oracle/preprocess_oracle.py::grounding_resize on the reference's
+ * swallowed `interpolation` argument), centred on a zero canvas; d_att_mask = 1 on the padding.
+ * image_top_coords (host, optional) = [x1_pad, y1_pad, new_w, new_h]. */
+int uvl_grounding_resize(const uint8_t* d_image, int height, int width, int row_stride_bytes, int output_sz,
+                         uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, int32_t image_top_coords[4], void* stream);
 /* Preprocessor_wo_mask.process alone, on an already cropped uint8 HWC patch. */
 int uvl_normalize_u8(const uint8_t* d_patch_hwc, int height, int width, float* d_norm_chw, void* stream);
 

@@ -5,6 +5,7 @@ Restates
   * `sample_target`            reference lib/train/data/processing_utils.py:159-243  (square crop around the box,
                                constant zero padding, resize to output_sz, attention mask of the padded area)
   * `Preprocessor_wo_mask`     reference lib/test/tracker/tracker_utils.py:20-29      ((x/255 - mean) / std, NCHW)
+  * `grounding_resize`         reference lib/train/data/processing_utils.py:60-141    (whole frame, aspect kept, centred zero pad)
 
 PARITY UNPINNED for the resize: the reference calls `cv2.resize` / `cv2.copyMakeBorder` (opencv-python 4.5.5.64,
 uvltrack_env.yaml:266), and OpenCV is neither vendored in /root/reference nor installed in this image, so the module
@@ -143,6 +144,47 @@ def sample_target(im: np.ndarray, target_bb, search_area_factor: float, output_s
     patch = resize_linear_u8(padded, output_sz, output_sz)
     att_r = resize_linear_mask(att, output_sz, output_sz)
     return patch, resize_factor, att_r, bbox
+
+
+def grounding_geometry(height: int, width: int, output_sz: int):
+    """processing_utils.py:77-104: resized size (aspect kept, long side = output_sz) and the centred padding."""
+    crop_sz = math.ceil(1 * output_sz)
+    if width > height:
+        ow, oh = crop_sz, int(crop_sz * height / width)
+    else:
+        oh, ow = crop_sz, int(crop_sz * width / height)
+    y1_pad = int((output_sz - oh) / 2)
+    y2_pad = int((output_sz - oh) / 2)
+    x1_pad = int((output_sz - ow) / 2)
+    x2_pad = int((output_sz - ow) / 2)
+    if (y1_pad + y2_pad + oh) != output_sz:
+        y1_pad += 1
+    if (x1_pad + x2_pad + ow) != output_sz:
+        x1_pad += 1
+    return dict(new_w=ow, new_h=oh, x1_pad=x1_pad, x2_pad=x2_pad, y1_pad=y1_pad, y2_pad=y2_pad)
+
+
+def grounding_resize(im: np.ndarray, output_sz: int, bbox):
+    """processing_utils.py:60-141 with mask=None: whole frame resized with the aspect ratio kept, zero-padded to a square.
+    NB the reference writes `cv2.resize(im, (ow, oh), interpolation)` with interpolation = PIL's BILINEAR (= 2): the third
+    POSITIONAL parameter of cv2.resize is `dst`, so the value is swallowed and OpenCV's default INTER_LINEAR runs -- restated so.
+    Returns (padded uint8 [out,out,3], box [4] normalised, att_mask [out,out] float 0/1, image_top_coords [x1_pad,y1_pad,new_w,new_h])."""
+    h, w = im.shape[:2]
+    g = grounding_geometry(h, w, output_sz)
+    img = resize_linear_u8(im, g["new_w"], g["new_h"])
+    padded = np.zeros((output_sz, output_sz, 3), dtype=np.uint8)
+    padded[g["y1_pad"]:g["y1_pad"] + g["new_h"], g["x1_pad"]:g["x1_pad"] + g["new_w"]] = img
+    box = np.array(bbox, dtype=np.float64).copy()
+    box[0] = bbox[0] * g["new_w"] / w
+    box[1] = bbox[1] * g["new_h"] / h
+    box[2] = bbox[2] * g["new_w"] / w
+    box[3] = bbox[3] * g["new_h"] / h
+    box[0] += g["x1_pad"]
+    box[1] += g["y1_pad"]
+    box /= output_sz
+    att = np.ones((output_sz, output_sz))
+    att[g["y1_pad"]:output_sz - g["y2_pad"], g["x1_pad"]:output_sz - g["x2_pad"]] = 0
+    return padded, box, att, [g["x1_pad"], g["y1_pad"], g["new_w"], g["new_h"]]
 
 
 def normalize(img_u8: np.ndarray) -> np.ndarray:

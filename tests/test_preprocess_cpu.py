@@ -112,3 +112,16 @@ def test_library_host_geometry_matches_oracle():
         assert (cg.crop_sz, cg.x1, cg.y1, cg.x1_pad, cg.x2_pad, cg.y1_pad, cg.y2_pad) == \
                (g["crop_sz"], g["x1"], g["y1"], g["x1_pad"], g["x2_pad"], g["y1_pad"], g["y2_pad"])
         assert abs(cg.resize_factor - out / g["crop_sz"]) < 1e-6
+
+
+def test_grounding_geometry_and_resize():
+    for (h, w, out) in [(480, 640, 256), (720, 1280, 256), (1080, 1920, 384), (640, 480, 256), (300, 300, 256), (512, 512, 256), (333, 1001, 320)]:
+        g = P.grounding_geometry(h, w, out)
+        assert g["x1_pad"] + g["x2_pad"] + g["new_w"] == out and g["y1_pad"] + g["y2_pad"] + g["new_h"] == out
+        assert max(g["new_w"], g["new_h"]) == out
+    img = _rand_img(480, 640, seed=9)
+    padded, box, att, top = P.grounding_resize(img, 256, [100.0, 50.0, 200.0, 120.0])
+    assert padded.shape == (256, 256, 3) and top == [0, 32, 256, 192]
+    assert np.all(padded[:32] == 0) and np.all(padded[224:] == 0) and np.all(att[:32] == 1) and np.all(att[32:224] == 0)
+    assert np.array_equal(padded[32:224], P.resize_linear_u8(img, 256, 192))
+    assert np.allclose(box, [100 * 256 / 640 / 256, (50 * 192 / 480 + 32) / 256, 200 * 256 / 640 / 256, 120 * 192 / 480 / 256])

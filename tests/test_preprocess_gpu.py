@@ -77,6 +77,22 @@ def test_reference_call_signatures():
         sample_target(img, box, 4.0)                       # output_sz=None is not a tracker call
 
 
+@pytest.mark.parametrize("hw_out", [(480, 640, 256), (720, 1280, 256), (1080, 1920, 384), (640, 480, 256), (512, 512, 256), (333, 1001, 320), (256, 256, 256)])
+def test_grounding_resize_matches_oracle(hw_out):
+    from lib.train.data.processing_utils import grounding_resize
+    H, W, out = hw_out
+    img = _rand_img(H, W, seed=H * 3 + W)
+    bbox = [0.1 * W, 0.2 * H, 0.3 * W, 0.25 * H]
+    padded, box, att, top = P.grounding_resize(img, out, bbox)
+    got = grounding_resize(img, out, torch.tensor(bbox), None, want_norm=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(got[0].cpu().numpy(), padded)
+    assert np.allclose(got[1].numpy(), box, atol=1e-6)
+    assert np.array_equal(got[2].cpu().numpy(), att)
+    assert got[4] == top and tuple(got[3].shape) == (out, out)
+    assert np.abs(got[5].cpu().numpy() - P.normalize(padded)).max() <= 1e-6
+
+
 def test_rejects_bad_input():
     from uvltrack_amd.preprocess import sample_target_fused
     from uvltrack_amd._native import NativeLibraryError

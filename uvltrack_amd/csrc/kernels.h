@@ -140,6 +140,12 @@ struct PreprocParams {
     uint8_t* att = nullptr;                                               // [out,out] 0/1 attention mask of the padded area, optional
 };
 hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);
+struct GroundingParams {                                                  // grounding_resize, processing_utils.py:60-141
+    const uint8_t* img = nullptr; int H = 0, W = 0, stride = 0;
+    int new_w = 0, new_h = 0, x1_pad = 0, y1_pad = 0, out = 0;
+    uint8_t* patch = nullptr; float* norm = nullptr; uint8_t* att = nullptr;
+};
+hipError_t launch_grounding_resize(const GroundingParams& p, hipStream_t s);
 hipError_t launch_normalize_u8(const uint8_t* src, float* dst, int n_pix, hipStream_t s);
 
 // out = relu(sum of split-K slabs) as bf16 (conv towers)

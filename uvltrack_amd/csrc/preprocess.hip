@@ -92,6 +92,55 @@ hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// grounding_resize (processing_utils.py:60-141): the whole frame resized to new_w x new_h (aspect kept, OpenCV 8-bit
+// INTER_LINEAR, separate x / y scales), centred in an out x out canvas of zeros; attention mask = 1 on the padding.
+__global__ __launch_bounds__(256) void grounding_resize_kernel(const GroundingParams p) {
+    const int dx = blockIdx.x * 16 + (threadIdx.x & 15), dy = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (dx >= p.out || dy >= p.out) return;
+    const int rx = dx - p.x1_pad, ry = dy - p.y1_pad;
+    const bool inside = rx >= 0 && rx < p.new_w && ry >= 0 && ry < p.new_h;
+    int o[3] = {0, 0, 0};
+    if (inside) {
+        auto px3 = [&](int y, int x, int* v) __attribute__((always_inline)) {
+            const uint8_t* s = p.img + (size_t)y * p.stride + (size_t)x * 3;
+            v[0] = s[0]; v[1] = s[1]; v[2] = s[2];
+        };
+        if (p.W == p.new_w && p.H == p.new_h) {
+            px3(ry, rx, o);
+        } else if (p.W == 2 * p.new_w && p.H == 2 * p.new_h) {
+            int a[3], b[3], c[3], d[3];
+            px3(2 * ry, 2 * rx, a); px3(2 * ry, 2 * rx + 1, b); px3(2 * ry + 1, 2 * rx, c); px3(2 * ry + 1, 2 * rx + 1, d);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = (a[k] + b[k] + c[k] + d[k] + 2) >> 2;
+        } else {
+            const Tap tx = axis_tap(rx, (double)p.W / (double)p.new_w, p.W, true), ty = axis_tap(ry, (double)p.H / (double)p.new_h, p.H, false);
+            int v00[3], v01[3], v10[3], v11[3];
+            px3(ty.s0, tx.s0, v00); px3(ty.s0, tx.s1, v01); px3(ty.s1, tx.s0, v10); px3(ty.s1, tx.s1, v11);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int h0 = v00[k] * tx.w0 + v01[k] * tx.w1, h1 = v10[k] * tx.w0 + v11[k] * tx.w1;
+                const int r = (((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                o[k] = min(max(r, 0), 255);
+            }
+        }
+    }
+    const size_t at = (size_t)dy * p.out + dx;
+    if (p.patch) { p.patch[at * 3] = (uint8_t)o[0]; p.patch[at * 3 + 1] = (uint8_t)o[1]; p.patch[at * 3 + 2] = (uint8_t)o[2]; }
+    if (p.att) p.att[at] = inside ? 0 : 1;
+    if (p.norm) {
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        const size_t plane = (size_t)p.out * p.out;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.norm[k * plane + at] = (((float)o[k] / 255.0f) - mean[k]) / stdv[k];
+    }
+}
+
+hipError_t launch_grounding_resize(const GroundingParams& p, hipStream_t s) {
+    if (p.out <= 0 || p.new_w <= 0 || p.new_h <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(grounding_resize_kernel, dim3((p.out + 15) / 16, (p.out + 15) / 16), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // Preprocessor_wo_mask.process on an already resized patch: uint8 HWC -> float32 CHW, ((x/255) - mean) / std
 __global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n_pix) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -987,6 +987,26 @@ extern "C" int uvl_sample_target_window(const uint8_t* d_window, int win_x0, int
                               search_area_factor, output_sz, d_patch_hwc, d_norm_chw, d_att_mask, geometry_out, stream);
 }
 
+// grounding_resize (processing_utils.py:77-104 for the integer geometry; Python int() truncates towards zero)
+extern "C" int uvl_grounding_resize(const uint8_t* d_image, int height, int width, int row_stride_bytes, int output_sz,
+                                    uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, int32_t image_top_coords[4], void* stream) {
+    if (!d_image || height <= 0 || width <= 0 || output_sz <= 0 || row_stride_bytes < 3 * width) return fail(UVL_EINVAL, "uvl_grounding_resize: bad argument");
+    if (!d_patch_hwc && !d_norm_chw && !d_att_mask) return fail(UVL_EINVAL, "uvl_grounding_resize: no output requested");
+    int ow, oh;
+    if (width > height) { ow = output_sz; oh = (int)((double)output_sz * height / width); }
+    else { oh = output_sz; ow = (int)((double)output_sz * width / height); }
+    if (ow <= 0 || oh <= 0) return fail(UVL_EINVAL, "uvl_grounding_resize: degenerate aspect ratio");
+    int y1 = (int)((output_sz - oh) / 2.0), y2 = y1, x1 = (int)((output_sz - ow) / 2.0), x2 = x1;
+    if (y1 + y2 + oh != output_sz) y1 += 1;
+    if (x1 + x2 + ow != output_sz) x1 += 1;
+    GroundingParams p;
+    p.img = d_image; p.H = height; p.W = width; p.stride = row_stride_bytes; p.new_w = ow; p.new_h = oh; p.x1_pad = x1; p.y1_pad = y1;
+    p.out = output_sz; p.patch = d_patch_hwc; p.norm = d_norm_chw; p.att = d_att_mask;
+    HIPCHK(launch_grounding_resize(p, (hipStream_t)stream));
+    if (image_top_coords) { image_top_coords[0] = x1; image_top_coords[1] = y1; image_top_coords[2] = ow; image_top_coords[3] = oh; }
+    return UVL_OK;
+}
+
 extern "C" int uvl_normalize_u8(const uint8_t* d_patch_hwc, int height, int width, float* d_norm_chw, void* stream) {
     if (!d_patch_hwc || !d_norm_chw || height <= 0 || width <= 0) return fail(UVL_EINVAL, "uvl_normalize_u8: bad argument");
     HIPCHK(launch_normalize_u8(d_patch_hwc, d_norm_chw, height * width, (hipStream_t)stream));

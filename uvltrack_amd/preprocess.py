@@ -126,6 +126,37 @@ def sample_target(im, target_bb, search_area_factor, output_sz=None, mask=None, 
     return r["patch"], r["resize_factor"], r["att_mask"]
 
 
+def grounding_resize(im, output_sz, bbox, mask=None, want_norm: bool = False):
+    """Drop-in for processing_utils.grounding_resize (reference lib/train/data/processing_utils.py:60-141; tracker:48): the whole
+    frame, aspect ratio kept, long side = output_sz, centred on zeros.  Returns (im_crop_padded uint8 CUDA [out,out,3], box
+    normalised to [0,1], att_mask float CUDA [out,out] (1 = padding), mask_crop_padded zeros [out,out], image_top_coords).
+    With want_norm=True the normalised image [1,3,out,out] is appended (one launch instead of resize + Preprocessor)."""
+    lib = _native.load()
+    frame = _frame_on_device(im)
+    H, W = int(frame.shape[0]), int(frame.shape[1])
+    out = int(output_sz)
+    dev = frame.device
+    patch = torch.empty((out, out, 3), dtype=torch.uint8, device=dev)
+    att = torch.empty((out, out), dtype=torch.uint8, device=dev)
+    norm = torch.empty((1, 3, out, out), dtype=torch.float32, device=dev) if want_norm else None
+    top = (C.c_int32 * 4)()
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    _native.check(lib.uvl_grounding_resize(ptr(frame), H, W, int(frame.stride(0)), out, ptr(patch), ptr(norm), ptr(att), top, _stream()),
+                  "uvl_grounding_resize")
+    x1_pad, y1_pad, new_w, new_h = [int(v) for v in top]
+    box = torch.as_tensor(bbox, dtype=torch.float32).detach().clone().cpu()
+    src = [float(v) for v in box.tolist()]
+    box[0] = src[0] * new_w / W
+    box[1] = src[1] * new_h / H
+    box[2] = src[2] * new_w / W
+    box[3] = src[3] * new_h / H
+    box[0] += x1_pad
+    box[1] += y1_pad
+    box /= out
+    res = (patch, box, att.to(torch.float64), torch.zeros(out, out), [x1_pad, y1_pad, new_w, new_h])
+    return res + (norm,) if want_norm else res
+
+
 class Preprocessor_wo_mask(object):
     """tracker_utils.py:20-29: uint8 HxWx3 patch -> normalised float [1,3,H,W] on the GPU."""
 
