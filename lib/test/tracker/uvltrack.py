@@ -1,0 +1,189 @@
+"""The UVLTrack tracker (reference lib/test/tracker/uvltrack.py:20-233) on the device ops of this repository: the caller on
+either side of the per-frame path.  Same public behaviour -- `UVLTrack(params, dataset_name)`, `initialize(image, info)`,
+`track(image, info)` -> {"target_bbox": [x, y, w, h]}, modes NL / NLBBOX / BBOX (cfg.TEST.MODE), prompt update every
+cfg.TEST.UPDATE_INTERVAL frames -- with every tensor step on the GPU:
+
+    reference (per frame)                                   here
+    cv2 crop + resize on the CPU, fp32 upload               uint8 crop window upload + fused crop/resize/normalise kernel
+    network.forward_test (eager ATen)                       uvl_forward_test (HIP)
+    three .cpu() copies + numpy argmax / box arithmetic     uvl_decode (one kernel), one 10-float read-back
+    network.forward_prompt / forward_prompt_init / forward  uvl_forward_prompt / uvl_forward (HIP)
+
+`params` carries what `lib/test/parameter/uvltrack.py:19-48` sets (cfg, template/search factor and size, grounding_size,
+checkpoint); `network=` injects an already built model (tests, benchmarks) instead of reading params.checkpoint."""
+import numpy as np
+import torch
+
+from lib.models.uvltrack.uvltrack import build_model
+from lib.test.tracker.basetracker import BaseTracker
+from lib.test.tracker.tracker_utils import Preprocessor_wo_mask
+from lib.train.data.processing_utils import grounding_resize, sample_target
+from lib.utils.box_ops import box_cxcywh_to_xywh, box_xywh_to_xyxy
+from lib.utils.misc import NestedTensor
+from uvltrack_amd.checkpoint import load_checkpoint
+from uvltrack_amd.preprocess import WindowUploader, sample_target_fused
+from uvltrack_amd.tokenizer import BertTokenizer, extract_token_from_nlp
+
+
+class UVLTrack(BaseTracker):
+    def __init__(self, params, dataset_name=None, network=None, tokenizer=None, device="cuda:0"):
+        super(UVLTrack, self).__init__(params)
+        self.device = torch.device(device)
+        if network is None:
+            network = build_model(params.cfg)
+            load_checkpoint(network, self.params.checkpoint, strict=False)          # tracker:24
+        self.cfg = params.cfg
+        self.network = network.to(self.device)
+        self.network.eval()
+        self.map_size = params.search_size // 16
+        self.preprocessor = Preprocessor_wo_mask()
+        self.state = None
+        self.debug = getattr(self.params, "debug", 0)
+        self.frame_id = 0
+        self.update_interval = self.cfg.TEST.UPDATE_INTERVAL
+        self.feat_size = self.params.search_size // 16
+        self.tokenizer = tokenizer                                                   # built lazily: BBOX mode needs no vocabulary
+        self.threshold = self.params.cfg.TEST.THRESHOLD
+        self.has_cont = self.params.cfg.TRAIN.CONT_WEIGHT > 0
+        self.max_score = 0
+        self.max_query_len = self.cfg.MODEL.BACKBONE.LANGUAGE.BERT.MAX_QUERY_LEN
+        self._uploader = None
+
+    # ------------------------------------------------------------------ helpers
+    def _tok(self):
+        if self.tokenizer is None:
+            self.tokenizer = BertTokenizer.from_pretrained(self.cfg.MODEL.BACKBONE.LANGUAGE.VOCAB_PATH, do_lower_case=True)   # tracker:40
+        return self.tokenizer
+
+    def extract_token_from_nlp(self, nlp, seq_length):
+        """tracker:196-233 -> (ids [1,L], mask [1,L]) on the device."""
+        ids, mask = extract_token_from_nlp(self._tok(), nlp, seq_length)
+        return torch.tensor(ids).unsqueeze(0).to(self.device), torch.tensor(mask).unsqueeze(0).to(self.device)
+
+    def window_prior(self):
+        """tracker:64-68 (only the numpy window is used by track())."""
+        hanning = np.hanning(self.map_size)
+        self.window = np.outer(hanning, hanning).flatten()
+        self._window_dev = torch.from_numpy(self.window.astype(np.float32)).to(self.device)
+
+    def anno2mask(self, gt_bboxes, size):
+        """tracker:183-194: cells whose centre lies inside the box, plus the cell of the box centre."""
+        gt_bboxes = gt_bboxes.detach().float().cpu()
+        bboxes = box_xywh_to_xyxy(gt_bboxes) * size
+        cood = torch.arange(size).unsqueeze(0).repeat(gt_bboxes.shape[0], 1) + 0.5
+        x_mask = ((cood > bboxes[:, 0:1]) & (cood < bboxes[:, 2:3])).unsqueeze(1)
+        y_mask = ((cood > bboxes[:, 1:2]) & (cood < bboxes[:, 3:4])).unsqueeze(2)
+        mask = (x_mask & y_mask)
+        cx = ((bboxes[:, 0] + bboxes[:, 2]) / 2).long()
+        cy = ((bboxes[:, 1] + bboxes[:, 3]) / 2).long()
+        bid = torch.arange(cx.shape[0]).to(cx)
+        mask[bid, cy, cx] = True
+        return mask.flatten(1).to(self.device)
+
+    def map_box_back(self, pred_box: list, resize_factor: float):
+        """tracker:167-173."""
+        cx_prev, cy_prev = self.state[0] + 0.5 * self.state[2], self.state[1] + 0.5 * self.state[3]
+        cx, cy, w, h = pred_box
+        half_side = 0.5 * self.params.search_size / resize_factor
+        return [cx + (cx_prev - half_side) - 0.5 * w, cy + (cy_prev - half_side) - 0.5 * h, w, h]
+
+    def _search_image(self, image, box, factor, size):
+        """Normalised crop [1,3,size,size] + resize factor: crop window upload for host frames, full-frame kernel for device frames."""
+        if isinstance(image, np.ndarray):
+            if self._uploader is None:
+                self._uploader = WindowUploader(max_side=2048, device=self.device)
+            r = self._uploader.sample_target(image, box, factor, size)
+        else:
+            r = sample_target_fused(image, box, factor, size, want_patch=False, want_mask=False)
+        return r["image"], r["resize_factor"]
+
+    # ------------------------------------------------------------------ tracker:45-62
+    def grounding(self, image, info: dict):
+        h, w = image.shape[:2]
+        bbox = torch.tensor([0., 0., 0., 0.])
+        im_crop_padded = grounding_resize(image, self.params.grounding_size, bbox, None)[0]
+        ground = self.preprocessor.process(im_crop_padded)
+        template = torch.zeros([1, 3, self.params.template_size, self.params.template_size], device=self.device)
+        template_mask = torch.zeros([1, (self.params.template_size // 16) ** 2], device=self.device).bool()
+        context_mask = torch.zeros([1, (self.params.search_size // 16) ** 2], device=self.device).bool()
+        text, mask = self.extract_token_from_nlp(info['language'], self.max_query_len)
+        self.text = NestedTensor(text, mask)
+        flag = torch.tensor([[1]], device=self.device)
+        with torch.no_grad():
+            out_dict = self.network.forward(template, ground, self.text, template_mask, context_mask, flag)
+        out_dict['pred_boxes'] = box_cxcywh_to_xywh(out_dict['pred_boxes'] * np.max(image.shape[:2]))[0, 0].cpu().tolist()
+        dx, dy = min(0, (w - h) / 2), min(0, (h - w) / 2)
+        out_dict['pred_boxes'][0] = out_dict['pred_boxes'][0] + dx
+        out_dict['pred_boxes'][1] = out_dict['pred_boxes'][1] + dy
+        return out_dict
+
+    # ------------------------------------------------------------------ tracker:70-108
+    def initialize(self, image, info: dict):
+        L = self.max_query_len
+        if self.cfg.TEST.MODE == 'NL':
+            grounding_state = self.grounding(image, info)
+            init_bbox = grounding_state['pred_boxes']
+            self.flag = torch.tensor([[2]], device=self.device)
+        elif self.cfg.TEST.MODE == 'NLBBOX':
+            text, mask = self.extract_token_from_nlp(info['language'], L)
+            self.text = NestedTensor(text, mask)
+            init_bbox = info['init_bbox']
+            self.flag = torch.tensor([[2]], device=self.device)
+        else:
+            self.text = NestedTensor(torch.zeros([1, L], device=self.device).long(), torch.zeros([1, L], device=self.device))
+            init_bbox = info['init_bbox']
+            self.flag = torch.tensor([[0]], device=self.device)
+        self.window_prior()
+        z_patch_arr, _, _, bbox = sample_target(image, init_bbox, self.params.template_factor, output_sz=self.params.template_size,
+                                                return_bbox=True)
+        self.template_mask = self.anno2mask(bbox.reshape(1, 4), size=self.params.template_size // 16)
+        self.z_patch_arr = z_patch_arr
+        self.template_bbox = (bbox * self.params.template_size)[0, 0].tolist()
+        self.template = self.preprocessor.process(z_patch_arr)
+        # forward the context once
+        y_patch_arr, _, _, y_bbox = sample_target(image, init_bbox, self.params.search_factor, output_sz=self.params.search_size,
+                                                  return_bbox=True)
+        self.y_patch_arr = y_patch_arr
+        self.context_bbox = (y_bbox * self.params.search_size)[0, 0].tolist()
+        context = self.preprocessor.process(y_patch_arr)
+        context_mask = self.anno2mask(y_bbox.reshape(1, 4), self.params.search_size // 16)
+        self.prompt = self.network.forward_prompt_init(self.template, context, self.text, self.template_mask, context_mask, self.flag)
+        self.state = [float(v) for v in init_bbox]
+        self.frame_id = 0
+        self.max_score = 0
+
+    # ------------------------------------------------------------------ tracker:110-140
+    def track(self, image, info: dict = None):
+        H, W, _ = image.shape
+        self.frame_id += 1
+        search, resize_factor = self._search_image(image, self.state, self.params.search_factor, self.params.search_size)
+        with torch.no_grad():
+            out_dict = self.network.forward_test(self.template, search, self.text, self.prompt, self.flag)
+            # argmax of cls * hann * softmax(cont)[0], box back to the frame, clip (tracker:116-125): one kernel, one read-back
+            st = torch.tensor([self.state], dtype=torch.float32)
+            new_state, score, box_net, idx = self.network.decode(out_dict, self._window_dev, st, torch.tensor([resize_factor], dtype=torch.float32),
+                                                                 torch.tensor([[float(H), float(W)]]), margin=10.0, has_cont=self.has_cont)
+            host = torch.cat([new_state.reshape(-1), score.reshape(-1), box_net.reshape(-1)]).cpu()
+        self.state = [float(v) for v in host[:4]]
+        score = float(host[4])
+        pred_box_net = host[5:9].clone()
+        self.last_index = idx
+
+        if score > self.max_score and self.has_cont:
+            self.pred_box_net = pred_box_net
+            self.out_dict = out_dict
+            self.max_score = score
+            self.best_frame = self.frame_id
+
+        if self.frame_id % self.update_interval == 0 and self.has_cont and self.max_score > self.threshold:
+            context_bbox = box_cxcywh_to_xywh(self.pred_box_net.reshape(1, 4))
+            context_mask = self.anno2mask(context_bbox, self.params.search_size // 16)
+            self.context_bbox = (context_bbox[0] * self.params.search_size).detach().cpu().tolist()
+            self.prompt = self.network.forward_prompt(self.out_dict, self.template_mask, context_mask)
+            self.max_score = 0
+
+        return {"target_bbox": self.state}
+
+
+def get_tracker_class():
+    return UVLTrack

@@ -1,0 +1,115 @@
+"""The tracker loop on the device ops (lib/test/tracker/uvltrack.py of this repository) against the CPU restatement
+oracle/tracker_oracle.py, frame by frame with teacher forcing (both sides start every frame from the oracle's state, so the
+crops are bit-identical and only bf16 noise separates the outputs).  Comparisons are tie-aware: the GPU's argmax cell must
+score within 1e-2 of the oracle's maximum, and the emitted box must equal the oracle's decode of THAT cell."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "the", "a", "white", "square", "moving", "right", "on", "dark", "ground", "bright",
+         "##s", "##ing", "object", "left", "small", "big", "in", "of", "and", ".", ","]
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def _video(n=12, H=160, W=200, seed=0):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(20, 90, size=(H // 8 + 1, W // 8 + 1, 3)).astype(np.float32)
+    bg = np.kron(base, np.ones((8, 8, 1), np.float32))[:H, :W]
+    frames, boxes = [], []
+    for t in range(n):
+        x, y = 70 + 4 * t, 60 + 2 * t
+        f = bg + rng.integers(-6, 7, size=bg.shape)
+        f[y:y + 20, x:x + 26] = np.array([230, 225, 210]) + rng.integers(-10, 11, size=(20, 26, 3))
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+        boxes.append([float(x), float(y), 26.0, 20.0])
+    return frames, boxes
+
+
+def _build(mode, tmp_path, update_interval=5):
+    from lib.test.tracker.uvltrack import UVLTrack
+    from lib.test.utils import TrackerParams
+    from oracle.tracker_oracle import OracleTracker
+    from uvltrack_amd import weightgen as wg
+    from uvltrack_amd.model import ModalityAdaptiveBoxHead, ModalityUnifiedFeatureExtractor
+    from uvltrack_amd.model import UVLTrack as Net
+    from uvltrack_amd.spec import spec_tiny
+    from uvltrack_amd.tokenizer import BertTokenizer
+    spec = spec_tiny()
+    sd = wg.make_state_dict(spec, 3, include_unused=True)
+    net = Net(ModalityUnifiedFeatureExtractor(spec), ModalityAdaptiveBoxHead(spec), max_batch=2)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    vocab = tmp_path / "vocab.txt"
+    vocab.write_text("\n".join(VOCAB) + "\n")
+    tok = BertTokenizer(str(vocab))
+    cfg = _ns(TEST=_ns(UPDATE_INTERVAL=update_interval, THRESHOLD=0.0, MODE=mode), TRAIN=_ns(CONT_WEIGHT=1.0),
+              MODEL=_ns(BACKBONE=_ns(LANGUAGE=_ns(VOCAB_PATH=str(vocab), BERT=_ns(MAX_QUERY_LEN=spec.text_len)))))
+    params = TrackerParams()
+    params.cfg, params.template_factor, params.template_size = cfg, 2.0, spec.template_size
+    params.search_factor, params.search_size, params.grounding_size, params.debug = 4.0, spec.search_size, spec.search_size, 0
+    trk = UVLTrack(params, "synthetic", network=net, tokenizer=tok)
+    orc = OracleTracker(spec, sd, mode=mode, template_factor=2.0, search_factor=4.0, update_interval=update_interval, threshold=0.0, tokenizer=tok)
+    return spec, trk, orc
+
+
+@pytest.mark.parametrize("mode", ["BBOX", "NLBBOX"])
+def test_tracker_frames_match_oracle(mode, tmp_path):
+    spec, trk, orc = _build(mode, tmp_path)
+    frames, boxes = _video()
+    info = {"init_bbox": boxes[0], "language": "the white square moving right on the dark ground"}
+    trk.initialize(frames[0], info)
+    orc.initialize(frames[0], info)
+    torch.cuda.synchronize()
+    assert np.array_equal(trk.template_mask.cpu().numpy(), orc.template_mask)
+    p_err = np.abs(trk.prompt.cpu().numpy() - orc.prompt).max()
+    assert p_err <= 0.03 * np.abs(orc.prompt).max(), "init prompt err %g" % p_err
+    if mode == "NLBBOX":
+        assert np.array_equal(trk.text.tensors.cpu().numpy(), orc.ids) and np.array_equal(trk.text.mask.cpu().numpy(), orc.tmask)
+    checked_update = False
+    for t in range(1, len(frames)):
+        # teacher forcing: both sides start the frame from the oracle's state
+        trk.state, trk.frame_id, trk.max_score = list(orc.state), orc.frame_id, orc.max_score
+        trk.prompt = torch.from_numpy(orc.prompt).cuda()
+        o = orc.track(frames[t])
+        g = trk.track(frames[t])
+        same_best = getattr(trk, "best_frame", None) == getattr(orc, "best_frame", None)
+        merged = orc.merged_scores()
+        gi = int(trk.last_index.item())
+        assert merged.max() - merged[gi] <= 1e-2, "frame %d: GPU argmax cell %d scores %.4f below the oracle maximum" % (t, gi, merged.max() - merged[gi])
+        want = orc.decode_at(gi)
+        tol = 1e-2 * spec.search_size / orc.last_resize + 1e-3
+        assert np.abs(np.asarray(g["target_bbox"]) - np.asarray(want)).max() <= tol, (t, g["target_bbox"], want)
+        if orc.updated and gi == orc.last_index and same_best:
+            err = np.abs(trk.prompt.cpu().numpy() - orc.prompt).max()
+            assert err <= 0.03 * np.abs(orc.prompt).max(), "prompt after update, frame %d: %g" % (t, err)
+            checked_update = True
+    assert orc.frame_id == len(frames) - 1 and len(o["target_bbox"]) == 4
+    assert checked_update, "no prompt update was compared (the best-scoring frames never coincided)"
+
+
+def test_tracker_nl_grounding_init(tmp_path):
+    spec, trk, orc = _build("NL", tmp_path)
+    frames, boxes = _video(n=3)
+    info = {"language": "a bright object moving right"}
+    want = orc.grounding(frames[0], info["language"])
+    out = trk.grounding(frames[0], info)
+    g = orc.grounding_out
+    B = 1
+    score = g["cls_score_test"].reshape(B, -1) * np.exp(g["cont_score"] - g["cont_score"].max(-1, keepdims=True))[..., 0] / \
+        np.exp(g["cont_score"] - g["cont_score"].max(-1, keepdims=True)).sum(-1)
+    top2 = np.sort(score[0])[-2:]
+    assert tuple(out["cont_score"].shape) == (1, spec.nx, 2)
+    assert np.abs(out["cont_score"].cpu().numpy() - g["cont_score"]).max() <= 5e-2
+    assert np.abs(out["bbox_map"].cpu().numpy() - g["bbox_map"]).max() <= 1e-2
+    if top2[1] - top2[0] > 2e-2:           # decisive argmax: the grounded box must agree
+        assert np.abs(np.asarray(out["pred_boxes"]) - np.asarray(want)).max() <= 1e-2 * max(frames[0].shape[:2]) + 1e-3
+    # full NL initialisation runs end to end and leaves a usable state
+    trk.initialize(frames[0], info)
+    r = trk.track(frames[1])
+    assert len(r["target_bbox"]) == 4 and all(np.isfinite(r["target_bbox"])) and int(trk.flag.item()) == 2
