@@ -228,28 +228,35 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
             }
-            float psum = 0.f;
+            // exponent arguments and the row-sum partials are formed two at a time (v_pk_fma_f32 / v_pk_add_f32): the VALU,
+            // not the MFMA pipe, bounds this kernel (32 quarter-rate v_exp_f32 per lane and tile cost as much as the 16 MFMAs)
+            f32x2 psum2 = {0.f, 0.f};
             if (masked) {
+                const f32x2 nm2 = {-m_run, -m_run};
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(s[jb][r] - m_run);
-                        s[jb][r] = pv;
-                        psum += pv;
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 a = f32x2{s[jb][r], s[jb][r + 1]} + nm2;
+                        const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                        s[jb][r] = pv[0];
+                        s[jb][r + 1] = pv[1];
+                        psum2 += pv;
                     }
             } else {
-                const float nm = -m_run;
+                const f32x2 nm2 = {-m_run, -m_run}, cs2 = {CS, CS};
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[jb][r], CS, nm));
-                        s[jb][r] = pv;
-                        psum += pv;
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 a = __builtin_elementwise_fma(f32x2{s[jb][r], s[jb][r + 1]}, cs2, nm2);
+                        const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                        s[jb][r] = pv[0];
+                        s[jb][r + 1] = pv[1];
+                        psum2 += pv;
                     }
             }
-            l_run += psum;
+            l_run += psum2[0] + psum2[1];
 
             // ---- O^T += V^T P^T ----
 #pragma unroll
