@@ -66,6 +66,15 @@ def main(src, tag):
     for fn in os.listdir(src):
         if fn.startswith("bench_") and fn.endswith(".json") and "profile" not in fn:
             shutil.copy(os.path.join(src, fn), os.path.join(out, tag + "_" + fn))
+    if os.path.exists(os.path.join(src, "attn_pmc.txt")):
+        body = open(os.path.join(src, "attn_pmc.txt")).read()
+        bench = open(os.path.join(src, "attn_bench.txt")).read() if os.path.exists(os.path.join(src, "attn_bench.txt")) else ""
+        open(os.path.join(out, tag + "_attention_pmc.md"), "w").write(
+            "# %s -- fused attention kernel alone (tools/attn_bench.py), rocprofv3 PMC passes on B=32, H=16, N=681\n\n"
+            "Counters are per launch as rocprofv3 reports them.  Instruction mix: SQ_INSTS_VALU / SQ_INSTS_MFMA = VALU instructions per MFMA\n"
+            "(16 MFMAs of 8 passes = 512 MFMA-pipe cycles per 64-key tile and wave); wave time: SQ_WAIT_ANY (s_waitcnt / barrier),\n"
+            "SQ_WAIT_INST_ANY (issue stalls), SQ_ACTIVE_INST_ANY (issuing) as fractions of SQ_WAVE_CYCLES.\n\n```\n%s```\n\n"
+            "Throughput of the same build on the frame's shapes:\n\n```\n%s```\n" % (tag, body, "\n".join(l for l in bench.splitlines() if l.startswith("attention")) + "\n"))
     print("\n".join(lines))
 
 

@@ -24,5 +24,15 @@ python bench.py --batch 32 --steps 30 --warmup 5 --no-cpu-baseline --profile-jso
 python bench.py --model L --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_L.json 2>/dev/null
 python bench.py --model L --batch 8 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_L_b8.json 2>/dev/null
 python bench.py --mode BBOX --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_bbox.json 2>/dev/null
-for f in default b8 b32 L L_b8 bbox; do tail -1 $O/bench_$f.json | cut -c1-140; done
+python bench.py --mode NL --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_nl.json 2>/dev/null
+python bench.py --template-size 128 --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_z128.json 2>/dev/null
+python bench.py --model L --template-size 128 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_L_z128.json 2>/dev/null
+# fused-attention kernel alone on the batched UVLTrack-L shape (B=32, H=16, N=681): instruction mix and busy counters
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/attn/p1 -o a -- python $REPO/tools/attn_bench.py 32 16 681 > $O/attn_p1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/attn/p2 -o a -- python $REPO/tools/attn_bench.py 32 16 681 > $O/attn_p2.log 2>&1
+cd $REPO
+python tools/pmc_report.py $O/attn attn_kernel > $O/attn_pmc.txt 2>&1
+python tools/attn_bench.py > $O/attn_bench.txt 2>&1
+for f in default b8 b32 L L_b8 bbox nl z128 L_z128; do tail -1 $O/bench_$f.json | cut -c1-140; done
 ls $O/stats $O/pmc_mfma | head -20

@@ -362,14 +362,15 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.N <= 0 || p.Npad % 64 != 0 || p.Npad < ((p.N + 63) / 64) * 64) return hipErrorInvalidValue;
     int cfg = g_tune_attn_cfg;
     if (cfg < 0) {
-        // enough (batch x heads x query blocks) to fill the chip with 128-query workgroups -> share the K/V tiles across
-        // 4 query waves; otherwise split the KEYS across the 4 waves (batch-1 latency shape)
+        // measured on MI355X (tools/attn_bench.py sweeps): 128-query workgroups share the K/V tiles once they fill the chip;
+        // a single sequence of 5..9 key tiles runs "single shot" (one wave per key tile, every tile in flight) as long as
+        // its 32-query workgroups fit the chip in one round; everything in between takes 64 queries x 2 key halves
         const long wg4 = (long)((p.N + 127) / 128) * p.H * p.B;
+        const long wg1 = (long)((p.N + 31) / 32) * p.H * p.B;
         const int nt = (p.N + 63) / 64;
         if (wg4 >= 256 || nt < 2) cfg = 0;
-        else if (nt >= 5 && nt <= 6) cfg = 5;        // batch-1 latency shape: one wave per key tile, every tile in flight at once
-        else if (nt >= 7 && nt <= 9) cfg = 6;
-        else if (nt >= 4) cfg = 2;
+        else if (wg1 <= 288 && nt >= 5 && nt <= 6) cfg = 5;
+        else if (wg1 <= 288 && nt >= 7 && nt <= 9) cfg = 6;
         else cfg = 1;
     }
     switch (cfg) {
