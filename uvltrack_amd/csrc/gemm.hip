@@ -310,7 +310,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
     static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && LPT * (NS - 2) <= 63, "geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: LDS-DMA destinations (M0) stay scalar
     const int wm = wave / WGN, wn = wave % WGN;
     const int g = CONV ? blockIdx.z : 0;             // conv tower (group)
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
@@ -342,9 +343,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
     const int kspan = p.K / p.splitk;
     const int kbase = sk * kspan;
     // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + NW*i), +8)
-    const bf16_t* src[LPT];
+    const bf16_t* src[CONV ? LPT : 1];                       // conv: full per-lane pointers (the tap moves them per K tile)
+    uint32_t loff[CONV ? 1 : LPT];                           // plain: 32-bit byte offsets from two wave-uniform bases, so a DMA
+                                                             // costs no VALU (global_load_lds v_off, s[base:base+1])
     int a_i[LPT_A], a_j[LPT_A];                              // conv: pixel of the A row this lane fetches
     const int convF = p.conv_F, cin_g = p.cin_g, lda = p.lda;
+    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * lda + kbase);
+    const char* w_base = reinterpret_cast<const char*>(p.W + ((size_t)g * p.N + n0) * p.ldw + kbase);
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int r = 8 * (wave + NW * i) + (lane >> 3);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
         if (i < LPT_A) {
             int gm = m0 + r;
             gm = gm < p.M ? gm : p.M - 1;
-            if (CONV) {
+            if constexpr (CONV) {
                 const int S = convF * convF;
                 const int b = gm / S, pix = gm - b * S;
                 a_i[i] = pix / convF;
@@ -360,34 +365,50 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
                 const int goff = g == 0 ? p.a_goff[0] : g == 1 ? p.a_goff[1] : g == 2 ? p.a_goff[2] : p.a_goff[3];
                 src[i] = p.A + (size_t)b * S * lda + goff + chunk * 8;       // + (pixel row) * lda + channel, per K tile
             } else {
-                src[i] = p.A + (size_t)gm * lda + kbase + chunk * 8;
+                loff[i] = (uint32_t)(gm - m0) * (uint32_t)lda * 2u + (uint32_t)chunk * 16u;
             }
         } else {
-            src[i] = p.W + ((size_t)g * p.N + n0 + r - BM) * p.ldw + kbase + chunk * 8;
+            if constexpr (CONV) src[i] = p.W + ((size_t)g * p.N + n0 + r - BM) * p.ldw + kbase + chunk * 8;
+            else loff[i] = (uint32_t)(r - BM) * (uint32_t)p.ldw * 2u + (uint32_t)chunk * 16u;
         }
     }
     auto issue = [&](int kt) __attribute__((always_inline)) {
         char* st = smem + (kt % NS) * STAGE;
-        int tap_di = 0, tap_dj = 0, c0 = 0;
-        if (CONV) {                                           // K index = tap * cin_g + channel; a 64-wide tile never straddles taps
+        if constexpr (CONV) {
+            // K index = tap * cin_g + channel; a 64-wide tile never straddles taps
             const int k0 = kbase + kt * BK;
             const int tap = k0 / cin_g;
-            c0 = k0 - tap * cin_g;
-            tap_di = tap / 3 - 1;
-            tap_dj = tap % 3 - 1;
-        }
+            const int c0 = k0 - tap * cin_g;
+            const int tap_di = tap / 3 - 1, tap_dj = tap % 3 - 1;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const bf16_t* gp;
-            if (CONV && i < LPT_A) {
-                const int ii = a_i[i] + tap_di, jj = a_j[i] + tap_dj;
-                const bool ok = (unsigned)ii < (unsigned)convF && (unsigned)jj < (unsigned)convF;
-                gp = ok ? src[i] + (size_t)(ii * convF + jj) * lda + c0 : reinterpret_cast<const bf16_t*>(g_zero_page);
-            } else {
-                gp = src[i] + kt * BK;
+            for (int i = 0; i < LPT; ++i) {
+                const bf16_t* gp;
+                if (i < LPT_A) {
+                    const int ii = a_i[i] + tap_di, jj = a_j[i] + tap_dj;
+                    const bool ok = (unsigned)ii < (unsigned)convF && (unsigned)jj < (unsigned)convF;
+                    gp = ok ? src[i] + (size_t)(ii * convF + jj) * lda + c0 : reinterpret_cast<const bf16_t*>(g_zero_page);
+                } else {
+                    gp = src[i] + kt * BK;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
+        } else {
+            // wave-uniform bases; the readfirstlane pair pins them in SGPRs (otherwise LLVM folds them back into per-lane
+            // 64-bit pointers and pays a 64-bit VALU add per DMA)
+            auto pin = [](const char* q) __attribute__((always_inline)) {
+                const uint64_t u = reinterpret_cast<uint64_t>(q);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+                return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+            };
+            const char* ab = pin(a_base + (size_t)kt * (BK * 2));
+            const char* wb = pin(w_base + (size_t)kt * (BK * 2));
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                const char* gp = (i < LPT_A ? ab : wb) + loff[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
+            }
         }
     };
 
