@@ -113,3 +113,31 @@ def test_tracker_nl_grounding_init(tmp_path):
     trk.initialize(frames[0], info)
     r = trk.track(frames[1])
     assert len(r["target_bbox"]) == 4 and all(np.isfinite(r["target_bbox"])) and int(trk.flag.item()) == 2
+
+
+def test_batch_tracker_matches_single_trackers(tmp_path):
+    """BatchUVLTrack (B sequences in lockstep, one batched forward / decode per frame) against B single trackers fed the same
+    frames, teacher-forced per frame; boxes agree within the bf16 gate unless the argmax is a near-tie."""
+    from lib.test.tracker.uvltrack_batch import BatchUVLTrack
+    spec, trk0, _ = _build("BBOX", tmp_path, update_interval=4)
+    _, trk1, _ = _build("BBOX", tmp_path, update_interval=4)
+    singles = [trk0, trk1]
+    bt = BatchUVLTrack(trk0.params, 2, network=trk0.network)
+    fa, ba = _video(n=9, seed=1)
+    fb, bb = _video(n=9, seed=2)
+    infos = [{"init_bbox": ba[0]}, {"init_bbox": [v + 3.0 for v in bb[0]]}]
+    for t, f, i in zip(singles, (fa[0], fb[0]), infos):
+        t.initialize(f, i)
+    bt.initialize([fa[0], fb[0]], infos)
+    assert torch.equal(bt.template[0:1], singles[0].template) and torch.equal(bt.prompt[1:2], singles[1].prompt)
+    agree = 0
+    for k in range(1, 9):
+        for b, t in enumerate(singles):            # teacher forcing from the batch tracker's state
+            t.state, t.max_score, t.frame_id = list(bt.state[b]), bt.max_score[b], bt.frame_id
+            t.prompt = bt.prompt[b:b + 1].clone()
+        res = bt.track([fa[k], fb[k]])
+        for b, (t, f) in enumerate(zip(singles, (fa[k], fb[k]))):
+            r = t.track(f)
+            d = np.abs(np.asarray(r["target_bbox"]) - np.asarray(res[b]["target_bbox"])).max()
+            agree += d <= 1e-2 * spec.search_size * 4 + 1e-3          # same cell chosen: boxes equal up to bf16 noise
+    assert agree >= 14, "batched and single trackers picked different cells in %d of 16 frames" % (16 - agree)
