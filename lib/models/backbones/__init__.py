@@ -1,8 +1,7 @@
-"""registry.BACKBONES['modality_unified_feature_extractor'] -- reference lib/models/backbones/__init__.py:4-7."""
-from lib import registry
+"""Backbone registry entry of the per-frame path.  Config key MODEL.BACKBONE.TYPE = 'modality_unified_feature_extractor'
+resolves to the HIP-backed extractor (the reference registers its eager module under the same key,
+lib/models/backbones/__init__.py:4-7)."""
+from lib.registry import BACKBONES
 from uvltrack_amd.model import ModalityUnifiedFeatureExtractor, build_backbone  # noqa: F401
 
-
-@registry.BACKBONES.register('modality_unified_feature_extractor')
-def build_modality_unified_feature_extractor(cfg):
-    return build_backbone(cfg)
+BACKBONES.register("modality_unified_feature_extractor", build_backbone)
