@@ -253,12 +253,15 @@ int main() {
         fill(na); hipMemcpy(A, h.data(), na * 2, hipMemcpyHostToDevice);
         fill(nw); hipMemcpy(W, h.data(), nw * 2, hipMemcpyHostToDevice);
     }
-    const int shapes[][3] = {{17696, 3072, 768}, {17696, 768, 3072}, {4424, 3072, 768}};
+    // fixed per-tile cost vs per-K-iteration cost: same tile grid, K = 768 / 1536 / 3072
+    const int shapes[][3] = {{17696, 3072, 768}, {17696, 3072, 1536}, {17696, 3072, 3072}};
     for (auto& s : shapes) {
         printf("M=%d N=%d K=%d\n", s[0], s[1], s[2]);
-        run_all<128, 128, 2, 2, 2>(A, W, C, s[0], s[1], s[2]);
-        run_all<64, 128, 2, 2, 2>(A, W, C, s[0], s[1], s[2]);
-        run_all<256, 256, 2, 4, 2>(A, W, C, s[0], s[1], s[2]);
+        run<128, 128, 2, 2, 2, 0, 12>(A, W, C, s[0], s[1], s[2], 8);
+        run<128, 128, 2, 2, 2, 4, 0>(A, W, C, s[0], s[1], s[2], 8);
+        run<256, 256, 2, 4, 2, 0, 12>(A, W, C, s[0], s[1], s[2], 8);
+        run<256, 256, 2, 4, 2, 4, 0>(A, W, C, s[0], s[1], s[2], 8);
+        run<64, 128, 2, 2, 2, 0, 12>(A, W, C, s[0], s[1], s[2], 8);
     }
     return 0;
 }
