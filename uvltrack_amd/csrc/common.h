@@ -51,6 +51,28 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float erf_abs = 1.0f - poly * t * e;                 // erf(|x| / sqrt 2)
     return 0.5f * x + 0.5f * fabsf(x) * erf_abs;               // 0.5 x (1 + sign(x) erf(|x|/sqrt 2))
 }
+// Two elements at a time, one transcendental per element: erf by Abramowitz & Stegun 7.1.28,
+//   erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16,  |error| <= 3e-7 for z >= 0,
+// i.e. six packed FMAs, four packed squarings and one v_rcp_f32 (the 7.1.26 form above needs v_rcp AND v_exp; 64 GELUs per
+// lane and 128x128 tile otherwise cost as much as the tile's MFMAs).  P^16 overflows to +inf for |x| > ~25: rcp(inf) = 0, erf = 1.
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752440f;
+    f32x2 pz = __builtin_elementwise_fma(z, f32x2{0.0000430638f, 0.0000430638f}, f32x2{0.0002765672f, 0.0002765672f});
+    pz = __builtin_elementwise_fma(pz, z, f32x2{0.0001520143f, 0.0001520143f});
+    pz = __builtin_elementwise_fma(pz, z, f32x2{0.0092705272f, 0.0092705272f});
+    pz = __builtin_elementwise_fma(pz, z, f32x2{0.0422820123f, 0.0422820123f});
+    pz = __builtin_elementwise_fma(pz, z, f32x2{0.0705230784f, 0.0705230784f});
+    pz = __builtin_elementwise_fma(pz, z, f32x2{1.0f, 1.0f});
+    pz = pz * pz;
+    pz = pz * pz;
+    pz = pz * pz;
+    pz = pz * pz;
+    const f32x2 r = {__builtin_amdgcn_rcpf(pz[0]), __builtin_amdgcn_rcpf(pz[1])};
+    const f32x2 hax = ax * 0.5f;
+    // 0.5 x + 0.5 |x| erf(|x| / sqrt 2) = 0.5 x + 0.5 |x| - 0.5 |x| r
+    return __builtin_elementwise_fma(-hax, r, __builtin_elementwise_fma(x, f32x2{0.5f, 0.5f}, hax));
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // MFMA 32x32x16 bf16 C/D fragment: register r of lane l holds

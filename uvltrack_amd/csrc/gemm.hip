@@ -123,8 +123,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     *reinterpret_cast<f32x4*>(cw + (lane & 31) * RS + cl * 4) = v;
                 } else {
                     if (EPI == EPI_BF16 && p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+                        const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
                     } else if (EPI == EPI_BF16 && p.act == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
