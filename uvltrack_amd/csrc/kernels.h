@@ -54,6 +54,15 @@ struct LnParams {
     bf16_t* y_bf16 = nullptr;                    // [M,D] compact, optional
     float* y_f32 = nullptr; int y_remap = 0;     // optional f32 output; y_remap: same row map as x (in-place LN) else compact
     float* y_copy = nullptr;                     // optional second f32 output, compact [M,D] (text snapshot)
+    float* x_snap = nullptr;                     // optional copy of the row AFTER the slab fold and BEFORE pre_add (= the previous
+                                                 // layer's output), same row map as x
+    // Optional second job of the launch: the contrastive logits of the PREVIOUS layer (extractor.py:85-93) from the snapshot the
+    // previous LayerNorm left in ct_x -- the wave that normalises search row s of sample b also writes logits[b, slot, s].
+    // No extra launch, no cross-stream event ('cls' text token only; 'mean' keeps the stand-alone contrast kernel).
+    const float* ct_x = nullptr;                 // snapshot [B, xbs, D]; row 0 = vis token, rows 1+ct_nz.. = search, row ct_nv = text row 0
+    const float* ct_txt = nullptr;               // [B, ct_T, D] text rows of that layer (pre-fusion layers) or null = snapshot row ct_nv
+    int ct_nz = 0, ct_nv = 0, ct_nx = 0, ct_T = 0, ct_skip_text = 0, ct_slot = 0, ct_ncont = 0;
+    const int64_t* ct_flag = nullptr; const float* ct_logit_scale = nullptr; float* ct_logits = nullptr;
 };
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
 

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
 #pragma unroll
             for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
                 if (sp < nsp) { v[i].x += sl[sp].x; v[i].y += sl[sp].y; v[i].z += sl[sp].z; v[i].w += sl[sp].w; }
+            if (p.x_snap) *reinterpret_cast<float4*>(p.x_snap + xrow * p.D + c) = v[i];
             if (padd) {
                 const float4 a = *reinterpret_cast<const float4*>(padd + c);
                 v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
@@ -81,6 +82,39 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
                 *reinterpret_cast<uint2*>(p.y_bf16 + (size_t)m * p.D + c) = w;
             }
         }
+    }
+    // ---- contrastive logits of the previous layer for this wave's search row (same arithmetic, in the same order, as
+    //      contrast_kernel: tau * normalize(x) . normalize(token), select [vis, txt, mean][flag]) ----
+    if (p.ct_x && t >= 1 + p.ct_nz && t < p.ct_nv) {
+        const int s = t - 1 - p.ct_nz;
+        const float* xb = p.ct_x + (size_t)b * p.xbs * p.D;
+        const float* xs = xb + (size_t)t * p.D;
+        const float* tk = p.ct_txt ? p.ct_txt + (size_t)b * p.ct_T * p.D : xb + (size_t)p.ct_nv * p.D;
+        float xx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
+        for (int c = lane * 4; c < p.D; c += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(xs + c);
+            const float4 vq = *reinterpret_cast<const float4*>(xb + c);
+            xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            xv += a.x * vq.x + a.y * vq.y + a.z * vq.z + a.w * vq.w;
+            vv += vq.x * vq.x + vq.y * vq.y + vq.z * vq.z + vq.w * vq.w;
+            if (!p.ct_skip_text) {
+                const float4 q = *reinterpret_cast<const float4*>(tk + c);
+                xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+                tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+            }
+        }
+        const float tau = __expf(p.ct_logit_scale[0]);
+        xx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
+        vv = fmaxf(sqrtf(wave_sum(vv)), 1e-12f);
+        const float lv = tau * wave_sum(xv) / (xx * vv);
+        float lt = 0.f;
+        if (!p.ct_skip_text) {
+            tt = fmaxf(sqrtf(wave_sum(tt)), 1e-12f);
+            lt = tau * wave_sum(xt) / (xx * tt);
+        }
+        const int fl = (int)p.ct_flag[b];
+        const float out = fl == 0 ? lv : (fl == 1 ? lt : 0.5f * (lv + lt));
+        if (lane == 0) p.ct_logits[((size_t)b * p.ct_ncont + p.ct_slot) * p.ct_nx + s] = out;
     }
 }
 

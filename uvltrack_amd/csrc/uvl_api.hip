@@ -87,6 +87,7 @@ struct uvl_model {
     // streams / events
     hipStream_t aux = nullptr, pf = nullptr;     // text-branch stream, weight-prefetch stream
     std::vector<hipEvent_t> ev_pf;
+    int fuse_contrast = 1;                       // UVL_FUSE_CONTRAST=0: stand-alone contrast kernels
     int prefetch = 0;                            // UVL_PREFETCH=1: measured -9 % FPS on MI355X (48 extra launches), off by default
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_bert, ev_cont;
@@ -134,6 +135,7 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
     m->ev_pf.resize(c->depth);
     for (auto& e : m->ev_pf) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     { const char* e = getenv("UVL_PREFETCH"); if (e) m->prefetch = atoi(e); }
+    { const char* e = getenv("UVL_FUSE_CONTRAST"); if (e) m->fuse_contrast = atoi(e); }
     m->ev_bert.resize(c->depth);
     m->ev_cont.resize(c->depth);
     for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -394,7 +396,7 @@ struct Pending { const float* part = nullptr; int nsplit = 0, rows = 0; size_t s
 struct Workspace {
     float* X; bf16_t *Xn, *Q, *K, *Vt, *O, *Hb, *P;
     bf16_t *Tn, *Tq, *Tk, *Tvt, *To, *Th;
-    float *key_add, *bert_add, *cont, *bbox, *Part, *PartT, *TxtSnap, *ConvPart;
+    float *key_add, *bert_add, *cont, *bbox, *Part, *PartT, *TxtSnap, *ConvPart, *XSnap;
     bf16_t *G0, *G1, *G2, *G3, *G4;
     size_t total;
 };
@@ -422,6 +424,7 @@ static Workspace carve(const uvl_model* m, int B, char* base) {
     w.Part = (float*)take((size_t)UVL_SKMAX * B * nj * D * 4);
     w.PartT = (float*)take((size_t)UVL_SKMAX * B * T * D * 4);
     w.TxtSnap = (float*)take((size_t)(m->nf > 0 ? m->nf : 1) * B * T * D * 4);
+    w.XSnap = (float*)take(B * nj * D * 4);
     w.ConvPart = (float*)take((size_t)UVL_CONV_SKMAX * B * S * 4 * C * 4);
     w.cont = (float*)take(B * S * 3 * 4);
     w.bbox = (float*)take(B * S * 4 * 4);
@@ -625,6 +628,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         RUN_GEMM(L, s, p, "gemm.patch");
     }
     int cont_slot = 0;
+    int fused_ct = -1, fused_slot = 0;           // contrast layer whose logits the next layer's LayerNorm-2 will write
     Pending pend_v;                              // split-K slabs not yet folded into the residual stream (visual/joint rows)
     for (int i = 0; i < m->depth; ++i) {
         const bool joint = i >= m->nf;
@@ -653,6 +657,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             consume(p, pend_v);
             if (joint) { p.pre_add0 = m->modal; p.pre_add1 = m->modal + D; p.split = nv; }     // forward_joint, mae_vit.py:196
             p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
+            if (fused_ct >= 0) p.x_snap = w.XSnap;   // this fold completes layer `fused_ct`: keep its output for the logits
             L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
         }
         {
@@ -672,6 +677,17 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
             consume(p, pend_v);
             p.gamma = vw.ln2g; p.beta = vw.ln2b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
+            if (fused_ct >= 0) {                 // logits of layer `fused_ct` ride on this launch (rows come from the snapshot)
+                if (!skip) L.cur = PART_V2;
+                p.ct_x = w.XSnap; p.ct_nz = nz; p.ct_nv = nv; p.ct_nx = nx; p.ct_T = T; p.ct_skip_text = skip;
+                p.ct_slot = fused_slot; p.ct_ncont = m->cfg.n_cont;
+                p.ct_flag = in->d_flag; p.ct_logit_scale = m->logit_scale_bb; p.ct_logits = out->d_logits;
+                if (fused_ct < m->nf && !skip) {   // pre-fusion layer: its text token comes from the text branch's snapshot
+                    if (fork && hipStreamWaitEvent(s, m->ev_bert[fused_ct], 0) != hipSuccess) return fail(UVL_EHIP, "bert event failed");
+                    p.ct_txt = w.TxtSnap + (size_t)fused_ct * B * T * D;
+                }
+                fused_ct = -1;
+            }
             L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
         }
         {
@@ -684,7 +700,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (i <= last_bert) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
         if (is_cont_layer(i)) {
-            if (out->d_logits) {
+            if (out->d_logits && !last && !m->cfg.txt_token_mean && m->fuse_contrast) {
+                // 'cls' text token and a following layer: the next LayerNorm-1 leaves this layer's output in XSnap and the
+                // next LayerNorm-2 computes the logits from it (no launch of its own)
+                fused_ct = i;
+                fused_slot = cont_slot;
+            } else if (out->d_logits) {
                 ContrastParams p;
                 if (!skip) L.cur = PART_V2;    // first consumer of text data on the visual side: everything from here is part V2
                 if (!joint && !skip) {   // text token of THIS layer comes from the text branch's snapshot
@@ -708,6 +729,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
     }
     if (pend_v.nsplit || pend_t.nsplit) return fail(UVL_ESTATE, "internal: split-K slabs left unconsumed");
+    if (fused_ct >= 0) return fail(UVL_ESTATE, "internal: fused contrast job left unlaunched");
 
     if (!skip) L.cur = PART_V2;
     // ---- head (modality_adaptive_box_head.py:62-94) ----
