@@ -99,6 +99,8 @@ struct HeadPrepParams {
     int cont_only = 0;                           // 1: only cont_score, search rows read from o_search (compact [B,S,D]); x is not touched
     int train_cont = 0;                          // 1: cont_score layout of the head's no-prompt branch, [B,S,2] (head:134-138)
     bf16_t* g0 = nullptr; int g0_ld = 0;
+    // optional second job: the backbone's contrastive logits of the LAST layer (extractor.py:85-93) for the same search rows
+    float* ct_logits = nullptr; const float* ct_logit_scale = nullptr; int ct_slot = 0, ct_ncont = 0;
     float *o_search = nullptr, *o_template = nullptr, *o_text = nullptr, *o_vis = nullptr, *o_txt = nullptr, *o_cont = nullptr;
 };
 hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s);

@@ -541,6 +541,32 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) 
         const float c2 = tau * wave_sum(d2) / (xx * n2);
         if (lane == 0) write_cont(p, b, s, c0, c1, c2);
     }
+    if (is_search && p.ct_logits) {              // same arithmetic and order as contrast_kernel (the row is cache-hot)
+        float sx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + c);
+            const float4 v = *reinterpret_cast<const float4*>(xb + c);
+            sx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            xv += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+            vv += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (have_text) {
+                const float4 q = *reinterpret_cast<const float4*>(txt_tok + c);
+                xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+                tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+            }
+        }
+        const float tau = __expf(p.ct_logit_scale[0]);
+        sx = fmaxf(sqrtf(wave_sum(sx)), 1e-12f);
+        vv = fmaxf(sqrtf(wave_sum(vv)), 1e-12f);
+        const float lv = tau * wave_sum(xv) / (sx * vv);
+        float lt = 0.f;
+        if (have_text) {
+            tt = fmaxf(sqrtf(wave_sum(tt)), 1e-12f);
+            lt = tau * wave_sum(xt) / (sx * tt);
+        }
+        const float o = fl == 0 ? lv : (fl == 1 ? lt : 0.5f * (lv + lt));
+        if (lane == 0) p.ct_logits[((size_t)b * p.ct_ncont + p.ct_slot) * p.nx + s] = o;
+    }
 }
 
 hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s) {

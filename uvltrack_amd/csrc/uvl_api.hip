@@ -628,6 +628,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         RUN_GEMM(L, s, p, "gemm.patch");
     }
     int cont_slot = 0;
+    int head_ct_slot = -1;                       // >= 0: head_prep also writes the last layer's logits into this slot
     int fused_ct = -1, fused_slot = 0;           // contrast layer whose logits the next layer's LayerNorm-2 will write
     Pending pend_v;                              // split-K slabs not yet folded into the residual stream (visual/joint rows)
     for (int i = 0; i < m->depth; ++i) {
@@ -700,7 +701,9 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (i <= last_bert) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
         if (is_cont_layer(i)) {
-            if (out->d_logits && !last && !m->cfg.txt_token_mean && m->fuse_contrast) {
+            if (out->d_logits && last && joint && i == m->depth - 1 && m->fuse_contrast && m->debug_stop_layer < 0) {
+                head_ct_slot = cont_slot;        // last layer: X is final, head_prep walks the same search rows anyway
+            } else if (out->d_logits && !last && !m->cfg.txt_token_mean && m->fuse_contrast) {
                 // 'cls' text token and a following layer: the next LayerNorm-1 leaves this layer's output in XSnap and the
                 // next LayerNorm-2 computes the logits from it (no launch of its own)
                 fused_ct = i;
@@ -745,6 +748,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         p.g0 = w.G0; p.g0_ld = g0_ld;
         p.o_search = out->d_search; p.o_template = out->d_template; p.o_text = out->d_text; p.o_vis = out->d_vis_token; p.o_txt = out->d_txt_token;
         p.o_cont = cont;
+        if (head_ct_slot >= 0) { p.ct_logits = out->d_logits; p.ct_logit_scale = m->logit_scale_bb; p.ct_slot = head_ct_slot; p.ct_ncont = m->cfg.n_cont; }
         if (tb) { p.prompt = nullptr; p.o_cont = nullptr; }      // first pass: token outputs + head input only
         L.run(s, "head_prep", 0, 0, tramp<HeadPrepParams, launch_head_prep>, &p);
         if (tb && !L.err) {
@@ -752,7 +756,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                                         tb->template_mask, tb->context_mask, B / 2, tb->prompts_out, s);
             if (rc) return rc;
             HeadPrepParams c = p;
-            c.cont_only = 1; c.train_cont = 1; c.prompt = tb->prompts_out; c.o_cont = cont;
+            c.cont_only = 1; c.train_cont = 1; c.prompt = tb->prompts_out; c.o_cont = cont; c.ct_logits = nullptr;
             L.run(s, "head_prep", 0, 0, tramp<HeadPrepParams, launch_head_prep>, &c);
         }
     }
