@@ -37,7 +37,7 @@ template <int N_> __device__ __forceinline__ void attn_wait_vmcnt() { asm volati
 #define ATTN_DEFER 8.0f
 
 template <int QW, int KS, int NS>
-__global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(const AttnParams p) {
+__device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, const int h, const int b, char* smem) {
     constexpr int NWAVES = QW * KS;
     constexpr int K_BYTES = 8192, V_BYTES = 8192, ADD_BYTES = 256, FLAG_BYTES = 16;
     constexpr int SLOT = K_BYTES + V_BYTES + ADD_BYTES + FLAG_BYTES;
@@ -46,13 +46,11 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
     constexpr int LPW = KV_PER_WAVE + 1;                 // + one key_add DMA, issued only by the slot's owner wave (qw == 0)
     constexpr int NSM2 = NS >= 2 ? NS - 2 : 0;           // NS == 1: "single shot" -- every key tile of the head is resident at once
     static_assert((16 * KS) % NWAVES == 0 && LPW * NSM2 <= 63, "geometry");
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // NS * STAGE (>= the merge exchange area)
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = wave / KS, ks = wave % KS;
     const bool add_owner = (qw == 0);                    // exactly one wave per slot stages (and rewrites) its key_add row
-    const int h = blockIdx.y, b = blockIdx.z;
     const int N = p.N, Npad = p.Npad;
     const size_t bh = (size_t)b * p.H + h;
     const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
@@ -62,7 +60,7 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
 
     const int nt = (N + 63) >> 6;                 // key tiles
     const int rounds = (nt + KS - 1) / KS;
-    const int q0 = (blockIdx.x * QW + qw) * 32;
+    const int q0 = (bx * QW + qw) * 32;
     const int qrow = q0 + (lane & 31);
     const int qld = qrow < N ? qrow : N - 1;
     bf16x8 qf[4];
@@ -338,6 +336,50 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
 }
 
 template <int QW, int KS, int NS>
+__global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // NS * STAGE (>= the merge exchange area)
+    attn_body<QW, KS, NS>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Two independent attention problems in one launch (batch-1 frames: the 40-token text-branch attention rides on the visual
+// one's configuration).  1-D grid, problem A owns [0, blocks_a); (query block, head, sample) are decoded per problem.
+template <int QW, int KS, int NS>
+__global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_pair_kernel(const AttnParams pa, const AttnParams pb, int blocks_a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < blocks_a) {
+        int id = (int)blockIdx.x;
+        const int nqb = (pa.N + 32 * QW - 1) / (32 * QW), qb = id % nqb;
+        id /= nqb;
+        attn_body<QW, KS, NS>(pa, qb, id % pa.H, id / pa.H, smem);
+    } else {
+        int id = (int)blockIdx.x - blocks_a;
+        const int nqb = (pb.N + 32 * QW - 1) / (32 * QW), qb = id % nqb;
+        id /= nqb;
+        attn_body<QW, KS, NS>(pb, qb, id % pb.H, id / pb.H, smem);
+    }
+}
+
+template <int QW, int KS, int NS>
+static hipError_t launch_attn_pair_cfg(const AttnParams& a, const AttnParams& b, hipStream_t s) {
+    constexpr size_t ring = (size_t)NS * KS * (8192 + 8192 + 256 + 16);
+    constexpr size_t xch = (size_t)QW * KS * 34 * 64 * 4;
+    constexpr size_t lds = ring > xch ? ring : xch;
+    auto kern = attn_pair_kernel<QW, KS, NS>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[48];
+    if (!name[0]) snprintf(name, sizeof(name), "attn_pair_kernel<%d,%d,%d>", QW, KS, NS);
+    g_last_kernel = name;
+    const int ba = ((a.N + 32 * QW - 1) / (32 * QW)) * a.H * a.B, bb = ((b.N + 32 * QW - 1) / (32 * QW)) * b.H * b.B;
+    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(64 * QW * KS), lds, s, a, b, ba);
+    return hipGetLastError();
+}
+
+template <int QW, int KS, int NS>
 static hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
     constexpr size_t ring = (size_t)NS * KS * (8192 + 8192 + 256 + 16);
     constexpr size_t xch = (size_t)QW * KS * 34 * 64 * 4;
@@ -358,8 +400,7 @@ static hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
 
 int g_tune_attn_cfg = -1;      // tools/attn_bench.py override
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
-    if (p.N <= 0 || p.Npad % 64 != 0 || p.Npad < ((p.N + 63) / 64) * 64) return hipErrorInvalidValue;
+static int pick_attn_cfg(const AttnParams& p) {
     int cfg = g_tune_attn_cfg;
     if (cfg < 0) {
         // measured on MI355X (tools/attn_bench.py sweeps): 128-query workgroups share the K/V tiles once they fill the chip;
@@ -373,6 +414,28 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         else if (wg1 <= 288 && nt >= 7 && nt <= 9) cfg = 6;
         else cfg = 1;
     }
+    return cfg;
+}
+
+hipError_t launch_attention_pair(const AttnParams& a, const AttnParams& b, hipStream_t s) {
+    auto ok = [](const AttnParams& p) { return p.N > 0 && p.Npad % 64 == 0 && p.Npad >= ((p.N + 63) / 64) * 64; };
+    if (!ok(a) || !ok(b)) return hipErrorInvalidValue;
+    const int cfg = pick_attn_cfg(a);
+    const int ntb = (b.N + 63) / 64;
+    // the rider must fit the configuration's key capacity: single-shot variants hold 6 / 9 key tiles, the ring variants any number
+    switch (cfg) {
+        case 1: return launch_attn_pair_cfg<2, 2, 2>(a, b, s);
+        case 5: if (ntb <= 6) return launch_attn_pair_cfg<1, 6, 1>(a, b, s); break;
+        case 6: if (ntb <= 9) return launch_attn_pair_cfg<1, 9, 1>(a, b, s); break;
+        default: break;
+    }
+    const hipError_t e = launch_attention(a, s);
+    return e != hipSuccess ? e : launch_attention(b, s);
+}
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
+    if (p.N <= 0 || p.Npad % 64 != 0 || p.Npad < ((p.N + 63) / 64) * 64) return hipErrorInvalidValue;
+    const int cfg = pick_attn_cfg(p);
     switch (cfg) {
         case 0: return launch_attn_cfg<4, 1, 2>(p, s);
         case 1: return launch_attn_cfg<2, 2, 2>(p, s);

@@ -298,7 +298,7 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 __device__ uint32_t g_zero_page[64];      // 256 zero bytes: DMA source of out-of-image conv taps (zero padding)
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk, const int g, char* smem) {
     constexpr int BK = 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -308,15 +308,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
     constexpr int LPT = ROWS / (8 * NW);             // DMA instructions per wave per tile (each fills 8 rows)
     constexpr int LPT_A = BM / (8 * NW);             // the first LPT_A instructions of a wave fill A rows, the rest W rows
     static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && LPT * (NS - 2) <= 63, "geometry");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: LDS-DMA destinations (M0) stay scalar
     const int wm = wave / WGN, wn = wave % WGN;
-    const int g = CONV ? blockIdx.z : 0;             // conv tower (group)
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
     // Workgroup b runs on XCD b % 8 (dispatch order; affects speed only), and every XCD has its own L2.
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xcd = bx & 7, idx = bx >> 3;
     int nt, mt;
     if (p.group_m == 0) {
         // small M: an XCD owns whole N panels, so every weight byte enters exactly one L2; the few A rows are shared by all
@@ -338,8 +336,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
     }
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // split-K: blockIdx.y owns the K range [sk*K/splitk, (sk+1)*K/splitk) and writes its own f32 partial slab
-    const int sk = blockIdx.y;
+    // split-K: slice sk owns the K range [sk*K/splitk, (sk+1)*K/splitk) and writes its own f32 partial slab
     const int kspan = p.K / p.splitk;
     const int kbase = sk * kspan;
     // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + NW*i), +8)
@@ -455,6 +452,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk);
 }
 
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
+}
+
+// Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
+// visual GEMM of the same kind).  1-D grid: problem A owns [0, blocks_a) = tiles_a x splitk_a, problem B the rest; tile
+// counts are multiples of 8, so the workgroup -> XCD relation of both tile maps is preserved.
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
+    if ((int)blockIdx.x < blocks_a) {
+        const int id = (int)blockIdx.x, sk = id / tiles_a;
+        gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false>(pa, id - sk * tiles_a, sk, 0, smem);
+    } else {
+        const int id = (int)blockIdx.x - blocks_a, sk = id / tiles_b;
+        gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false>(pb, id - sk * tiles_b, sk, 0, smem);
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false>
 static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
@@ -566,6 +585,42 @@ static hipError_t launch_epi(const GemmParams& p, int groups, hipStream_t s) {
     const long tiles128 = (long)((p.M + 127) / 128) * (p.N / 128) * groups;
     if (p.N % 128 == 0 && tiles128 >= 512) return launch_cfg<128, 128, 2, 2, EPI, CONV>(p, groups, s);
     return launch_cfg<64, 64, 2, 2, EPI, CONV>(p, groups, s);
+}
+
+// Both problems in one launch when they resolve to the same 64x64 / 3-stage instantiation (the batch-1 configuration);
+// otherwise two launches on the same stream -- same results either way.
+template <int EPI>
+static hipError_t launch_pair_epi(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
+    GemmParams a = a_in, b = b_in;
+    a.group_m = b.group_m = 0;
+    const int ta = 8 * ((a.N / 64 + 7) / 8) * ((a.M + 63) / 64), tb = 8 * ((b.N / 64 + 7) / 8) * ((b.M + 63) / 64);
+    const int ba = ta * a.splitk, bb = tb * b.splitk;
+    constexpr size_t lds = 3 * (size_t)(64 + 64) * 128;
+    auto kern = gemm_glds_pair_kernel<64, 64, 2, 2, EPI, 3>;
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_pair_kernel<64,64,2,2,%d,3>", EPI);
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(256), lds, s, a, b, ba, ta, tb);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
+    auto plain = [](const GemmParams& p) {
+        return p.conv_F == 0 && (p.groups <= 1) && p.N % 64 == 0 && p.K % 64 == 0 && p.M > 0 && p.splitk >= 1 &&
+               (p.splitk == 1 || (p.epi == EPI_F32 && !p.accumulate && (p.K / 64) % p.splitk == 0));
+    };
+    const bool pairable = plain(a) && plain(b) && a.epi == b.epi && !use_v1() && pick_plain_cfg(a) == 4 && pick_plain_cfg(b) == 4 &&
+                          (g_tune_gemm_gm <= 0);
+    if (!pairable) {
+        const hipError_t e = launch_gemm(a, s);
+        return e != hipSuccess ? e : launch_gemm(b, s);
+    }
+    switch (a.epi) {
+        case EPI_BF16: return launch_pair_epi<EPI_BF16>(a, b, s);
+        case EPI_F32: return launch_pair_epi<EPI_F32>(a, b, s);
+        case EPI_QKV: return launch_pair_epi<EPI_QKV>(a, b, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {

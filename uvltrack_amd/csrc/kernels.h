@@ -32,6 +32,8 @@ struct GemmParams {
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+// two independent plain GEMMs; one launch when both resolve to the batch-1 instantiation, else two launches (same results)
+hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_t s);
 
 struct AttnParams {
     const bf16_t *q = nullptr, *k = nullptr, *vt = nullptr;   // [B,H,Npad,64], [B,H,Npad,64], [B,H,64,Npad]
@@ -40,6 +42,7 @@ struct AttnParams {
     int B = 0, H = 0, N = 0, Npad = 0;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+hipError_t launch_attention_pair(const AttnParams& a, const AttnParams& b, hipStream_t s);   // b (few keys) rides on a's configuration
 
 struct LnParams {
     const float* x = nullptr;                    // input rows, f32
@@ -65,6 +68,7 @@ struct LnParams {
     const int64_t* ct_flag = nullptr; const float* ct_logit_scale = nullptr; float* ct_logits = nullptr;
 };
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
+hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s);   // two independent problems, one launch
 
 // images -> bf16 patch rows [(b, z tokens..., x tokens...), 768] in (c,kh,kw) order (mae_vit.py:94-100)
 hipError_t launch_im2row(const float* z, const float* x, bf16_t* out, int B, int Hz, int Hx, hipStream_t s);

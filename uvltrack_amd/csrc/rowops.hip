@@ -14,9 +14,9 @@ namespace uvl {
 #define LN_MAX_SLABS 4
 
 template <int NV>
-__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
+__device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wave;
+    const int m = bx * 4 + wave;
     if (m >= p.M) return;
     const int b = m / p.rpb, t = m - b * p.rpb;
     const size_t xrow = (size_t)b * p.xbs + p.xro + t;
@@ -118,12 +118,33 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
     }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) { ln_body<NV>(p, blockIdx.x); }
+
+// Two independent LayerNorm problems in one launch (batch-1 frames pair every text-branch kernel with the visual kernel
+// of the same kind, see uvl_api.hip): workgroups [0, split) work on pa, the rest on pb.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
+    // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
+    if ((int)blockIdx.x < split) ln_body<NV>(pa, (int)blockIdx.x);
+    else ln_body<NV>(pb, (int)blockIdx.x - split);
+}
+
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
     if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0) return hipErrorInvalidValue;
     const int grid = (p.M + 3) / 4;
     if (p.D <= 256) hipLaunchKernelGGL(ln_kernel<1>, dim3(grid), dim3(256), 0, s, p);
     else if (p.D <= 768) hipLaunchKernelGGL(ln_kernel<3>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(ln_kernel<4>, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s) {
+    if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0) return hipErrorInvalidValue;
+    const int ga = (a.M + 3) / 4, gb = (b.M + 3) / 4;
+    if (a.D <= 256) hipLaunchKernelGGL(ln_pair_kernel<1>, dim3(ga + gb), dim3(256), 0, s, a, b, ga);
+    else if (a.D <= 768) hipLaunchKernelGGL(ln_pair_kernel<3>, dim3(ga + gb), dim3(256), 0, s, a, b, ga);
+    else hipLaunchKernelGGL(ln_pair_kernel<4>, dim3(ga + gb), dim3(256), 0, s, a, b, ga);
     return hipGetLastError();
 }
 

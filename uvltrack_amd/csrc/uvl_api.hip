@@ -87,6 +87,7 @@ struct uvl_model {
     // streams / events
     hipStream_t aux = nullptr, pf = nullptr;     // text-branch stream, weight-prefetch stream
     std::vector<hipEvent_t> ev_pf;
+    int pair_text = 1;                           // UVL_PAIR_TEXT=0: text branch on its own stream even for one sequence
     int fuse_contrast = 1;                       // UVL_FUSE_CONTRAST=0: stand-alone contrast kernels
     int prefetch = 0;                            // UVL_PREFETCH=1: measured -9 % FPS on MI355X (48 extra launches), off by default
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -136,6 +137,7 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
     for (auto& e : m->ev_pf) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     { const char* e = getenv("UVL_PREFETCH"); if (e) m->prefetch = atoi(e); }
     { const char* e = getenv("UVL_FUSE_CONTRAST"); if (e) m->fuse_contrast = atoi(e); }
+    { const char* e = getenv("UVL_PAIR_TEXT"); if (e) m->pair_text = atoi(e); }
     m->ev_bert.resize(c->depth);
     m->ev_cont.resize(c->depth);
     for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -521,8 +523,60 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     L.parts = parts;
     // eager full-frame runs fork the text branch onto the library's second stream and join with events; a partial walk
     // (graph capture of one part) launches on `s` only and leaves the cross-part ordering to uvl_graph_launch
-    const bool fork = !skip && !prof && m->nf > 0 && parts == PART_ALL;
+    // One sequence: every text-branch kernel rides in the SAME launch as the visual kernel of its kind (GEMM with GEMM,
+    // attention with attention, LayerNorm with LayerNorm -- the two layer structures line up op for op), so the 40-token branch
+    // costs neither launches nor a second queue; measured, the two-stream form slows each visual layer by ~11 us through
+    // contention and ends level with visual layer nf-1 (profiles/r01_summary.md).  Larger batches keep the second stream.
+    const bool paired = !skip && m->nf > 0 && m->pair_text && B == 1;
+    const bool fork = !skip && !prof && m->nf > 0 && parts == PART_ALL && !paired;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
+    enum { R_GEMM = 0, R_ATTN = 1, R_LN = 2 };
+    struct Rider { int kind; const char* what; double flops, bytes; GemmParams g; AttnParams a; LnParams l; };
+    std::vector<Rider> riders;                   // text-branch launches waiting for a visual launch of the same kind
+    size_t rider_at = 0;
+    struct GemmPair { GemmParams a, b; };
+    struct AttnPair { AttnParams a, b; };
+    struct LnPair { LnParams a, b; };
+    // launch a visual kernel; if the next waiting text kernel is of the same kind (and, for GEMMs, the same epilogue), take it along
+    auto run_gemm = [&](hipStream_t st, GemmParams& p, const char* what, bool is_text) {
+        const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K);
+        if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.g = p; riders.push_back(r); return; }
+        if (paired && rider_at < riders.size() && riders[rider_at].kind == R_GEMM && riders[rider_at].g.epi == p.epi) {
+            GemmPair gp{p, riders[rider_at].g};
+            const Rider& r = riders[rider_at++];
+            L.run(st, what, fl + r.flops, by + r.bytes, [](void* c, hipStream_t q) { auto* x = (GemmPair*)c; return launch_gemm_pair(x->a, x->b, q); }, &gp);
+            return;
+        }
+        L.run(st, what, fl, by, tramp<GemmParams, launch_gemm>, &p);
+    };
+    auto run_attn = [&](hipStream_t st, AttnParams& p, const char* what, double fl, double by, bool is_text) {
+        if (paired && is_text) { Rider r{}; r.kind = R_ATTN; r.what = what; r.flops = fl; r.bytes = by; r.a = p; riders.push_back(r); return; }
+        if (paired && rider_at < riders.size() && riders[rider_at].kind == R_ATTN) {
+            AttnPair ap{p, riders[rider_at].a};
+            const Rider& r = riders[rider_at++];
+            L.run(st, what, fl + r.flops, by + r.bytes, [](void* c, hipStream_t q) { auto* x = (AttnPair*)c; return launch_attention_pair(x->a, x->b, q); }, &ap);
+            return;
+        }
+        L.run(st, what, fl, by, tramp<AttnParams, launch_attention>, &p);
+    };
+    auto run_ln = [&](hipStream_t st, LnParams& p, double by, bool is_text) {
+        if (paired && is_text) { Rider r{}; r.kind = R_LN; r.what = "layernorm"; r.flops = 0; r.bytes = by; r.l = p; riders.push_back(r); return; }
+        if (paired && rider_at < riders.size() && riders[rider_at].kind == R_LN && riders[rider_at].l.D == p.D) {
+            LnPair lp{p, riders[rider_at].l};
+            const Rider& r = riders[rider_at++];
+            L.run(st, "layernorm", 0, by + r.bytes, [](void* c, hipStream_t q) { auto* x = (LnPair*)c; return launch_layernorm_pair(x->a, x->b, q); }, &lp);
+            return;
+        }
+        L.run(st, "layernorm", 0, by, tramp<LnParams, launch_layernorm>, &p);
+    };
+    auto flush_riders = [&](hipStream_t st) {    // whatever did not find a partner runs alone, in order
+        for (; rider_at < riders.size(); ++rider_at) {
+            Rider& r = riders[rider_at];
+            if (r.kind == R_GEMM) L.run(st, r.what, r.flops, r.bytes, tramp<GemmParams, launch_gemm>, &r.g);
+            else if (r.kind == R_ATTN) L.run(st, r.what, r.flops, r.bytes, tramp<AttnParams, launch_attention>, &r.a);
+            else L.run(st, r.what, 0, r.bytes, tramp<LnParams, launch_layernorm>, &r.l);
+        }
+    };
 
     // -- setup: masks, cls rows (visual part) / BERT additive mask (text part)
     struct SetupCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B, skip, what; } sc{m, in, w, B, skip, 1};
@@ -545,7 +599,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     auto consume = [](LnParams& p, Pending& pd) { p.part = pd.part; p.nsplit = pd.nsplit; p.part_rows = pd.rows; p.part_stride = pd.stride; pd = Pending(); };
     auto is_cont_layer = [&](int i) { bool c = false; for (int k = 0; k < m->cfg.n_cont; ++k) c |= (m->cfg.cont_layers[k] == i); return c; };
     auto residual_gemm = [&](hipStream_t st, const char* what, const bf16_t* A, int lda, const bf16_t* Wt, const float* bias, int Mr, int K,
-                             int rpb, int oro, float* slab, Pending& pd, bool allow_split) {
+                             int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false) {
         GemmParams p;
         p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
         const int sk = allow_split ? choose_splitk(Mr, D, K) : 1;
@@ -555,7 +609,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         } else {                  // x += A W^T + b in place
             p.C = w.X; p.accumulate = 1; p.rpb = rpb; p.obs = nj; p.oro = oro;
         }
-        RUN_GEMM(L, st, p, what);
+        run_gemm(st, p, what, is_text);
     };
     if (!skip) {
         struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
@@ -580,35 +634,35 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 GemmParams p;
                 p.A = w.Tn; p.lda = D; p.W = bw.wqkv; p.ldw = D; p.bias = bw.bqkv; p.M = Mt; p.N = 3 * D; p.K = D;
                 p.epi = 2; p.rpb = T; p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.H = H; p.Npad = 64; p.D = D;
-                RUN_GEMM(L, sa, p, "gemm.bert_qkv");
+                run_gemm(sa, p, "gemm.bert_qkv", true);
             }
             {
                 AttnParams p;
                 p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64;
-                L.run(sa, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, tramp<AttnParams, launch_attention>, &p);
+                run_attn(sa, p, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, true);
             }
-            residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, true);
+            residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, true, true);
             {
                 LnParams p;        // post-LN in place on the text rows
                 p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
                 consume(p, pend_t);
                 p.gamma = bw.ln1g; p.beta = bw.ln1b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
-                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
+                run_ln(sa, p, (double)Mt * D * 10, true);
             }
             {
                 GemmParams p;
                 p.A = w.Tn; p.lda = D; p.W = bw.wi; p.ldw = D; p.bias = bw.bi; p.M = Mt; p.N = Fn; p.K = D;
                 p.epi = 0; p.C = w.Th; p.ldc = Fn; p.act = 1;
-                RUN_GEMM(L, sa, p, "gemm.bert_i");
+                run_gemm(sa, p, "gemm.bert_i", true);
             }
-            residual_gemm(sa, "gemm.bert_o", w.Th, Fn, bw.wo, bw.bo, Mt, Fn, T, nv, w.PartT, pend_t, true);
+            residual_gemm(sa, "gemm.bert_o", w.Th, Fn, bw.wo, bw.bo, Mt, Fn, T, nv, w.PartT, pend_t, true, true);
             {
                 LnParams p;
                 p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
                 consume(p, pend_t);
                 p.gamma = bw.ln2g; p.beta = bw.ln2b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
                 if (is_cont_layer(i) && out->d_logits) p.y_copy = w.TxtSnap + (size_t)i * Mt * D;   // this layer's text rows for the logits
-                L.run(sa, "layernorm", 0, (double)Mt * D * 10, tramp<LnParams, launch_layernorm>, &p);
+                run_ln(sa, p, (double)Mt * D * 10, true);
             }
             if (fork && is_cont_layer(i) && out->d_logits) {
                 if (hipEventRecord(m->ev_bert[i], sa) != hipSuccess) text_err = fail(UVL_EHIP, "bert event failed");
@@ -617,6 +671,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         L.cur = saved_part;
     };
     if (last_bert < 0 && fork && hipEventRecord(m->ev_join, sa) != hipSuccess) return fail(UVL_EHIP, "join record failed");
+    if (paired) {                                // parameters of the whole text branch, in order; launched as riders below
+        for (int i = 0; i <= last_bert; ++i) text_layer(i);
+        if (text_err) return text_err;
+    }
     // -- patch embed (mae_vit.py:203-215)
     struct ImCtx { const uvl_inputs* in; Workspace w; int B, hz, hx; } ic{in, w, B, m->cfg.template_size, m->cfg.search_size};
     L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
@@ -638,6 +696,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         const VitBlockW& vw = m->vit[i];
         const bool last = (i == m->depth - 1) || (m->debug_stop_layer == i);
         if (joint && i == m->nf) {               // first fusion layer reads the text rows
+            if (paired) flush_riders(s);         // the text branch's last LayerNorm has no visual partner before this point
             if (!skip) L.cur = PART_V2;
             if (fork && hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
         }
@@ -659,18 +718,18 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             if (joint) { p.pre_add0 = m->modal; p.pre_add1 = m->modal + D; p.split = nv; }     // forward_joint, mae_vit.py:196
             p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
             if (fused_ct >= 0) p.x_snap = w.XSnap;   // this fold completes layer `fused_ct`: keep its output for the logits
-            L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
+            run_ln(s, p, (double)M * D * 6, false);
         }
         {
             GemmParams p;
             p.A = w.Xn; p.lda = D; p.W = vw.wqkv; p.ldw = D; p.bias = vw.bqkv; p.M = M; p.N = 3 * D; p.K = D;
             p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D;
-            RUN_GEMM(L, s, p, "gemm.qkv");
+            run_gemm(s, p, "gemm.qkv", false);
         }
         {
             AttnParams p;
             p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad;
-            L.run(s, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, tramp<AttnParams, launch_attention>, &p);
+            run_attn(s, p, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, false);
         }
         residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true);
         {
@@ -689,16 +748,16 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 }
                 fused_ct = -1;
             }
-            L.run(s, "layernorm", 0, (double)M * D * 6, tramp<LnParams, launch_layernorm>, &p);
+            run_ln(s, p, (double)M * D * 6, false);
         }
         {
             GemmParams p;
             p.A = w.Xn; p.lda = D; p.W = vw.wfc1; p.ldw = D; p.bias = vw.bfc1; p.M = M; p.N = Fn; p.K = D;
             p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
-            RUN_GEMM(L, s, p, "gemm.fc1");
+            run_gemm(s, p, "gemm.fc1", false);
         }
         residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last);
-        if (i <= last_bert) { text_layer(i); if (text_err) return text_err; }
+        if (i <= last_bert && !paired) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
         if (is_cont_layer(i)) {
             if (out->d_logits && last && joint && i == m->depth - 1 && m->fuse_contrast && m->debug_stop_layer < 0) {
@@ -731,6 +790,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     if (m->nf >= m->depth && fork && m->debug_stop_layer < 0) {   // no fusion layer at all: still join the text branch
         if (hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
     }
+    if (paired) flush_riders(s);
     if (pend_v.nsplit || pend_t.nsplit) return fail(UVL_ESTATE, "internal: split-K slabs left unconsumed");
     if (fused_ct >= 0) return fail(UVL_ESTATE, "internal: fused contrast job left unlaunched");
 
@@ -875,7 +935,8 @@ extern "C" int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl
     graph_free(m);
     if (!m->cap_stream) HIPCHK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     HIPCHK(hipDeviceSynchronize());
-    const bool text = !in->skip_text && m->nf >= 0;
+    // one sequence with paired text kernels is a single-stream frame: one graph, like the no-text case
+    const bool text = !in->skip_text && m->nf >= 0 && !(m->pair_text && in->batch == 1 && m->nf > 0);
     const int part_of[3] = {PART_TEXT, PART_V1, PART_V2};
     for (int k = 0; k < 3; ++k) {
         if (!text && k != 1) continue;
