@@ -638,6 +638,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
             return hipErrorInvalidValue;
         }
         if (p.epi != EPI_BF16) return hipErrorInvalidValue;
+        if (!use_v1() && p.N % 32 == 0) return launch_glds<128, 32, 4, 1, EPI_BF16, 3, true>(p, s);   // last tower layer: 32 channels
         return launch_epi<EPI_BF16, true>(p, groups, s);
     }
     switch (p.epi) {

@@ -589,10 +589,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(sa, m->ev_fork, 0) != hipSuccess) return fail(UVL_EHIP, "fork failed");
     }
     L.cur = PART_V1;
+    if (paired) sc.what = 3;                     // single-stream frame: visual and text set-up in one launch
     L.run(s, "setup", 0, 0, setup_fn, &sc);
     SetupCtx sct = sc;
     sct.what = 2;
-    if (!skip) { L.cur = PART_TEXT; L.run(sa, "setup", 0, 0, setup_fn, &sct); L.cur = PART_V1; }
+    if (!skip && !paired) { L.cur = PART_TEXT; L.run(sa, "setup", 0, 0, setup_fn, &sct); L.cur = PART_V1; }
     // -- text branch (extractor.py:54,62): embedding + the first nf BERT layers depend on the text only, so the whole
     //    chain is enqueued up front on its own stream; layers whose output the contrastive logits need leave a snapshot
     Pending pend_t;
