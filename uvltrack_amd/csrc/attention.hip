@@ -409,7 +409,8 @@ static int pick_attn_cfg(const AttnParams& p) {
         const long wg4 = (long)((p.N + 127) / 128) * p.H * p.B;
         const long wg1 = (long)((p.N + 31) / 32) * p.H * p.B;
         const int nt = (p.N + 63) / 64;
-        if (wg4 >= 256 || nt < 2) cfg = 0;
+        if (wg4 >= 256 && nt >= 11) cfg = 3;         // long sequences (UVLTrack-L): a third ring stage pays (+4..8 %)
+        else if (wg4 >= 256 || nt < 2) cfg = 0;
         else if (wg1 <= 288 && nt >= 5 && nt <= 6) cfg = 5;
         else if (wg1 <= 288 && nt >= 7 && nt <= 9) cfg = 6;
         else cfg = 1;
