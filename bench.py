@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--mode", default="NLBBOX", choices=["BBOX", "NL", "NLBBOX"])
     ap.add_argument("--skip-text", action="store_true", help="BBOX mode only: do not run the text branch (configs[1])")
     ap.add_argument("--launch", default="eager", choices=["eager", "graph"],
-                    help="eager: the frame's ~150 kernels are launched on two HIP streams each step (fastest on ROCm 7.2, where "
+                    help="eager: the frame's ~100-150 kernels are launched each step (one stream for one sequence, two for several) (fastest on ROCm 7.2, where "
                          "hipGraphLaunch costs more host time per node than a plain launch); graph: hipGraph replay")
     ap.add_argument("--no-graph", action="store_true", help="alias of --launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,7 +217,7 @@ def main():
             "config": {"workload": "UVLTrack-%s z%d/x%d/T%d %s%s, %d sequence(s)/GPU, batch shards + RCCL all-gather of boxes" % (
                 args.model, spec.template_size, spec.search_size, spec.text_len, args.mode, " (text branch skipped)" if skip_text else "", B),
                 "per_gpu_batch": B, "global_batch": B * world, "tokens_visual": spec.nv, "tokens_joint": spec.nj,
-                "gflop_per_frame": flops_frame / 1e9, "launch": "hipgraph" if use_graph else "eager-2-streams", "parallelism": "dp%d" % world},
+                "gflop_per_frame": flops_frame / 1e9, "launch": "hipgraph" if use_graph else ("eager-1-stream" if (B == 1 and not skip_text and os.environ.get("UVL_PAIR_TEXT", "1") != "0") or skip_text else "eager-2-streams"), "parallelism": "dp%d" % world},
             "frame_model_tflops": flops_frame * fps / 1e12,
             "frame_mfma_frac": flops_frame * fps / 1e12 / (PEAK_BF16_TFLOPS * world),
             "frame_hbm_frac": (weight_bytes * (args.steps / elapsed)) / 1e9 / PEAK_HBM_GBS,
