@@ -70,6 +70,18 @@ struct LnParams {
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
 hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s);   // two independent problems, one launch
 
+// set-up + BERT embedding + im2row of a single-stream frame in one launch (rowops.hip::prologue_kernel)
+struct PrologueParams {
+    const uint8_t* text_mask = nullptr; const int64_t* flag = nullptr; const float* cls_token = nullptr;
+    float* x = nullptr; float* key_add = nullptr; float* bert_add = nullptr;
+    int nz = 0, nv = 0, nj = 0, npad = 0, T = 0, D = 0, B = 0;
+    const int64_t* ids = nullptr; const float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    bf16_t* tn = nullptr; int vocab = 0;
+    const float *z = nullptr, *ximg = nullptr; bf16_t* patches = nullptr; int Hz = 0, Hx = 0;
+    int n_setup = 0, n_embed = 0;                // filled by the launcher
+};
+hipError_t launch_prologue(const PrologueParams& p, hipStream_t s);
+
 // images -> bf16 patch rows [(b, z tokens..., x tokens...), 768] in (c,kh,kw) order (mae_vit.py:94-100)
 hipError_t launch_im2row(const float* z, const float* x, bf16_t* out, int B, int Hz, int Hx, hipStream_t s);
 

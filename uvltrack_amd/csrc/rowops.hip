@@ -152,10 +152,10 @@ hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream
 // im2row for PatchEmbed (mae_vit.py:94-100): Conv2d(3, D, k16, s16) == GEMM over (c,kh,kw) patch vectors.
 // One thread moves one 16-pixel patch line: 64 B of f32 in, 32 B of bf16 out.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void im2row_kernel(const float* __restrict__ z, const float* __restrict__ x,
-                                                     bf16_t* __restrict__ out, int B, int Hz, int Hx) {
+__device__ __forceinline__ void im2row_body(const float* __restrict__ z, const float* __restrict__ x,
+                                            bf16_t* __restrict__ out, int B, int Hz, int Hx, int bx) {
     const int gz = Hz / 16, gx = Hx / 16, nz = gz * gz, nx = gx * gx, per = nz + nx;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gid = (long)bx * 256 + threadIdx.x;
     const long total = (long)B * per * 48;
     if (gid >= total) return;
     const int line = gid % 48;                  // c*16 + kh
@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256) void im2row_kernel(const float* __restrict__ z
     dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+__global__ __launch_bounds__(256) void im2row_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                                                     bf16_t* __restrict__ out, int B, int Hz, int Hx) {
+    im2row_body(z, x, out, B, Hz, Hx, blockIdx.x);
+}
+
 hipError_t launch_im2row(const float* z, const float* x, bf16_t* out, int B, int Hz, int Hx, hipStream_t s) {
     const long total = (long)B * ((Hz / 16) * (Hz / 16) + (Hx / 16) * (Hx / 16)) * 48;
     hipLaunchKernelGGL(im2row_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, x, out, B, Hz, Hx);
@@ -193,13 +198,13 @@ hipError_t launch_im2row(const float* z, const float* x, bf16_t* out, int B, int
 // (bert_backbone.py:260-274).  Writes the f32 residual row and the bf16 GEMM operand.
 // ------------------------------------------------------------------------------------------------
 template <int NV>
-__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
-                                                         const float* __restrict__ pos, const float* __restrict__ type0,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ x, int xbs, int xro, bf16_t* __restrict__ y,
-                                                         int B, int T, int D, int vocab) {
+__device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                const float* __restrict__ pos, const float* __restrict__ type0,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                float* __restrict__ x, int xbs, int xro, bf16_t* __restrict__ y,
+                                                int B, int T, int D, int vocab, int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wave;
+    const int m = bx * 4 + wave;
     if (m >= B * T) return;
     const int b = m / T, t = m - b * T;
     long id = ids[m];
@@ -253,6 +258,15 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
     }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                         const float* __restrict__ pos, const float* __restrict__ type0,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ x, int xbs, int xro, bf16_t* __restrict__ y,
+                                                         int B, int T, int D, int vocab) {
+    bert_embed_body<NV>(ids, word, pos, type0, gamma, beta, x, xbs, xro, y, B, T, D, vocab, blockIdx.x);
+}
+
 hipError_t launch_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0,
                              const float* gamma, const float* beta, float* x, int xbs, int xro, bf16_t* y_bf16,
                              int B, int T, int D, int vocab, hipStream_t s) {
@@ -270,11 +284,10 @@ hipError_t launch_bert_embed(const int64_t* ids, const float* word, const float*
 //   key i: 0 = cls, [1,1+nz) template, [1+nz,nv) search, [nv,nj) text
 //   flag==1 masks cls+template; search never; text where mask==0 or flag==0
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ tmask, const int64_t* __restrict__ flag,
-                                                    const float* __restrict__ cls_token, float* __restrict__ x,
-                                                    float* __restrict__ key_add, float* __restrict__ bert_add,
-                                                    int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void setup_body(const uint8_t* __restrict__ tmask, const int64_t* __restrict__ flag,
+                                           const float* __restrict__ cls_token, float* __restrict__ x,
+                                           float* __restrict__ key_add, float* __restrict__ bert_add,
+                                           int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what, int b) {
     const int fl = (int)flag[b];
     if (what & 2) {
         for (int t = threadIdx.x; t < 64; t += 256)
@@ -290,6 +303,41 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ 
         key_add[(size_t)b * npad + i] = a;
     }
     for (int c = threadIdx.x; c < D; c += 256) x[(size_t)b * nj * D + c] = cls_token[c];
+}
+
+__global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ tmask, const int64_t* __restrict__ flag,
+                                                    const float* __restrict__ cls_token, float* __restrict__ x,
+                                                    float* __restrict__ key_add, float* __restrict__ bert_add,
+                                                    int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what) {
+    setup_body(tmask, flag, cls_token, x, key_add, bert_add, nz, nv, nj, npad, T, D, skip_text, what, blockIdx.x);
+}
+
+// The three input-side kernels of a frame in one launch (single-stream frames): workgroups [0, n_setup) build the masks and
+// the cls rows, the next n_embed do the BERT embedding + LayerNorm, the rest gather the image patches.
+template <int NV>
+__global__ __launch_bounds__(256) void prologue_kernel(const PrologueParams p) {
+    const int bx = blockIdx.x;
+    if (bx < p.n_setup) {
+        setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, 0, 3, bx);
+    } else if (bx < p.n_setup + p.n_embed) {
+        bert_embed_body<NV>(p.ids, p.word, p.pos, p.type0, p.emb_g, p.emb_b, p.x, p.nj, p.nv, p.tn, p.B, p.T, p.D, p.vocab, bx - p.n_setup);
+    } else {
+        im2row_body(p.z, p.ximg, p.patches, p.B, p.Hz, p.Hx, bx - p.n_setup - p.n_embed);
+    }
+}
+
+hipError_t launch_prologue(const PrologueParams& q, hipStream_t s) {
+    PrologueParams p = q;
+    if (p.D % 4 != 0 || p.D > 1024) return hipErrorInvalidValue;
+    const long total = (long)p.B * ((p.Hz / 16) * (p.Hz / 16) + (p.Hx / 16) * (p.Hx / 16)) * 48;
+    p.n_setup = p.B;
+    p.n_embed = (p.B * p.T + 3) / 4;
+    const int n_im = (int)((total + 255) / 256);
+    const dim3 grid(p.n_setup + p.n_embed + n_im);
+    if (p.D <= 256) hipLaunchKernelGGL(prologue_kernel<1>, grid, dim3(256), 0, s, p);
+    else if (p.D <= 768) hipLaunchKernelGGL(prologue_kernel<3>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(prologue_kernel<4>, grid, dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_setup(const uint8_t* text_mask, const int64_t* flag, const float* cls_token, float* x,

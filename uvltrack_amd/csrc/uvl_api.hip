@@ -589,7 +589,15 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(sa, m->ev_fork, 0) != hipSuccess) return fail(UVL_EHIP, "fork failed");
     }
     L.cur = PART_V1;
-    if (paired) sc.what = 3;                     // single-stream frame: visual and text set-up in one launch
+    PrologueParams pro;
+    if (paired) {                                // single-stream frame: set-up, BERT embedding and im2row in ONE launch
+        pro.text_mask = in->d_text_mask; pro.flag = in->d_flag; pro.cls_token = m->cls_token; pro.x = w.X; pro.key_add = w.key_add;
+        pro.bert_add = w.bert_add; pro.nz = nz; pro.nv = nv; pro.nj = nj; pro.npad = npad; pro.T = T; pro.D = D; pro.B = B;
+        pro.ids = in->d_text_ids; pro.word = m->word; pro.pos = m->pos; pro.type0 = m->type0; pro.emb_g = m->emb_g; pro.emb_b = m->emb_b;
+        pro.tn = w.Tn; pro.vocab = m->cfg.vocab;
+        pro.z = in->d_template; pro.ximg = in->d_search; pro.patches = w.P; pro.Hz = m->cfg.template_size; pro.Hx = m->cfg.search_size;
+        L.run(s, "prologue", 0, 0, tramp<PrologueParams, launch_prologue>, &pro);
+    } else
     L.run(s, "setup", 0, 0, setup_fn, &sc);
     SetupCtx sct = sc;
     sct.what = 2;
@@ -612,7 +620,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         }
         run_gemm(st, p, what, is_text);
     };
-    if (!skip) {
+    if (!skip && !paired) {
         struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
         L.cur = PART_TEXT;
         L.run(sa, "bert_embed", 0, 0, [](void* c, hipStream_t st) {
@@ -678,7 +686,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     }
     // -- patch embed (mae_vit.py:203-215)
     struct ImCtx { const uvl_inputs* in; Workspace w; int B, hz, hx; } ic{in, w, B, m->cfg.template_size, m->cfg.search_size};
-    L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
+    if (!paired) L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
     {
         GemmParams p;
         p.A = w.P; p.lda = 768; p.W = m->w_patch; p.ldw = 768; p.bias = m->b_patch;
