@@ -531,7 +531,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     const bool fork = !skip && !prof && m->nf > 0 && parts == PART_ALL && !paired;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
     enum { R_GEMM = 0, R_ATTN = 1, R_LN = 2 };
-    struct Rider { int kind; const char* what; double flops, bytes; GemmParams g; AttnParams a; LnParams l; };
+    struct Rider { int kind; const char* what; double flops, bytes; GemmParams g; AttnParams a; LnParams l; int layer; };
+    int rider_layer = 0;                         // BERT layer whose launches are being queued
     std::vector<Rider> riders;                   // text-branch launches waiting for a visual launch of the same kind
     size_t rider_at = 0;
     struct GemmPair { GemmParams a, b; };
@@ -540,7 +541,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // launch a visual kernel; if the next waiting text kernel is of the same kind (and, for GEMMs, the same epilogue), take it along
     auto run_gemm = [&](hipStream_t st, GemmParams& p, const char* what, bool is_text) {
         const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K);
-        if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.g = p; riders.push_back(r); return; }
+        if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.g = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_GEMM && riders[rider_at].g.epi == p.epi) {
             GemmPair gp{p, riders[rider_at].g};
             const Rider& r = riders[rider_at++];
@@ -550,7 +551,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         L.run(st, what, fl, by, tramp<GemmParams, launch_gemm>, &p);
     };
     auto run_attn = [&](hipStream_t st, AttnParams& p, const char* what, double fl, double by, bool is_text) {
-        if (paired && is_text) { Rider r{}; r.kind = R_ATTN; r.what = what; r.flops = fl; r.bytes = by; r.a = p; riders.push_back(r); return; }
+        if (paired && is_text) { Rider r{}; r.kind = R_ATTN; r.what = what; r.flops = fl; r.bytes = by; r.a = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_ATTN) {
             AttnPair ap{p, riders[rider_at].a};
             const Rider& r = riders[rider_at++];
@@ -560,7 +561,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         L.run(st, what, fl, by, tramp<AttnParams, launch_attention>, &p);
     };
     auto run_ln = [&](hipStream_t st, LnParams& p, double by, bool is_text) {
-        if (paired && is_text) { Rider r{}; r.kind = R_LN; r.what = "layernorm"; r.flops = 0; r.bytes = by; r.l = p; riders.push_back(r); return; }
+        if (paired && is_text) { Rider r{}; r.kind = R_LN; r.what = "layernorm"; r.flops = 0; r.bytes = by; r.l = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_LN && riders[rider_at].l.D == p.D) {
             LnPair lp{p, riders[rider_at].l};
             const Rider& r = riders[rider_at++];
@@ -569,8 +570,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         }
         L.run(st, "layernorm", 0, by, tramp<LnParams, launch_layernorm>, &p);
     };
-    auto flush_riders = [&](hipStream_t st) {    // whatever did not find a partner runs alone, in order
-        for (; rider_at < riders.size(); ++rider_at) {
+    auto flush_riders = [&](hipStream_t st, int upto_layer = 1 << 30) {    // whatever did not find a partner runs alone, in order
+        for (; rider_at < riders.size() && riders[rider_at].layer <= upto_layer; ++rider_at) {
             Rider& r = riders[rider_at];
             if (r.kind == R_GEMM) L.run(st, r.what, r.flops, r.bytes, tramp<GemmParams, launch_gemm>, &r.g);
             else if (r.kind == R_ATTN) L.run(st, r.what, r.flops, r.bytes, tramp<AttnParams, launch_attention>, &r.a);
@@ -681,7 +682,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     };
     if (last_bert < 0 && fork && hipEventRecord(m->ev_join, sa) != hipSuccess) return fail(UVL_EHIP, "join record failed");
     if (paired) {                                // parameters of the whole text branch, in order; launched as riders below
-        for (int i = 0; i <= last_bert; ++i) text_layer(i);
+        for (int i = 0; i <= last_bert; ++i) { rider_layer = i; text_layer(i); }
         if (text_err) return text_err;
     }
     // -- patch embed (mae_vit.py:203-215)
@@ -777,6 +778,9 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 fused_ct = i;
                 fused_slot = cont_slot;
             } else if (out->d_logits) {
+                // a stand-alone contrast kernel of a pre-fusion layer reads that BERT layer's snapshot: its last LayerNorm may
+                // still be waiting for a partner
+                if (paired && !joint) flush_riders(s, i);
                 ContrastParams p;
                 if (!skip) L.cur = PART_V2;    // first consumer of text data on the visual side: everything from here is part V2
                 if (!joint && !skip) {   // text token of THIS layer comes from the text branch's snapshot
