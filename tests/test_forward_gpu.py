@@ -127,9 +127,12 @@ def test_forward_matches_oracle_per_sample_batch1(name):
         assert ok, "%s sample %d\n%s" % (name, b, fmt_report(rep))
 
 
-def test_graph_replay_equals_eager():
+@pytest.mark.parametrize("batch", [None, 1])
+def test_graph_replay_equals_eager(batch):
     meta, spec, ref = load_case("tiny_mixed")
     inp = rebuild_inputs(meta, spec)
+    if batch is not None:                      # one sequence: single-stream frame, one graph
+        inp = {k: v[:batch].copy() for k, v in inp.items()}
     eng = _engine(meta, spec)
     eager = _run(eng, inp)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -146,10 +149,14 @@ def test_graph_replay_equals_eager():
     assert np.abs(outs["bbox_map"].cpu().numpy() - eager["bbox_map"]).max() > 1e-4
 
 
-def test_skip_text_is_exact_for_box_outputs():
-    """BBOX-only mode may drop the text branch: every box output is bit-identical."""
-    meta, spec, _ = load_case("tiny_mixed")
+@pytest.mark.parametrize("name,batch", [("tiny_mixed", None), ("tiny_mixed", 1), ("tiny_switches", 1), ("b_z128_x256", 1)])
+def test_skip_text_is_exact_for_box_outputs(name, batch):
+    """BBOX-only mode may drop the text branch: every box output is bit-identical -- also for one sequence,
+    where the full frame runs the paired kernels and the text-less frame the plain ones."""
+    meta, spec, _ = load_case(name)
     inp = rebuild_inputs(meta, spec)
+    if batch is not None:
+        inp = {k: v[:batch].copy() for k, v in inp.items()}
     inp["flag"][:] = 0
     eng = _engine(meta, spec)
     full = _run(eng, inp)
