@@ -17,7 +17,7 @@ namespace uvl {
 template <int NV>
 __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = bx * 4 + wave;
+    const int m = bx * (int)(blockDim.x >> 6) + wave;     // one row per wave, blockDim.x / 64 rows per workgroup
     if (m >= p.M) return;
     const int b = m / p.rpb, t = m - b * p.rpb;
     const size_t xrow = (size_t)b * p.xbs + p.xro + t;
@@ -131,13 +131,13 @@ __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const L
     else ln_body<NV>(pb, (int)blockIdx.x - split);
 }
 
-// Rows (= waves) per workgroup.  One: 64-thread workgroups keep many more row loads in flight per CU than 256-thread ones
-// (measured: +3 % frames/s for one sequence, +11 % at 32 sequences, where the kernel streams ~135 MB).  UVL_LN_WPB overrides.
+// Rows (= waves) per workgroup: 4.  One or two rows per workgroup measure the same within noise (1114 / 1119-1125 / 1122-1131
+// frames/s for 4 / 1 / 2 at one sequence, identical at 32); UVL_LN_WPB = 1 | 2 | 4 overrides for experiments.
 static int ln_waves_per_block(int) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("UVL_LN_WPB"); forced = e ? atoi(e) : 0; }
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return 1;
+    return 4;
 }
 
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
