@@ -164,7 +164,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    finite = bool(torch.isfinite(outs["bbox_map"]).all().item())
+    finite = bool(torch.isfinite(outs["bbox_map"]).all().item()) and bool(torch.isfinite(outs["logits"]).all().item())
+    if not finite:
+        raise SystemExit("bench.py: the forward pass produced non-finite outputs -- timing of a broken path is not reported")
 
     if rank == 0:
         frames = world * B * args.steps
