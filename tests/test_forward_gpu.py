@@ -195,3 +195,32 @@ def test_repeated_frames_are_bit_identical(name, batch):
             continue
         for k in keys:
             assert torch.equal(cur[k], ref[k]), k
+
+
+@pytest.mark.parametrize("name,batch", [("b_z128_x256", 16), ("b_z256_x256", 8), ("l_z128_x384", 8)])
+def test_large_batch_matches_single_sequence_runs(name, batch):
+    """The batched regime takes other kernels than the fixtures' 2-3 samples (grouped tile order, 64x128 / 128x128 tiles,
+    128x128 implicit-GEMM conv tiles, 128-query attention workgroups with 2 or 3 ring stages): a batch of 8-16 sequences with
+    mixed flags must reproduce the one-sequence runs (themselves checked against the reference) sample by sample."""
+    from uvltrack_amd import weightgen as wg
+    from uvltrack_amd.engine import HipEngine
+    meta, spec, _ = load_case(name)
+    _engines.clear()
+    eng = HipEngine(spec, torch.device("cuda:0"), max_batch=batch)
+    eng.load_state_dict(rebuild_weights(meta, spec, include_unused=True))
+    inp = wg.make_inputs(spec, batch=batch, seed=77, flags=[(i * 7) % 3 for i in range(batch)])
+    inp["mask"][1, :] = False                      # one all-padding text
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    big = eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
+    big = {k: v.cpu().numpy() for k, v in big.items() if torch.is_tensor(v)}
+    scale = max(1.0, spec.depth / 12.0)
+    for b in range(batch):
+        one = eng.forward(*[t(inp[k][b:b + 1]) for k in ("template", "search", "ids", "mask", "prompt", "flag")])
+        one = {k: v.cpu().numpy() for k, v in one.items() if torch.is_tensor(v)}
+        for k, tol in (("bbox_map", 1e-2), ("cls_score_test", 1e-2), ("cont_score", 5e-2), ("logits", 0.15)):
+            err = np.abs(big[k][b:b + 1] - one[k]).max()
+            assert np.isfinite(big[k]).all() and err <= tol * scale, "%s sample %d: %g" % (k, b, err)
+        for k in ("search", "template", "text"):
+            err = np.abs(big[k][b:b + 1] - one[k]).max()
+            assert err <= 0.03 * scale * np.abs(one[k]).max(), "%s sample %d: %g" % (k, b, err)
+    eng.close()
