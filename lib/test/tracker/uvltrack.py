@@ -48,6 +48,7 @@ class UVLTrack(BaseTracker):
         self.max_score = 0
         self.max_query_len = self.cfg.MODEL.BACKBONE.LANGUAGE.BERT.MAX_QUERY_LEN
         self._uploader = None
+        self._meta_host = None
 
     # ------------------------------------------------------------------ helpers
     def _tok(self):
@@ -160,9 +161,14 @@ class UVLTrack(BaseTracker):
         with torch.no_grad():
             out_dict = self.network.forward_test(self.template, search, self.text, self.prompt, self.flag)
             # argmax of cls * hann * softmax(cont)[0], box back to the frame, clip (tracker:116-125): one kernel, one read-back
-            st = torch.tensor([self.state], dtype=torch.float32)
-            new_state, score, box_net, idx = self.network.decode(out_dict, self._window_dev, st, torch.tensor([resize_factor], dtype=torch.float32),
-                                                                 torch.tensor([[float(H), float(W)]]), margin=10.0, has_cont=self.has_cont)
+            # previous state, resize factor and frame size travel in ONE 7-float upload from pinned memory
+            if self._meta_host is None:
+                self._meta_host = torch.empty(7, dtype=torch.float32).pin_memory()
+            self._meta_host[:4] = torch.tensor(self.state, dtype=torch.float32)
+            self._meta_host[4], self._meta_host[5], self._meta_host[6] = float(resize_factor), float(H), float(W)
+            meta = self._meta_host.to(self.device, non_blocking=True)
+            new_state, score, box_net, idx = self.network.decode(out_dict, self._window_dev, meta[:4].reshape(1, 4), meta[4:5], meta[5:7].reshape(1, 2),
+                                                                 margin=10.0, has_cont=self.has_cont)
             host = torch.cat([new_state.reshape(-1), score.reshape(-1), box_net.reshape(-1)]).cpu()
         self.state = [float(v) for v in host[:4]]
         score = float(host[4])
