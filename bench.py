@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--search-size", type=int, default=None)
     ap.add_argument("--mode", default="NLBBOX", choices=["BBOX", "NL", "NLBBOX"])
     ap.add_argument("--skip-text", action="store_true", help="BBOX mode only: do not run the text branch (configs[1])")
+    ap.add_argument("--reuse-text", action="store_true", help="NOT the headline: frames after the first take the text branch (BERT embedding + "
+                    "pre-fusion layers) from the workspace, as the tracker does for a fixed sentence (uvl_inputs.reuse_text); eager launch only")
     ap.add_argument("--launch", default="eager", choices=["eager", "graph"],
                     help="eager: the frame's ~100-150 kernels are launched each step (one stream for one sequence, two for several) (fastest on ROCm 7.2, where "
                          "hipGraphLaunch costs more host time per node than a plain launch); graph: hipGraph replay")
@@ -113,6 +115,7 @@ def main():
     flag_val = {"BBOX": 0, "NL": 1, "NLBBOX": 2}[args.mode]
     flags = [flag_val] * B
     skip_text = bool(args.skip_text and args.mode == "BBOX")
+    reuse_text = bool(args.reuse_text and not skip_text)
 
     eng = HipEngine(spec, dev, max_batch=max(B, 1))
     eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
@@ -124,7 +127,7 @@ def main():
     use_graph = args.launch == "graph" and not args.no_graph
     if not use_graph:
         outs = eng.alloc_outputs(B)
-        step_fn = eng.make_eager_step(*targs, skip_text=skip_text, outs=outs)
+        step_fn = eng.make_eager_step(*targs, skip_text=skip_text, outs=outs, reuse_text=reuse_text)
     else:
         _, outs = eng.capture(*targs, skip_text=skip_text)
         step_fn = eng.replay
@@ -172,7 +175,9 @@ def main():
         frames = world * B * args.steps
         fps = frames / elapsed
         # ---- roofline of the dominant kernel: HIP events around every launch, on the launching stream ----
-        eng.forward(*targs, skip_text=skip_text, profile=True)
+        if reuse_text:
+            eng.forward(*targs)                       # leaves the text rows the profiled frame reuses
+        eng.forward(*targs, skip_text=skip_text, profile=True, reuse_text=reuse_text)
         prof = eng.profile_entries()
         # A HIP event pair around a launch also times the dispatch of that launch.  One-sequence frames are a single stream of
         # back-to-back kernels, so the bracketing cost per launch is known exactly on average:
@@ -208,7 +213,7 @@ def main():
                     "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                     "traffic": traffic}
-        flops_frame = spec.flops_per_frame(skip_text=skip_text)
+        flops_frame = spec.flops_per_frame(skip_text=skip_text, reuse_text=reuse_text)
         weight_bytes = 2.0 * sum(int(np.prod(s)) for n, s in __import__("uvltrack_amd.spec", fromlist=["x"]).state_dict_schema(spec, False).items()
                                  if len(s) >= 2 and "embeddings" not in n and "pos_embed" not in n)
         line = {
@@ -217,9 +222,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "UVLTrack-%s z%d/x%d/T%d %s%s, %d sequence(s)/GPU, batch shards + RCCL all-gather of boxes" % (
-                args.model, spec.template_size, spec.search_size, spec.text_len, args.mode, " (text branch skipped)" if skip_text else "", B),
+                args.model, spec.template_size, spec.search_size, spec.text_len, args.mode, " (text branch skipped)" if skip_text else (" (text branch reused from the first frame)" if reuse_text else ""), B),
                 "per_gpu_batch": B, "global_batch": B * world, "tokens_visual": spec.nv, "tokens_joint": spec.nj,
-                "gflop_per_frame": flops_frame / 1e9, "launch": "hipgraph" if use_graph else ("eager-1-stream" if (B == 1 and not skip_text and os.environ.get("UVL_PAIR_TEXT", "1") != "0") or skip_text else "eager-2-streams"), "parallelism": "dp%d" % world},
+                "gflop_per_frame": flops_frame / 1e9, "launch": "hipgraph" if use_graph else ("eager-1-stream" if (B == 1 and not skip_text and os.environ.get("UVL_PAIR_TEXT", "1") != "0") or skip_text or reuse_text else "eager-2-streams"), "parallelism": "dp%d" % world},
             "frame_model_tflops": flops_frame * fps / 1e12,
             "frame_mfma_frac": flops_frame * fps / 1e12 / (PEAK_BF16_TFLOPS * world),
             "frame_hbm_frac": (weight_bytes * (args.steps / elapsed)) / 1e9 / PEAK_HBM_GBS,

@@ -69,6 +69,11 @@ typedef struct uvl_inputs {
     const int64_t* d_flag;       /* [B] i64 in {0 BBOX, 1 NL, 2 NLBBOX} */
     int32_t skip_text;           /* 1: all flags are 0 and the caller does not need `text`/`txt_token`:
                                     run the visual stream only (exact for every box output) */
+    int32_t reuse_text;          /* 1: d_text_ids / d_text_mask are the ones of the last call that ran with reuse_text = 0 on this
+                                    workspace at this batch size: the text branch below the first fusion layer (BERT embedding +
+                                    layers, extractor.py:54,62) is a function of the text alone, so its rows are taken from the
+                                    workspace instead of being recomputed (bit-identical outputs).  Not a reference feature: a
+                                    tracker's sentence is fixed for a sequence (lib/test/tracker/uvltrack.py:57,114). */
 } uvl_inputs;
 
 /* Output dict of forward_test: caller-allocated f32 device tensors.

@@ -35,6 +35,8 @@ class UVLTrack(BaseTracker):
         self.cfg = params.cfg
         self.network = network.to(self.device)
         self.network.eval()
+        # the sentence is fixed for a sequence: forward_test may keep the text branch of the previous frame (uvl_inputs.reuse_text)
+        self.network.cache_text = True
         self.map_size = params.search_size // 16
         self.preprocessor = Preprocessor_wo_mask()
         self.state = None

@@ -149,7 +149,7 @@ def test_graph_replay_equals_eager(batch):
     assert np.abs(outs["bbox_map"].cpu().numpy() - eager["bbox_map"]).max() > 1e-4
 
 
-@pytest.mark.parametrize("name,batch", [("tiny_mixed", None), ("tiny_mixed", 1), ("tiny_switches", 1), ("b_z128_x256", 1)])
+@pytest.mark.parametrize("name,batch", [("tiny_mixed", None), ("tiny_mixed", 1), ("tiny_switches", 1), ("b_z128_x256", 1), ("b_z256_x256", 1)])
 def test_skip_text_is_exact_for_box_outputs(name, batch):
     """BBOX-only mode may drop the text branch: every box output is bit-identical -- also for one sequence,
     where the full frame runs the paired kernels and the text-less frame the plain ones."""
@@ -163,6 +163,39 @@ def test_skip_text_is_exact_for_box_outputs(name, batch):
     skip = _run(eng, inp, skip_text=True)
     for k in ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "template", "vis_token", "pred_boxes"):
         np.testing.assert_array_equal(full[k], skip[k], err_msg=k)
+
+
+@pytest.mark.parametrize("name,batch", [("tiny_mixed", None), ("tiny_switches", 1), ("tiny_allmasked_text", None), ("b_z256_x256", 1), ("b_z128_x256", None)])
+def test_reused_text_branch_is_bit_identical(name, batch):
+    """uvl_inputs.reuse_text: a later frame (other search crop, same sentence) that takes the text branch from the workspace
+    equals the frame that recomputes it, bit for bit, on every output; a changed sentence (in place or a new tensor) is noticed."""
+    meta, spec, _ = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    if batch is not None:
+        inp = {k: v[:batch].copy() for k, v in inp.items()}
+    eng = _engine(meta, spec)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inp.items()}
+    g = torch.Generator().manual_seed(7)
+    search2 = torch.randn(t["search"].shape, generator=g).cuda()
+    keys = ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "template", "text", "vis_token", "txt_token", "pred_boxes")
+    run = lambda srch, **kw: {k: v.clone() for k, v in eng.forward(t["template"], srch, t["ids"], t["mask"], t["prompt"], t["flag"], **kw).items() if k in keys}
+    want = run(search2)                                       # full frame on the second crop
+    run(t["search"])                                          # frame 1 (full): leaves its text rows in the workspace
+    assert eng._text_matches(eng._text_key(t["search"].shape[0], t["ids"], t["mask"]))
+    for _ in range(3):                                        # frames 2..4 reuse them
+        got = run(search2, reuse_text=True)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), k
+    # another sentence written into the same tensor: the version counter changes, the branch is recomputed
+    old = t["ids"].clone()
+    t["ids"].copy_((old + 3) % spec.vocab)
+    assert not eng._text_matches(eng._text_key(t["search"].shape[0], t["ids"], t["mask"]))
+    got2 = run(search2, reuse_text=True)
+    want2 = run(search2)
+    for k in keys:
+        assert torch.equal(got2[k], want2[k]), k
+    if not name.startswith("tiny_allmasked") and bool((t["flag"] != 0).any()):
+        assert not torch.equal(got2["text"], want["text"])    # the sentence did matter
 
 
 def test_cpu_tensors_fail_loudly():

@@ -41,7 +41,7 @@ class UvlInputs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32),
         ("d_template", C.c_void_p), ("d_search", C.c_void_p), ("d_text_ids", C.c_void_p), ("d_text_mask", C.c_void_p),
-        ("d_prompt", C.c_void_p), ("d_flag", C.c_void_p), ("skip_text", C.c_int32),
+        ("d_prompt", C.c_void_p), ("d_flag", C.c_void_p), ("skip_text", C.c_int32), ("reuse_text", C.c_int32),
     ]
 
 

@@ -18,6 +18,9 @@ LIB = os.path.join(HERE, "libuvltrack_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "prompter.hip", "preprocess.hip", "uvl_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1",      # accumulators stay in VGPRs (unified file on gfx950): no v_accvgpr moves around the softmax
+         # a*b+c fuses where the SOURCE expression says so, not wherever the optimiser finds a multiply next to an add: the same
+         # device function gives the same bits in every kernel it is inlined into (paired / stand-alone launch forms)
+         "-ffp-contract=on",
          "-I", INCLUDE, "-I", CSRC]
 
 

@@ -53,6 +53,8 @@ struct LnParams {
     const float* pre_add0 = nullptr;             // optional vector added to rows with t <  split (then written back to x)
     const float* pre_add1 = nullptr;             //                          rows with t >= split
     int split = 0;
+    const float* x_alt = nullptr; int x_alt_rows = 0;   // optional: rows with t >= split are READ from x_alt[b * x_alt_rows + t - split]
+                                                 // (text rows kept from an earlier frame); the fold is still written to x
     const float *gamma = nullptr, *beta = nullptr; float eps = 1e-6f;
     bf16_t* y_bf16 = nullptr;                    // [M,D] compact, optional
     float* y_f32 = nullptr; int y_remap = 0;     // optional f32 output; y_remap: same row map as x (in-place LN) else compact
@@ -78,6 +80,7 @@ struct PrologueParams {
     const int64_t* ids = nullptr; const float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
     bf16_t* tn = nullptr; int vocab = 0;
     const float *z = nullptr, *ximg = nullptr; bf16_t* patches = nullptr; int Hz = 0, Hx = 0;
+    int skip_text = 0, setup_what = 3;           // as launch_setup; ids == nullptr: no embedding workgroups
     int n_setup = 0, n_embed = 0;                // filled by the launcher
 };
 hipError_t launch_prologue(const PrologueParams& p, hipStream_t s);

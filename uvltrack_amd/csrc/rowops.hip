@@ -22,6 +22,7 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const int b = m / p.rpb, t = m - b * p.rpb;
     const size_t xrow = (size_t)b * p.xbs + p.xro + t;
     float* xr = const_cast<float*>(p.x) + xrow * p.D;
+    const float* xin = (p.x_alt && t >= p.split) ? p.x_alt + ((size_t)b * p.x_alt_rows + (t - p.split)) * p.D : xr;
     const float* padd = (t < p.split) ? p.pre_add0 : p.pre_add1;
     const int nsp = (t < p.part_rows) ? p.nsplit : 0;       // rows beyond part_rows were not produced by that GEMM
     const size_t pm = (size_t)b * p.part_rows + t;           // compact row index inside a slab
@@ -31,7 +32,7 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < p.D) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            v[i] = *reinterpret_cast<const float4*>(xin + c);
             float4 sl[LN_MAX_SLABS];                         // pending split-K slabs: issue every load, then add in slab order
 #pragma unroll
             for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
@@ -45,7 +46,7 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
                 const float4 a = *reinterpret_cast<const float4*>(padd + c);
                 v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
             }
-            if (padd || nsp > 0) *reinterpret_cast<float4*>(xr + c) = v[i];
+            if (padd || nsp > 0 || xin != xr) *reinterpret_cast<float4*>(xr + c) = v[i];
             sum += v[i].x + v[i].y + v[i].z + v[i].w;
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -330,7 +331,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void prologue_kernel(const PrologueParams p) {
     const int bx = blockIdx.x;
     if (bx < p.n_setup) {
-        setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, 0, 3, bx);
+        setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, p.skip_text, p.setup_what, bx);
     } else if (bx < p.n_setup + p.n_embed) {
         bert_embed_body<NV>(p.ids, p.word, p.pos, p.type0, p.emb_g, p.emb_b, p.x, p.nj, p.nv, p.tn, p.B, p.T, p.D, p.vocab, bx - p.n_setup);
     } else {
@@ -343,7 +344,7 @@ hipError_t launch_prologue(const PrologueParams& q, hipStream_t s) {
     if (p.D % 4 != 0 || p.D > 1024) return hipErrorInvalidValue;
     const long total = (long)p.B * ((p.Hz / 16) * (p.Hz / 16) + (p.Hx / 16) * (p.Hx / 16)) * 48;
     p.n_setup = p.B;
-    p.n_embed = (p.B * p.T + 3) / 4;
+    p.n_embed = p.ids ? (p.B * p.T + 3) / 4 : 0;
     const int n_im = (int)((total + 255) / 256);
     const dim3 grid(p.n_setup + p.n_embed + n_im);
     if (p.D <= 256) hipLaunchKernelGGL(prologue_kernel<1>, grid, dim3(256), 0, s, p);

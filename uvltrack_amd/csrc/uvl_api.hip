@@ -514,6 +514,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     if (!in->d_template || !in->d_search || !in->d_prompt || !in->d_flag) return fail(UVL_EINVAL, "missing input pointer");
     const int skip = in->skip_text ? 1 : 0;
     if (!skip && (!in->d_text_ids || !in->d_text_mask)) return fail(UVL_EINVAL, "text inputs required unless skip_text");
+    // reuse_text: the text branch below the first fusion layer depends on the text alone, and a tracker's text does not change
+    // over a sequence -- take its results (final text rows + the per-layer snapshots for the logits) from the workspace, where
+    // the last full call left them.  The frame is then the single-stream visual schedule with nj rows from layer nf on.
+    const int reuse = (!skip && in->reuse_text && m->nf > 0 && m->nf < m->depth) ? 1 : 0;
+    if (reuse && tb) return fail(UVL_EINVAL, "uvl_forward: reuse_text is a forward_test option");
     const Workspace w = carve(m, B, (char*)d_ws);
     if (!d_ws || ws_bytes < w.total) return fail(UVL_EINVAL, "workspace too small: %zu < %zu", ws_bytes, w.total);
     if ((uintptr_t)d_ws % 256) return fail(UVL_EINVAL, "workspace must be 256-byte aligned");
@@ -527,8 +532,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // attention with attention, LayerNorm with LayerNorm -- the two layer structures line up op for op), so the 40-token branch
     // costs neither launches nor a second queue; measured, the two-stream form slows each visual layer by ~11 us through
     // contention and ends level with visual layer nf-1 (profiles/r01_summary.md).  Larger batches keep the second stream.
-    const bool paired = !skip && m->nf > 0 && m->pair_text && B == 1;
-    const bool fork = !skip && !prof && m->nf > 0 && parts == PART_ALL && !paired;
+    const bool paired = !skip && !reuse && m->nf > 0 && m->pair_text && B == 1;
+    const bool fork = !skip && !reuse && !prof && m->nf > 0 && parts == PART_ALL && !paired;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
     enum { R_GEMM = 0, R_ATTN = 1, R_LN = 2 };
     struct Rider { int kind; const char* what; double flops, bytes; GemmParams g; AttnParams a; LnParams l; int layer; };
@@ -591,10 +596,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     }
     L.cur = PART_V1;
     PrologueParams pro;
-    if (paired) {                                // single-stream frame: set-up, BERT embedding and im2row in ONE launch
+    const bool one_queue = paired || skip || reuse;   // single-stream frame: set-up, BERT embedding (if any) and im2row in ONE launch
+    if (one_queue) {
         pro.text_mask = in->d_text_mask; pro.flag = in->d_flag; pro.cls_token = m->cls_token; pro.x = w.X; pro.key_add = w.key_add;
         pro.bert_add = w.bert_add; pro.nz = nz; pro.nv = nv; pro.nj = nj; pro.npad = npad; pro.T = T; pro.D = D; pro.B = B;
-        pro.ids = in->d_text_ids; pro.word = m->word; pro.pos = m->pos; pro.type0 = m->type0; pro.emb_g = m->emb_g; pro.emb_b = m->emb_b;
+        pro.ids = paired ? in->d_text_ids : nullptr; pro.skip_text = skip; pro.setup_what = skip ? 1 : 3; pro.word = m->word; pro.pos = m->pos; pro.type0 = m->type0; pro.emb_g = m->emb_g; pro.emb_b = m->emb_b;
         pro.tn = w.Tn; pro.vocab = m->cfg.vocab;
         pro.z = in->d_template; pro.ximg = in->d_search; pro.patches = w.P; pro.Hz = m->cfg.template_size; pro.Hx = m->cfg.search_size;
         L.run(s, "prologue", 0, 0, tramp<PrologueParams, launch_prologue>, &pro);
@@ -602,7 +608,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     L.run(s, "setup", 0, 0, setup_fn, &sc);
     SetupCtx sct = sc;
     sct.what = 2;
-    if (!skip && !paired) { L.cur = PART_TEXT; L.run(sa, "setup", 0, 0, setup_fn, &sct); L.cur = PART_V1; }
+    if (!one_queue) { L.cur = PART_TEXT; L.run(sa, "setup", 0, 0, setup_fn, &sct); L.cur = PART_V1; }
     // -- text branch (extractor.py:54,62): embedding + the first nf BERT layers depend on the text only, so the whole
     //    chain is enqueued up front on its own stream; layers whose output the contrastive logits need leave a snapshot
     Pending pend_t;
@@ -621,7 +627,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         }
         run_gemm(st, p, what, is_text);
     };
-    if (!skip && !paired) {
+    if (!one_queue) {
         struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
         L.cur = PART_TEXT;
         L.run(sa, "bert_embed", 0, 0, [](void* c, hipStream_t st) {
@@ -631,7 +637,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         }, &bc);
         L.cur = PART_V1;
     }
-    const int last_bert = skip ? -1 : ((m->debug_stop_layer >= 0 && m->debug_stop_layer < m->nf - 1) ? m->debug_stop_layer : m->nf - 1);
+    const int last_bert = (skip || reuse) ? -1 : ((m->debug_stop_layer >= 0 && m->debug_stop_layer < m->nf - 1) ? m->debug_stop_layer : m->nf - 1);
     int text_err = 0;
     // one BERT layer (BertLayer.forward, bert_backbone.py:390-394); launched interleaved with the visual layers so both
     // hardware queues are fed in step (the host enqueues ~3.5 us per launch)
@@ -671,7 +677,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
                 consume(p, pend_t);
                 p.gamma = bw.ln2g; p.beta = bw.ln2b; p.eps = 1e-12f; p.y_bf16 = w.Tn; p.y_f32 = w.X; p.y_remap = 1;
-                if (is_cont_layer(i) && out->d_logits) p.y_copy = w.TxtSnap + (size_t)i * Mt * D;   // this layer's text rows for the logits
+                // this layer's text rows: for the logits, and (last BERT layer) for later frames that reuse the text branch
+                if ((is_cont_layer(i) && out->d_logits) || i == m->nf - 1) p.y_copy = w.TxtSnap + (size_t)i * Mt * D;
                 run_ln(sa, p, (double)Mt * D * 10, true);
             }
             if (fork && is_cont_layer(i) && out->d_logits) {
@@ -687,7 +694,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     }
     // -- patch embed (mae_vit.py:203-215)
     struct ImCtx { const uvl_inputs* in; Workspace w; int B, hz, hx; } ic{in, w, B, m->cfg.template_size, m->cfg.search_size};
-    if (!paired) L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
+    if (!one_queue) L.run(s, "im2row", 0, 0, [](void* c, hipStream_t st) { auto* x = (ImCtx*)c; return launch_im2row(x->in->d_template, x->in->d_search, x->w.P, x->B, x->hz, x->hx, st); }, &ic);
     {
         GemmParams p;
         p.A = w.P; p.lda = 768; p.W = m->w_patch; p.ldw = 768; p.bias = m->b_patch;
@@ -726,6 +733,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
             consume(p, pend_v);
             if (joint) { p.pre_add0 = m->modal; p.pre_add1 = m->modal + D; p.split = nv; }     // forward_joint, mae_vit.py:196
+            if (reuse && i == m->nf) { p.x_alt = w.TxtSnap + (size_t)(m->nf - 1) * B * T * D; p.x_alt_rows = T; }   // text rows kept from the last full frame
             p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
             if (fused_ct >= 0) p.x_snap = w.XSnap;   // this fold completes layer `fused_ct`: keep its output for the logits
             run_ln(s, p, (double)M * D * 6, false);
@@ -949,7 +957,7 @@ extern "C" int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl
     if (!m->cap_stream) HIPCHK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     HIPCHK(hipDeviceSynchronize());
     // one sequence with paired text kernels is a single-stream frame: one graph, like the no-text case
-    const bool text = !in->skip_text && m->nf >= 0 && !(m->pair_text && in->batch == 1 && m->nf > 0);
+    const bool text = !in->skip_text && !in->reuse_text && m->nf >= 0 && !(m->pair_text && in->batch == 1 && m->nf > 0);
     const int part_of[3] = {PART_TEXT, PART_V1, PART_V2};
     for (int k = 0; k < 3; ++k) {
         if (!text && k != 1) continue;

@@ -52,6 +52,7 @@ class HipEngine:
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
         self._graph_io = None
+        self._text_primed = None                          # see _text_key
         self.weights_loaded = False
 
     def close(self):
@@ -93,6 +94,7 @@ class HipEngine:
             _native.check(self.lib.uvl_finalize_weights(self.handle, self._stream()), "uvl_finalize_weights")
         self.weights_loaded = True
         self._graph_io = None
+        self._text_primed = None
         return unknown
 
     # ------------------------------------------------------------------ forward
@@ -102,7 +104,20 @@ class HipEngine:
             self._ws = torch.empty(n + 256, dtype=torch.uint8, device=self.device)
             self._ws_batch = B
             self._graph_io = None
+            self._text_primed = None
+        if self._text_primed is not None and self._text_primed[0] != B:
+            self._text_primed = None                      # the workspace is carved per batch size: another B overwrites the kept rows
         return self._ws
+
+    # The text branch below the first fusion layer depends on the text alone; `forward(..., reuse_text=True)` skips it when the
+    # workspace still holds the rows of a call with the very same text tensors (same objects, not modified since).
+    @staticmethod
+    def _text_key(B, ids, mask):
+        return (B, ids, ids._version, mask, mask._version)
+
+    def _text_matches(self, key) -> bool:
+        p = self._text_primed
+        return p is not None and p[0] == key[0] and p[1] is key[1] and p[2] == key[2] and p[3] is key[3] and p[4] == key[4]
 
     def _ws_ptr(self, ws):
         p = ws.data_ptr()
@@ -114,7 +129,7 @@ class HipEngine:
         outs["argmax"] = torch.empty(B, dtype=torch.int64, device=self.device)
         return outs
 
-    def _pack_io(self, template, search, ids, mask, prompt, flag, outs, skip_text):
+    def _pack_io(self, template, search, ids, mask, prompt, flag, outs, skip_text, reuse_text=False):
         B = search.shape[0]
         i = _native.UvlInputs()
         i.batch = B
@@ -123,6 +138,7 @@ class HipEngine:
         i.d_text_mask = mask.data_ptr() if mask is not None else None
         i.d_prompt, i.d_flag = prompt.data_ptr(), flag.data_ptr()
         i.skip_text = 1 if skip_text else 0
+        i.reuse_text = 1 if reuse_text else 0
         o = _native.UvlOutputs()
         for k, f in _OUT_FIELD.items():
             setattr(o, f, outs[k].data_ptr() if k in outs else None)
@@ -153,10 +169,13 @@ class HipEngine:
                 raise ValueError("text must be [B,%d]" % s.text_len)
         return template, search, ids, mask, prompt, flag
 
-    def forward(self, template, search, ids, mask, prompt, flag, skip_text: bool = False, outs=None, profile: bool = False):
-        """UVLTrack.forward_test on device tensors; returns the output dict (f32 device tensors)."""
+    def forward(self, template, search, ids, mask, prompt, flag, skip_text: bool = False, outs=None, profile: bool = False,
+                reuse_text: bool = False):
+        """UVLTrack.forward_test on device tensors; returns the output dict (f32 device tensors).  `reuse_text`: allow the text
+        branch of an earlier call with the same `ids` / `mask` tensor objects (unmodified) to be reused (uvl_inputs.reuse_text)."""
         if not self.weights_loaded:
             raise _native.NativeLibraryError("weights have not been loaded")
+        key = self._text_key(search.shape[0], ids, mask) if (ids is not None and mask is not None and not skip_text) else None
         template, search, ids, mask, prompt, flag = self._canon_inputs(template, search, ids, mask, prompt, flag)
         B = search.shape[0]
         if B > self.max_batch:
@@ -165,7 +184,10 @@ class HipEngine:
             ws = self._workspace(B)
             if outs is None:
                 outs = self.alloc_outputs(B)
-            i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text)
+            reuse = bool(reuse_text) and key is not None and self._text_matches(key)
+            if key is not None:
+                self._text_primed = key                   # this call leaves (or keeps) that text's rows in the workspace
+            i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text, reuse)
             n = self.lib.uvl_workspace_bytes(self.handle, B)
             if profile:
                 ms = (C.c_float * _native.UVL_NFAM)()
@@ -181,16 +203,20 @@ class HipEngine:
         self._keep = (template, search, ids, mask)      # inputs must outlive the asynchronous launches
         return outs
 
-    def make_eager_step(self, template, search, ids, mask, prompt, flag, skip_text: bool = False, outs=None):
+    def make_eager_step(self, template, search, ids, mask, prompt, flag, skip_text: bool = False, outs=None, reuse_text: bool = False):
         """Pre-validate the inputs once and return a zero-argument callable that enqueues one frame (the benchmark's
-        steady-state loop: same device buffers every step, no per-step Python work besides one ctypes call)."""
+        steady-state loop: same device buffers every step, no per-step Python work besides one ctypes call).  `reuse_text`: one
+        full frame is run here, every step then reuses its text branch."""
+        if reuse_text and not skip_text:
+            outs = self.forward(template, search, ids, mask, prompt, flag, outs=outs)
         template, search, ids, mask, prompt, flag = self._canon_inputs(template, search, ids, mask, prompt, flag)
         B = search.shape[0]
         with torch.cuda.device(self.device):
             ws = self._workspace(B)
             if outs is None:
                 outs = self.alloc_outputs(B)
-            i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text)
+            i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text, reuse_text and not skip_text)
+            self._text_primed = None                      # the step's text is not tracked
             n = self.lib.uvl_workspace_bytes(self.handle, B)
         outs["flag"], outs["prompt"], outs["prompts"] = flag, prompt, prompt
         keep = (template, search, ids, mask, prompt, flag, ws, outs, i, o)
@@ -228,6 +254,7 @@ class HipEngine:
             outs = self.alloc_outputs(B)
             outs["cont_score"] = torch.empty(B, s.nx, 2, dtype=torch.float32, device=self.device)
             prompts = torch.empty(B, 3, s.dim, dtype=torch.float32, device=self.device)
+            self._text_primed = None                      # this call's text branch overwrites the kept rows
             i, o = self._pack_io(template, search, ids, mask, dummy, flag, outs, False)
             n = self.lib.uvl_workspace_bytes(self.handle, B)
             p = lambda t: C.c_void_p(t.data_ptr())
@@ -309,6 +336,7 @@ class HipEngine:
                       mask=None if mask is None else mask.clone(), prompt=prompt.clone(), flag=flag.clone())
             outs = self.alloc_outputs(B)
             ws = self._workspace(B)
+            self._text_primed = None
             i, o = self._pack_io(st["template"], st["search"], st["ids"], st["mask"], st["prompt"], st["flag"], outs, skip_text)
             n = self.lib.uvl_workspace_bytes(self.handle, B)
             torch.cuda.synchronize(self.device)
@@ -320,5 +348,6 @@ class HipEngine:
     def replay(self):
         if self._graph_io is None:
             raise _native.NativeLibraryError("no captured graph")
+        self._text_primed = None
         _native.check(self.lib.uvl_graph_launch(self.handle, self._stream()), "uvl_graph_launch")
         return self._graph_io[1]

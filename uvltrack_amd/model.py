@@ -130,7 +130,9 @@ class UVLTrack(nn.Module):
         ids, mask = text.tensors, text.mask
         if mask is None:
             mask = torch.ones_like(ids)
-        out = eng.forward(template, search, ids, mask, prompt, flag)
+        # `self.cache_text = True` (off by default; the trackers in lib/test/tracker switch it on): when `text` carries the same
+        # tensor objects as the previous call, unmodified, the text branch below the first fusion layer is not recomputed
+        out = eng.forward(template, search, ids, mask, prompt, flag, reuse_text=bool(getattr(self, "cache_text", False)))
         out.pop("argmax", None)
         return out
 

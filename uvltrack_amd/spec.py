@@ -92,14 +92,14 @@ class ModelSpec:
         return asdict(self)
 
     # ---- algorithmic work (SURVEY.md §8d formula) -------------------------
-    def flops_per_frame(self, skip_text: bool = False) -> float:
+    def flops_per_frame(self, skip_text: bool = False, reuse_text: bool = False) -> float:
         D, nv = self.dim, self.nv
         nj = nv if skip_text else self.nj
         f = 0.0
         for i in range(self.depth):
             n = nj if i in self.fusion_layers else nv
             f += 24.0 * n * D * D + 4.0 * n * n * D
-        if not skip_text:
+        if not skip_text and not reuse_text:
             T = self.text_len
             f += self.n_bert * (24.0 * T * D * D + 4.0 * T * T * D)
         f += 2.0 * (self.nz + self.nx) * 768 * D
