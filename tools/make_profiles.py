@@ -49,7 +49,7 @@ def main(src, tag):
     f, nf = agg(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"))
     w, nw = agg(os.path.join(src, "pmc_write", "bench_counter_collection.csv"))
     for k in sorted(stats, key=lambda k: -stats[k][2]):
-        if not re.match(r"(gemm|attn|ln_|contrast|head|im2row|bert|setup|slab)", k):
+        if not re.match(r"(gemm|attn|ln_|contrast|head|im2row|bert|setup|slab|prologue)", k):
             continue
         calls, avg_us, pct = stats[k]
         busy = m.get(k, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(nm.get(k, 1), 1)

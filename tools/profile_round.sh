@@ -25,6 +25,8 @@ python bench.py --model L --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_L
 python bench.py --model L --batch 8 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_L_b8.json 2>/dev/null
 python bench.py --mode BBOX --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_bbox.json 2>/dev/null
 python bench.py --mode BBOX --skip-text --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_bbox_notext.json 2>/dev/null
+python bench.py --reuse-text --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_reuse_text.json 2>/dev/null
+python bench.py --reuse-text --batch 8 --steps 60 --warmup 10 --no-cpu-baseline > $O/bench_reuse_text_b8.json 2>/dev/null
 python bench.py --mode NL --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_nl.json 2>/dev/null
 python bench.py --template-size 128 --steps 300 --warmup 50 --no-cpu-baseline > $O/bench_z128.json 2>/dev/null
 python bench.py --model L --template-size 128 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_L_z128.json 2>/dev/null
@@ -35,5 +37,5 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INST
 cd $REPO
 python tools/pmc_report.py $O/attn attn_kernel > $O/attn_pmc.txt 2>&1
 python tools/attn_bench.py > $O/attn_bench.txt 2>&1
-for f in default b8 b32 L L_b8 bbox bbox_notext nl z128 L_z128; do tail -1 $O/bench_$f.json | cut -c1-140; done
+for f in default b8 b32 L L_b8 bbox bbox_notext reuse_text reuse_text_b8 nl z128 L_z128; do tail -1 $O/bench_$f.json | cut -c1-140; done
 ls $O/stats $O/pmc_mfma | head -20
