@@ -14,9 +14,18 @@ namespace uvl {
 // ------------------------------------------------------------------------------------------------
 #define LN_MAX_SLABS 4
 
-template <int NV>
+// 4 KB of zeros: the source of loads whose value is not wanted (absent slab / absent pre-add vector), so that every load of a
+// row is issued unconditionally up front -- a load under a run-time condition is compiled as branch + load + s_waitcnt vmcnt(0),
+// which turned the row into nine dependent memory round trips (7 us per launch for 1.7 MB of rows).
+__device__ float g_zero_row[1024];
+
+__device__ __forceinline__ float4 sel4(bool c, const float4& a) { return c ? a : make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// FULL: D == NV * 256 (the real models): no column guard at all.  The row index is made wave-uniform explicitly, so the row's
+// addresses, the slab count and the pre-add selection live in scalar registers.
+template <int NV, bool FULL>
 __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = bx * (int)(blockDim.x >> 6) + wave;     // one row per wave, blockDim.x / 64 rows per workgroup
     if (m >= p.M) return;
     const int b = m / p.rpb, t = m - b * p.rpb;
@@ -26,38 +35,75 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const float* padd = (t < p.split) ? p.pre_add0 : p.pre_add1;
     const int nsp = (t < p.part_rows) ? p.nsplit : 0;       // rows beyond part_rows were not produced by that GEMM
     const size_t pm = (size_t)b * p.part_rows + t;           // compact row index inside a slab
-    float4 v[NV];
+    // ---- phase 1: every load of the row, no use in between ----
+    const float* slab[LN_MAX_SLABS];
+#pragma unroll
+    for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
+        slab[sp] = (sp < nsp) ? p.part + (size_t)sp * p.part_stride + pm * p.D : g_zero_row;
+    const float* pa = padd ? padd : g_zero_row;
+    float4 v[NV], sl[NV][LN_MAX_SLABS], ad[NV], g[NV], be[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c0 = (lane + 64 * i) * 4;
+        ok[i] = FULL || c0 < p.D;
+        const int c = ok[i] ? c0 : 0;
+        v[i] = *reinterpret_cast<const float4*>(xin + c);
+#pragma unroll
+        for (int sp = 0; sp < LN_MAX_SLABS; ++sp) sl[i][sp] = *reinterpret_cast<const float4*>(slab[sp] + c);
+        ad[i] = *reinterpret_cast<const float4*>(pa + c);
+        g[i] = *reinterpret_cast<const float4*>(p.gamma + c);
+        be[i] = *reinterpret_cast<const float4*>(p.beta + c);
+    }
+    // the second job's operands (contrastive logits of the previous layer, see below) are independent of the row: same round trip
+    const bool do_ct = p.ct_x && t >= 1 + p.ct_nz && t < p.ct_nv;
+    float4 ca[NV], cv[NV], cq[NV];
+    float ct_ls = 0.f;
+    int ct_fl = 0;
+    if (do_ct) {
+        const float* xb = p.ct_x + (size_t)b * p.xbs * p.D;
+        const float* xs = xb + (size_t)t * p.D;
+        const float* tk = p.ct_skip_text ? xb : (p.ct_txt ? p.ct_txt + (size_t)b * p.ct_T * p.D : xb + (size_t)p.ct_nv * p.D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = ok[i] ? (lane + 64 * i) * 4 : 0;
+            ca[i] = *reinterpret_cast<const float4*>(xs + c);
+            cv[i] = *reinterpret_cast<const float4*>(xb + c);
+            cq[i] = *reinterpret_cast<const float4*>(tk + c);
+        }
+        ct_ls = p.ct_logit_scale[0];
+        ct_fl = (int)p.ct_flag[b];
+    }
+    __builtin_amdgcn_sched_barrier(0);       // keep the scheduler from pulling the first adds up between the loads (it would
+                                             // wait for the first few loads, reuse their registers and issue the rest afterwards)
+    // ---- phase 2: fold the slabs in slab order, snapshot, pre-add, write back ----
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
-        if (c < p.D) {
-            v[i] = *reinterpret_cast<const float4*>(xin + c);
-            float4 sl[LN_MAX_SLABS];                         // pending split-K slabs: issue every load, then add in slab order
+        v[i] = sel4(ok[i], v[i]);
 #pragma unroll
-            for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
-                sl[sp] = (sp < nsp) ? *reinterpret_cast<const float4*>(p.part + (size_t)sp * p.part_stride + pm * p.D + c)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
-                if (sp < nsp) { v[i].x += sl[sp].x; v[i].y += sl[sp].y; v[i].z += sl[sp].z; v[i].w += sl[sp].w; }
-            if (p.x_snap) *reinterpret_cast<float4*>(p.x_snap + xrow * p.D + c) = v[i];
-            if (padd) {
-                const float4 a = *reinterpret_cast<const float4*>(padd + c);
-                v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
-            }
-            if (padd || nsp > 0 || xin != xr) *reinterpret_cast<float4*>(xr + c) = v[i];
-            sum += v[i].x + v[i].y + v[i].z + v[i].w;
-        } else {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < LN_MAX_SLABS; ++sp) {
+            const float4 a = sl[i][sp];
+            const bool on = ok[i] && sp < nsp;
+            v[i].x = on ? v[i].x + a.x : v[i].x; v[i].y = on ? v[i].y + a.y : v[i].y;
+            v[i].z = on ? v[i].z + a.z : v[i].z; v[i].w = on ? v[i].w + a.w : v[i].w;
         }
+        if (p.x_snap && ok[i]) *reinterpret_cast<float4*>(p.x_snap + xrow * p.D + c) = v[i];
+        {
+            const bool on = ok[i] && padd != nullptr;
+            const float4 a = ad[i];
+            v[i].x = on ? v[i].x + a.x : v[i].x; v[i].y = on ? v[i].y + a.y : v[i].y;
+            v[i].z = on ? v[i].z + a.z : v[i].z; v[i].w = on ? v[i].w + a.w : v[i].w;
+        }
+        if ((padd || nsp > 0 || xin != xr) && ok[i]) *reinterpret_cast<float4*>(xr + c) = v[i];
+        sum += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mean = wave_sum(sum) / (float)p.D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < p.D) {
+        if (ok[i]) {
             const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
             sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
@@ -67,14 +113,12 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
-        if (c < p.D) {
-            const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
-            const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
+        if (ok[i]) {
             float4 y;
-            y.x = (v[i].x - mean) * rstd * g.x + be.x;
-            y.y = (v[i].y - mean) * rstd * g.y + be.y;
-            y.z = (v[i].z - mean) * rstd * g.z + be.z;
-            y.w = (v[i].w - mean) * rstd * g.w + be.w;
+            y.x = (v[i].x - mean) * rstd * g[i].x + be[i].x;
+            y.y = (v[i].y - mean) * rstd * g[i].y + be[i].y;
+            y.z = (v[i].z - mean) * rstd * g[i].z + be[i].z;
+            y.w = (v[i].w - mean) * rstd * g[i].w + be[i].w;
             if (p.y_f32) *reinterpret_cast<float4*>(p.y_f32 + yrow * p.D + c) = y;
             if (p.y_copy) *reinterpret_cast<float4*>(p.y_copy + (size_t)m * p.D + c) = y;
             if (p.y_bf16) {
@@ -87,25 +131,24 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     }
     // ---- contrastive logits of the previous layer for this wave's search row (same arithmetic, in the same order, as
     //      contrast_kernel: tau * normalize(x) . normalize(token), select [vis, txt, mean][flag]) ----
-    if (p.ct_x && t >= 1 + p.ct_nz && t < p.ct_nv) {
+    if (do_ct) {
         const int s = t - 1 - p.ct_nz;
-        const float* xb = p.ct_x + (size_t)b * p.xbs * p.D;
-        const float* xs = xb + (size_t)t * p.D;
-        const float* tk = p.ct_txt ? p.ct_txt + (size_t)b * p.ct_T * p.D : xb + (size_t)p.ct_nv * p.D;
         float xx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
-        for (int c = lane * 4; c < p.D; c += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(xs + c);
-            const float4 vq = *reinterpret_cast<const float4*>(xb + c);
-            xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-            xv += a.x * vq.x + a.y * vq.y + a.z * vq.z + a.w * vq.w;
-            vv += vq.x * vq.x + vq.y * vq.y + vq.z * vq.z + vq.w * vq.w;
-            if (!p.ct_skip_text) {
-                const float4 q = *reinterpret_cast<const float4*>(tk + c);
-                xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
-                tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (ok[i]) {
+                const float4 a = ca[i], vq = cv[i];
+                xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+                xv += a.x * vq.x + a.y * vq.y + a.z * vq.z + a.w * vq.w;
+                vv += vq.x * vq.x + vq.y * vq.y + vq.z * vq.z + vq.w * vq.w;
+                if (!p.ct_skip_text) {
+                    const float4 q = cq[i];
+                    xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+                    tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+                }
             }
         }
-        const float tau = __expf(p.ct_logit_scale[0]);
+        const float tau = __expf(ct_ls);
         xx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
         vv = fmaxf(sqrtf(wave_sum(vv)), 1e-12f);
         const float lv = tau * wave_sum(xv) / (xx * vv);
@@ -114,22 +157,21 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
             tt = fmaxf(sqrtf(wave_sum(tt)), 1e-12f);
             lt = tau * wave_sum(xt) / (xx * tt);
         }
-        const int fl = (int)p.ct_flag[b];
-        const float out = fl == 0 ? lv : (fl == 1 ? lt : 0.5f * (lv + lt));
+        const float out = ct_fl == 0 ? lv : (ct_fl == 1 ? lt : 0.5f * (lv + lt));
         if (lane == 0) p.ct_logits[((size_t)b * p.ct_ncont + p.ct_slot) * p.ct_nx + s] = out;
     }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) { ln_body<NV>(p, blockIdx.x); }
+template <int NV, bool FULL>
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) { ln_body<NV, FULL>(p, blockIdx.x); }
 
 // Two independent LayerNorm problems in one launch (batch-1 frames pair every text-branch kernel with the visual kernel
 // of the same kind, see uvl_api.hip): workgroups [0, split) work on pa, the rest on pb.
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
-    if ((int)blockIdx.x < split) ln_body<NV>(pa, (int)blockIdx.x);
-    else ln_body<NV>(pb, (int)blockIdx.x - split);
+    if ((int)blockIdx.x < split) ln_body<NV, FULL>(pa, (int)blockIdx.x);
+    else ln_body<NV, FULL>(pb, (int)blockIdx.x - split);
 }
 
 // Rows (= waves) per workgroup: 4.  One or two rows per workgroup measure the same within noise (1114 / 1119-1125 / 1122-1131
@@ -145,9 +187,11 @@ hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
     if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0) return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(p.M);
     const int grid = (p.M + wpb - 1) / wpb;
-    if (p.D <= 256) hipLaunchKernelGGL(ln_kernel<1>, dim3(grid), dim3(64 * wpb), 0, s, p);
-    else if (p.D <= 768) hipLaunchKernelGGL(ln_kernel<3>, dim3(grid), dim3(64 * wpb), 0, s, p);
-    else hipLaunchKernelGGL(ln_kernel<4>, dim3(grid), dim3(64 * wpb), 0, s, p);
+    if (p.D == 768) hipLaunchKernelGGL((ln_kernel<3, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else if (p.D == 1024) hipLaunchKernelGGL((ln_kernel<4, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else if (p.D <= 256) hipLaunchKernelGGL((ln_kernel<1, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else if (p.D <= 768) hipLaunchKernelGGL((ln_kernel<3, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else hipLaunchKernelGGL((ln_kernel<4, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
     return hipGetLastError();
 }
 
@@ -155,9 +199,11 @@ hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream
     if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0) return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(a.M);
     const int ga = (a.M + wpb - 1) / wpb, gb = (b.M + wpb - 1) / wpb;
-    if (a.D <= 256) hipLaunchKernelGGL(ln_pair_kernel<1>, dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
-    else if (a.D <= 768) hipLaunchKernelGGL(ln_pair_kernel<3>, dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
-    else hipLaunchKernelGGL(ln_pair_kernel<4>, dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    if (a.D == 768) hipLaunchKernelGGL((ln_pair_kernel<3, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else if (a.D == 1024) hipLaunchKernelGGL((ln_pair_kernel<4, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else if (a.D <= 256) hipLaunchKernelGGL((ln_pair_kernel<1, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else if (a.D <= 768) hipLaunchKernelGGL((ln_pair_kernel<3, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else hipLaunchKernelGGL((ln_pair_kernel<4, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
     return hipGetLastError();
 }
 
