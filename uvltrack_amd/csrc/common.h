@@ -25,6 +25,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return r.u;
 }
 
+// A 32-bit word at a wave-uniform address through the scalar cache (read-only inputs: flags, logit scales).  hipcc sometimes
+// fetches such a word with a vector load and then waits on vmcnt for it in front of the row loads; this keeps it off that counter.
+__device__ __forceinline__ uint32_t sload_u32(const void* uniform_ptr) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ float sload_f32(const float* uniform_ptr) { return __uint_as_float(sload_u32(uniform_ptr)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -565,97 +565,146 @@ __device__ __forceinline__ void write_cont(const HeadPrepParams& p, int b, int s
     }
 }
 
+// All global loads of a wave's row and of the operands it is compared against are issued before the first use (one memory
+// round trip, see ln_body); FULL: D == NV * 256.
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) {
     extern __shared__ float sh[];              // [D] txt token, [D] cls-tokenize token
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int D = p.D;
+    bool ok[NV];
+    int cc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c0 = (lane + 64 * i) * 4;
+        ok[i] = FULL || c0 < D;
+        cc[i] = ok[i] ? c0 : 0;
+    }
     if (p.cont_only) {                         // cont_score of the search rows against a prompt that was computed after the first pass
         const int s = blockIdx.x * 4 + wave;
         if (s >= p.nx) return;
         const float* xr = p.o_search + ((size_t)b * p.nx + s) * D;
         const float* pr = p.prompt + (size_t)b * 3 * D;
+        float4 a[NV], p0[NV], p1[NV], p2[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            a[i] = *reinterpret_cast<const float4*>(xr + cc[i]);
+            p0[i] = *reinterpret_cast<const float4*>(pr + cc[i]);
+            p1[i] = *reinterpret_cast<const float4*>(pr + D + cc[i]);
+            p2[i] = *reinterpret_cast<const float4*>(pr + 2 * D + cc[i]);
+        }
+        const float ls = sload_f32(p.logit_scale);
+        __builtin_amdgcn_sched_barrier(0);
         float xx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-        for (int c = lane * 4; c < D; c += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(xr + c);
-            const float4 p0 = *reinterpret_cast<const float4*>(pr + c);
-            const float4 p1 = *reinterpret_cast<const float4*>(pr + D + c);
-            const float4 p2 = *reinterpret_cast<const float4*>(pr + 2 * D + c);
-            xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-            d0 += a.x * p0.x + a.y * p0.y + a.z * p0.z + a.w * p0.w;
-            d1 += a.x * p1.x + a.y * p1.y + a.z * p1.z + a.w * p1.w;
-            d2 += a.x * p2.x + a.y * p2.y + a.z * p2.z + a.w * p2.w;
-            n0 += p0.x * p0.x + p0.y * p0.y + p0.z * p0.z + p0.w * p0.w;
-            n1 += p1.x * p1.x + p1.y * p1.y + p1.z * p1.z + p1.w * p1.w;
-            n2 += p2.x * p2.x + p2.y * p2.y + p2.z * p2.z + p2.w * p2.w;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (!ok[i]) continue;
+            xx += a[i].x * a[i].x + a[i].y * a[i].y + a[i].z * a[i].z + a[i].w * a[i].w;
+            d0 += a[i].x * p0[i].x + a[i].y * p0[i].y + a[i].z * p0[i].z + a[i].w * p0[i].w;
+            d1 += a[i].x * p1[i].x + a[i].y * p1[i].y + a[i].z * p1[i].z + a[i].w * p1[i].w;
+            d2 += a[i].x * p2[i].x + a[i].y * p2[i].y + a[i].z * p2[i].z + a[i].w * p2[i].w;
+            n0 += p0[i].x * p0[i].x + p0[i].y * p0[i].y + p0[i].z * p0[i].z + p0[i].w * p0[i].w;
+            n1 += p1[i].x * p1[i].x + p1[i].y * p1[i].y + p1[i].z * p1[i].z + p1[i].w * p1[i].w;
+            n2 += p2[i].x * p2[i].x + p2[i].y * p2[i].y + p2[i].z * p2[i].z + p2[i].w * p2[i].w;
         }
         xx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
         n0 = fmaxf(sqrtf(wave_sum(n0)), 1e-12f);
         n1 = fmaxf(sqrtf(wave_sum(n1)), 1e-12f);
         n2 = fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
-        const float tau = __expf(p.logit_scale[0]);
+        const float tau = __expf(ls);
         const float c0 = tau * wave_sum(d0) / (xx * n0), c1 = tau * wave_sum(d1) / (xx * n1), c2 = tau * wave_sum(d2) / (xx * n2);
         if (lane == 0) write_cont(p, b, s, c0, c1, c2);
         return;
     }
     const float* xb = p.x + (size_t)b * p.nj * D;
-    const int fl = (int)p.flag[b];
+    const int fl = (int)sload_u32(p.flag + b);       // low word of the int64 flag (0 / 1 / 2)
+    const bool with_cont = p.prompt != nullptr && p.o_cont != nullptr;
+    const float ls = with_cont ? sload_f32(p.logit_scale) : 0.f;
+    const float cls = p.ct_logits ? sload_f32(p.ct_logit_scale) : 0.f;
     float* txt_tok = sh;
     float* tok = sh + D;
     const bool have_text = !p.skip_text;
-    if (have_text) block_txt_token(txt_tok, xb + (size_t)p.nv * D, p.text_mask + (size_t)b * p.T, p.T, D, p.mean_mode);
-    if (p.cls_tokenize) {
-        for (int c = threadIdx.x; c < D; c += 256) {
-            const float v = xb[c], t = have_text ? txt_tok[c] : 0.f;
-            tok[c] = fl == 0 ? v : (fl == 1 ? t : 0.5f * (v + t));
-        }
-        __syncthreads();
-    }
+    const bool use_lds = have_text && (p.mean_mode || p.cls_tokenize);   // 'cls' text token without CLS_TOKENIZE: straight from its row
     const int rows = have_text ? p.nj : p.nv;
     const int r = blockIdx.x * 4 + wave;
-    if (r == 0 && have_text && p.o_txt && wave == 0) {
-        // txt_token output row (written by the wave that also owns the cls row of this batch)
-        for (int c = lane * 4; c < D; c += 256)
-            *reinterpret_cast<float4*>(p.o_txt + (size_t)b * D + c) = *reinterpret_cast<const float4*>(txt_tok + c);
+    const bool active = r < rows;
+    const bool is_search = active && r >= 1 + p.nz && r < p.nv;
+    const int s = r - 1 - p.nz;
+    const bool txt_out = r == 0 && have_text && p.o_txt != nullptr;     // the wave of the cls row also writes txt_token
+    const float* xr = xb + (size_t)(active ? r : 0) * D;
+    // ---- loads: the row; for search rows the vis token, the text token and the three prompts (valid addresses even when unused) ----
+    float4 a[NV], v[NV], q[NV], p0[NV], p1[NV], p2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] = *reinterpret_cast<const float4*>(xr + cc[i]);
+    if (is_search || txt_out) {
+        const float* tq = have_text ? xb + (size_t)p.nv * D : xb;
+        const float* pq = with_cont ? p.prompt + (size_t)b * 3 * D : xb;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = *reinterpret_cast<const float4*>(xb + cc[i]);
+            q[i] = *reinterpret_cast<const float4*>(tq + cc[i]);
+            p0[i] = *reinterpret_cast<const float4*>(pq + cc[i]);
+            p1[i] = *reinterpret_cast<const float4*>(pq + D + cc[i]);
+            p2[i] = *reinterpret_cast<const float4*>(pq + 2 * D + cc[i]);
+        }
     }
-    if (r >= rows) return;
-    const float* xr = xb + (size_t)r * D;
+    __builtin_amdgcn_sched_barrier(0);
+    if (use_lds) {                             // masked-mean text token / CLS_TOKENIZE: the token goes through LDS
+        block_txt_token(txt_tok, xb + (size_t)p.nv * D, p.text_mask + (size_t)b * p.T, p.T, D, p.mean_mode);
+        if (p.cls_tokenize) {
+            for (int c = threadIdx.x; c < D; c += 256) {
+                const float vv = xb[c], t = txt_tok[c];
+                tok[c] = fl == 0 ? vv : (fl == 1 ? t : 0.5f * (vv + t));
+            }
+            __syncthreads();
+        }
+        if (is_search || txt_out) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) q[i] = *reinterpret_cast<const float4*>(txt_tok + cc[i]);
+        }
+    } else if (p.cls_tokenize) {               // no text at all: the token is the vis token
+        for (int c = threadIdx.x; c < D; c += 256) tok[c] = fl == 1 ? 0.f : (fl == 0 ? xb[c] : 0.5f * xb[c]);
+        __syncthreads();
+    }
+    if (txt_out) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) *reinterpret_cast<float4*>(p.o_txt + (size_t)b * D + cc[i]) = q[i];
+    }
+    if (!active) return;
     float* dst = nullptr;
     if (r == 0) dst = p.o_vis ? p.o_vis + (size_t)b * D : nullptr;
     else if (r < 1 + p.nz) dst = p.o_template ? p.o_template + ((size_t)b * p.nz + (r - 1)) * D : nullptr;
     else if (r < p.nv) dst = p.o_search ? p.o_search + ((size_t)b * p.nx + (r - 1 - p.nz)) * D : nullptr;
     else dst = p.o_text ? p.o_text + ((size_t)b * p.T + (r - p.nv)) * D : nullptr;
-    const bool is_search = r >= 1 + p.nz && r < p.nv;
-    const int s = r - 1 - p.nz;
     float xx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    const bool with_cont = p.prompt != nullptr && p.o_cont != nullptr;
-    const float* pr = with_cont ? p.prompt + (size_t)b * 3 * D : nullptr;
-    for (int c = lane * 4; c < D; c += 256) {
-        const float4 a = *reinterpret_cast<const float4*>(xr + c);
-        if (dst) *reinterpret_cast<float4*>(dst + c) = a;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (!ok[i]) continue;
+        const int c = cc[i];
+        if (dst) *reinterpret_cast<float4*>(dst + c) = a[i];
         if (is_search) {
             bf16_t* g = p.g0 + ((size_t)b * p.nx + s) * p.g0_ld;
             uint2 w;
-            w.x = pack_bf16x2(a.x, a.y);
-            w.y = pack_bf16x2(a.z, a.w);
+            w.x = pack_bf16x2(a[i].x, a[i].y);
+            w.y = pack_bf16x2(a[i].z, a[i].w);
             *reinterpret_cast<uint2*>(g + c) = w;
             if (p.cls_tokenize) {
                 const float4 t = *reinterpret_cast<const float4*>(tok + c);
-                w.x = pack_bf16x2(a.x * t.x, a.y * t.y);
-                w.y = pack_bf16x2(a.z * t.z, a.w * t.w);
+                w.x = pack_bf16x2(a[i].x * t.x, a[i].y * t.y);
+                w.y = pack_bf16x2(a[i].z * t.z, a[i].w * t.w);
                 *reinterpret_cast<uint2*>(g + D + c) = w;
             }
-            if (!with_cont) continue;
-            const float4 p0 = *reinterpret_cast<const float4*>(pr + c);
-            const float4 p1 = *reinterpret_cast<const float4*>(pr + D + c);
-            const float4 p2 = *reinterpret_cast<const float4*>(pr + 2 * D + c);
-            xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-            d0 += a.x * p0.x + a.y * p0.y + a.z * p0.z + a.w * p0.w;
-            d1 += a.x * p1.x + a.y * p1.y + a.z * p1.z + a.w * p1.w;
-            d2 += a.x * p2.x + a.y * p2.y + a.z * p2.z + a.w * p2.w;
-            n0 += p0.x * p0.x + p0.y * p0.y + p0.z * p0.z + p0.w * p0.w;
-            n1 += p1.x * p1.x + p1.y * p1.y + p1.z * p1.z + p1.w * p1.w;
-            n2 += p2.x * p2.x + p2.y * p2.y + p2.z * p2.z + p2.w * p2.w;
+            if (with_cont) {
+                xx += a[i].x * a[i].x + a[i].y * a[i].y + a[i].z * a[i].z + a[i].w * a[i].w;
+                d0 += a[i].x * p0[i].x + a[i].y * p0[i].y + a[i].z * p0[i].z + a[i].w * p0[i].w;
+                d1 += a[i].x * p1[i].x + a[i].y * p1[i].y + a[i].z * p1[i].z + a[i].w * p1[i].w;
+                d2 += a[i].x * p2[i].x + a[i].y * p2[i].y + a[i].z * p2[i].z + a[i].w * p2[i].w;
+                n0 += p0[i].x * p0[i].x + p0[i].y * p0[i].y + p0[i].z * p0[i].z + p0[i].w * p0[i].w;
+                n1 += p1[i].x * p1[i].x + p1[i].y * p1[i].y + p1[i].z * p1[i].z + p1[i].w * p1[i].w;
+                n2 += p2[i].x * p2[i].x + p2[i].y * p2[i].y + p2[i].z * p2[i].z + p2[i].w * p2[i].w;
+            }
         }
     }
     if (is_search && with_cont) {
@@ -663,27 +712,26 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) 
         n0 = fmaxf(sqrtf(wave_sum(n0)), 1e-12f);
         n1 = fmaxf(sqrtf(wave_sum(n1)), 1e-12f);
         n2 = fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
-        const float tau = __expf(p.logit_scale[0]);
+        const float tau = __expf(ls);
         const float c0 = tau * wave_sum(d0) / (xx * n0);
         const float c1 = tau * wave_sum(d1) / (xx * n1);
         const float c2 = tau * wave_sum(d2) / (xx * n2);
         if (lane == 0) write_cont(p, b, s, c0, c1, c2);
     }
-    if (is_search && p.ct_logits) {              // same arithmetic and order as contrast_kernel (the row is cache-hot)
+    if (is_search && p.ct_logits) {              // same arithmetic and order as contrast_kernel
         float sx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
-        for (int c = lane * 4; c < D; c += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(xr + c);
-            const float4 v = *reinterpret_cast<const float4*>(xb + c);
-            sx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-            xv += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
-            vv += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (!ok[i]) continue;
+            sx += a[i].x * a[i].x + a[i].y * a[i].y + a[i].z * a[i].z + a[i].w * a[i].w;
+            xv += a[i].x * v[i].x + a[i].y * v[i].y + a[i].z * v[i].z + a[i].w * v[i].w;
+            vv += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
             if (have_text) {
-                const float4 q = *reinterpret_cast<const float4*>(txt_tok + c);
-                xt += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
-                tt += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+                xt += a[i].x * q[i].x + a[i].y * q[i].y + a[i].z * q[i].z + a[i].w * q[i].w;
+                tt += q[i].x * q[i].x + q[i].y * q[i].y + q[i].z * q[i].z + q[i].w * q[i].w;
             }
         }
-        const float tau = __expf(p.ct_logit_scale[0]);
+        const float tau = __expf(cls);
         sx = fmaxf(sqrtf(wave_sum(sx)), 1e-12f);
         vv = fmaxf(sqrtf(wave_sum(vv)), 1e-12f);
         const float lv = tau * wave_sum(xv) / (sx * vv);
@@ -700,7 +748,14 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) 
 hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s) {
     const int rows = p.cont_only ? p.nx : (p.skip_text ? p.nv : p.nj);
     if (p.cont_only && (!p.o_search || !p.prompt || !p.o_cont)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_prep_kernel, dim3((rows + 3) / 4, p.B), dim3(256), 2 * p.D * sizeof(float), s, p);
+    if (p.D % 4 != 0 || p.D > 1024) return hipErrorInvalidValue;
+    const dim3 grid((rows + 3) / 4, p.B), block(256);
+    const size_t lds = 2 * p.D * sizeof(float);
+    if (p.D == 768) hipLaunchKernelGGL((head_prep_kernel<3, true>), grid, block, lds, s, p);
+    else if (p.D == 1024) hipLaunchKernelGGL((head_prep_kernel<4, true>), grid, block, lds, s, p);
+    else if (p.D <= 256) hipLaunchKernelGGL((head_prep_kernel<1, false>), grid, block, lds, s, p);
+    else if (p.D <= 768) hipLaunchKernelGGL((head_prep_kernel<3, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((head_prep_kernel<4, false>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -708,28 +763,60 @@ hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s) {
 // Head tail.  One workgroup per sample: the four 1x1 convs on the 32-channel tower outputs, sigmoids,
 // size-map select by flag (head:80-82), convert2bbox (head:108-119) and the argmax over S.
 // ------------------------------------------------------------------------------------------------
+// C8 == 32 (HEAD_DIM 256): a position's 4 x 32 tower outputs, its cont_score row and grid coordinates are fetched with 16-byte
+// loads before anything else and the 1x1 weights are staged meanwhile -- one memory round trip for the sample's single
+// workgroup instead of one per channel group; C8 == 0: any width, plain loops.
+template <int C8>
 __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) {
     extern __shared__ float shw[];              // [7*c8] weights, [8] bias
     __shared__ float red_v[256];
     __shared__ int red_i[256];
-    const int b = blockIdx.x, c8 = p.c8;
+    const int b = blockIdx.x, c8 = C8 ? C8 : p.c8;
+    constexpr int NG = C8 ? C8 / 2 : 1;         // 16-byte groups of a position's 4 * C8 bf16 values
+    uint4 gv[NG];
+    float cs[3], gx = 0.f, gy = 0.f;
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+        const float* cr = p.cont + ((size_t)b * p.S + s) * p.cont_ch;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cs[k] = cr[k < p.cont_ch ? k : 0];
+        gx = p.coord[s];
+        gy = p.coord[p.S + s];
+        if constexpr (C8 != 0) {
+            const uint4* g = reinterpret_cast<const uint4*>(p.g4 + ((size_t)b * p.S + s) * p.ld);
+#pragma unroll
+            for (int q = 0; q < NG; ++q) gv[q] = g[q];
+        }
+    };
+    if ((int)threadIdx.x < p.S) fetch(threadIdx.x);
+    const int fl = (int)p.flag[b];
     for (int i = threadIdx.x; i < 7 * c8; i += 256) shw[i] = p.w1[i];
     if (threadIdx.x < 7) shw[7 * c8 + threadIdx.x] = p.b1[threadIdx.x];
     __syncthreads();
     const float* bias = shw + 7 * c8;
-    const int fl = (int)p.flag[b];
     float best = -INFINITY;
     int best_i = 0x7fffffff;
+    float4 best_bb = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = threadIdx.x; s < p.S; s += 256) {
-        const bf16_t* g = p.g4 + ((size_t)b * p.S + s) * p.ld;
+        if (s != (int)threadIdx.x) fetch(s);
         float o[7];
         // tower t reads channels [t*c8, (t+1)*c8); outputs: 0 cls | 1,2 offset | 3,4 bbox | 5,6 bbox_grounding
-        const int tower_of[7] = {0, 1, 1, 2, 2, 3, 3};
+        constexpr int tower_of[7] = {0, 1, 1, 2, 2, 3, 3};
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             float acc = bias[k];
-            const bf16_t* gt = g + tower_of[k] * c8;
-            for (int c = 0; c < c8; ++c) acc += bf2f(gt[c]) * shw[k * c8 + c];
+            if constexpr (C8 != 0) {
+#pragma unroll
+                for (int c = 0; c < C8; ++c) {
+                    const int e = tower_of[k] * C8 + c;
+                    const uint4 u = gv[e / 8];
+                    const uint32_t w = (e % 8) / 2 == 0 ? u.x : ((e % 8) / 2 == 1 ? u.y : ((e % 8) / 2 == 2 ? u.z : u.w));
+                    const float gval = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+                    acc += gval * shw[k * C8 + c];
+                }
+            } else {
+                const bf16_t* gt = p.g4 + ((size_t)b * p.S + s) * p.ld + tower_of[k] * c8;
+                for (int c = 0; c < c8; ++c) acc += bf2f(gt[c]) * shw[k * c8 + c];
+            }
             o[k] = acc;
         }
         const float cls = sigmoidf_(o[0]);
@@ -737,25 +824,22 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) 
         const float oy = p.offset_sigmoid ? sigmoidf_(o[2]) : o[2];
         const float w = fl == 1 ? sigmoidf_(o[5]) : sigmoidf_(o[3]);
         const float h = fl == 1 ? sigmoidf_(o[6]) : sigmoidf_(o[4]);
-        const float* cs = p.cont + ((size_t)b * p.S + s) * p.cont_ch;
         float mx = cs[0];
-        for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k]);
+        for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k < 3 ? k : 0]);
         float den = 0.f;
-        for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k] - mx);
+        for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k < 3 ? k : 0] - mx);
         const float p0 = __expf(cs[0] - mx) / den;
         const float score = cls * p0;
         const size_t bs = (size_t)b * p.S + s;
         if (p.o_cls_test) p.o_cls_test[bs] = cls;
         if (p.o_cls) p.o_cls[bs] = p.joint_cls ? score : cls;
-        if (p.o_bbox_map) {
-            float4 bb;
-            bb.x = (p.coord[s] + ox) / (float)p.F;
-            bb.y = (p.coord[p.S + s] + oy) / (float)p.F;
-            bb.z = w;
-            bb.w = h;
-            *reinterpret_cast<float4*>(p.o_bbox_map + bs * 4) = bb;
-        }
-        if (score > best) { best = score; best_i = s; }
+        float4 bb;
+        bb.x = (gx + ox) / (float)p.F;
+        bb.y = (gy + oy) / (float)p.F;
+        bb.z = w;
+        bb.w = h;
+        if (p.o_bbox_map) *reinterpret_cast<float4*>(p.o_bbox_map + bs * 4) = bb;
+        if (score > best) { best = score; best_i = s; best_bb = bb; }
     }
     red_v[threadIdx.x] = best;
     red_i[threadIdx.x] = best_i;
@@ -771,14 +855,24 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) 
         }
         __syncthreads();
     }
-    __threadfence_block();
-    const int win = red_i[0] < p.S ? red_i[0] : 0;
-    if (threadIdx.x < 4 && p.o_pred && p.o_bbox_map) p.o_pred[(size_t)b * 4 + threadIdx.x] = p.o_bbox_map[((size_t)b * p.S + win) * 4 + threadIdx.x];
+    const bool found = red_i[0] < p.S;           // false only when no score compared greater than -inf (NaN everywhere): position 0
+    const int win = found ? red_i[0] : 0;
+    if (p.o_pred && p.o_bbox_map) {
+        // the winner is some thread's own best (strict >, lowest index first): that thread still holds its box
+        if (found && best_i == win) *reinterpret_cast<float4*>(p.o_pred + (size_t)b * 4) = best_bb;
+        if (!found && threadIdx.x == 0) {
+            // thread 0 computed position 0 itself in its first iteration; its store is visible to itself
+            *reinterpret_cast<float4*>(p.o_pred + (size_t)b * 4) = *reinterpret_cast<const float4*>(p.o_bbox_map + (size_t)b * p.S * 4);
+        }
+    }
     if (threadIdx.x == 0 && p.o_argmax) p.o_argmax[b] = win;
 }
 
 hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(head_tail_kernel, dim3(p.B), dim3(256), (7 * p.c8 + 8) * sizeof(float), s, p);
+    const size_t lds = (7 * p.c8 + 8) * sizeof(float);
+    if (p.cont_ch < 1 || p.cont_ch > 3) return hipErrorInvalidValue;
+    if (p.c8 == 32 && p.ld % 8 == 0) hipLaunchKernelGGL(head_tail_kernel<32>, dim3(p.B), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(head_tail_kernel<0>, dim3(p.B), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
