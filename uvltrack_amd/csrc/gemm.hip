@@ -80,9 +80,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // per lane: every store instruction covers whole 128-byte lines (measured on the fc1 shape at M = 17.7k,
 // tools/probes/gemm_probe.hip: 112 us, against 124 us for element-per-lane stores and 141 us for 8 bytes per lane on
 // 32 different rows).  V^T of the QKV projection is token-contiguous and is stored straight from registers.
+//
+// The bias of the lane's columns is fetched by gemm_bias_preload at kernel start (it does not depend on the product): as
+// conditional loads inside the epilogue they were four dependent L2 round trips per launch, each behind its own s_waitcnt.
+__device__ uint32_t g_zero_page[256];     // 1 KB of zeros: DMA source of out-of-image conv taps (zero padding), absent bias
+
+template <int TN>
+__device__ __forceinline__ void gemm_bias_preload(const GemmParams& p, int colw, int lane, int g, int sk, f32x4 (&bv)[TN][4]) {
+    const float* bp = (p.bias && sk == 0) ? p.bias + (size_t)g * p.N + colw : reinterpret_cast<const float*>(g_zero_page);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(bp + j * 32 + 8 * q + 4 * (lane >> 5));
+}
+
 template <int TM, int TN, int WM, int WN, int EPI, int NW>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
-                                                  int lane, int wave, int g, int sk) {
+                                                  int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4]) {
+    const bool has_bias = p.bias && sk == 0;
     constexpr int ES = (EPI == EPI_F32) ? 4 : 2;               // output element size
     constexpr int RS = WN * ES + 16;                            // padded LDS row stride
     constexpr int LPR = WN * ES / 16;                           // lanes per row on the way out
@@ -103,11 +118,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     for (int q = 0; q < 4; ++q) {
                         const int col = colw + j * 32 + 8 * q + 4 * (lane >> 5);
                         const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
-                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][4 * q + e] + bv[e]);
+                            p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][4 * q + e] + (has_bias ? bv[j][q][e] : 0.f));
                     }
             }
             continue;
@@ -118,7 +131,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
             for (int q = 0; q < 4; ++q) {
                 const int cl = j * 32 + 8 * q + 4 * (lane >> 5);
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (p.bias && sk == 0) v += *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.N + colw + cl);
+                if (has_bias) v += bv[j][q];
                 if (EPI == EPI_F32) {
                     *reinterpret_cast<f32x4*>(cw + (lane & 31) * RS + cl * 4) = v;
                 } else {
@@ -133,20 +146,42 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     *reinterpret_cast<uint2*>(cw + (lane & 31) * RS + cl * 2) = o;
                 }
             }
+        if constexpr (EPI == EPI_F32) {
+            // the table / residual operands of all row groups are requested together (one wait), then added in the same order
+            constexpr int NIT = 32 / RPI;
+            f32x4 v[NIT], tv[NIT], ov[NIT];
+            float* dst[NIT];
+            bool inb[NIT];
+            const int c16 = lane % LPR, col = colw + c16 * (16 / ES);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = it * RPI + lane / LPR;
+                const int row = m0 + wm * WM + i * 32 + r;
+                inb[it] = row < p.M;
+                const int rc = inb[it] ? row : p.M - 1;
+                const int b = rc / p.rpb, rem = rc - b * p.rpb;
+                v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
+                dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
+                if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) ov[it] = *reinterpret_cast<const f32x4*>(dst[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (p.addtab) v[it] += tv[it];
+                if (p.accumulate) v[it] += ov[it];
+                if (inb[it]) *reinterpret_cast<f32x4*>(dst[it]) = v[it];
+            }
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
             const int r = it * RPI + lane / LPR, c16 = lane % LPR;
             const int row = m0 + wm * WM + i * 32 + r;
             const int col = colw + c16 * (16 / ES);
             if (EPI == EPI_F32) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
-                if (row < p.M) {
-                    const int b = row / p.rpb, rem = row - b * p.rpb;
-                    if (p.addtab) v += *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
-                    float* dst = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
-                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                }
             } else {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(cw + r * RS + c16 * 16);
                 if (row < p.M) {
@@ -295,7 +330,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-__device__ uint32_t g_zero_page[64];      // 256 zero bytes: DMA source of out-of-image conv taps (zero padding)
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk, const int g, char* smem) {
@@ -409,6 +443,9 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         }
     };
 
+    f32x4 bias_v[TN][4];
+    gemm_bias_preload<TN>(p, n0 + wn * WN, lane, g, sk, bias_v);     // older than every DMA: retired by the first tile wait
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -449,7 +486,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         }
     }
     static_assert(32 * (WN * 4 + 16) * NW <= NS * STAGE, "epilogue staging fits in the ring");
-    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk);
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
