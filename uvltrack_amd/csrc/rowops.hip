@@ -262,24 +262,34 @@ __device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                 float* __restrict__ x, int xbs, int xro, bf16_t* __restrict__ y,
                                                 int B, int T, int D, int vocab, int bx) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = bx * 4 + wave;
     if (m >= B * T) return;
     const int b = m / T, t = m - b * T;
-    long id = ids[m];
+    // the token id through the scalar cache (ids are < 2^31: the low word of the int64), then every row operand in one round trip
+    long id = (long)(int)sload_u32(ids + m);
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const float* wr = word + (size_t)id * D;
     const float* pr = pos + (size_t)t * D;
-    float4 v[NV];
+    float4 v[NV], qa[NV], ty[NV], g[NV], be[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c0 = (lane + 64 * i) * 4;
+        ok[i] = c0 < D;
+        const int c = ok[i] ? c0 : 0;
+        v[i] = *reinterpret_cast<const float4*>(wr + c);
+        qa[i] = *reinterpret_cast<const float4*>(pr + c);
+        ty[i] = *reinterpret_cast<const float4*>(type0 + c);
+        g[i] = *reinterpret_cast<const float4*>(gamma + c);
+        be[i] = *reinterpret_cast<const float4*>(beta + c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < D) {
-            const float4 a = *reinterpret_cast<const float4*>(wr + c);
-            const float4 q = *reinterpret_cast<const float4*>(pr + c);
-            const float4 ty = *reinterpret_cast<const float4*>(type0 + c);
-            v[i] = make_float4(a.x + q.x + ty.x, a.y + q.y + ty.y, a.z + q.z + ty.z, a.w + q.w + ty.w);
+        if (ok[i]) {
+            v[i] = make_float4(v[i].x + qa[i].x + ty[i].x, v[i].y + qa[i].y + ty[i].y, v[i].z + qa[i].z + ty[i].z, v[i].w + qa[i].w + ty[i].w);
             sum += v[i].x + v[i].y + v[i].z + v[i].w;
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -289,8 +299,7 @@ __device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids,
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < D) {
+        if (ok[i]) {
             const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
             sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
@@ -300,14 +309,12 @@ __device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids,
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
-        if (c < D) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        if (ok[i]) {
             float4 o;
-            o.x = (v[i].x - mean) * rstd * g.x + be.x;
-            o.y = (v[i].y - mean) * rstd * g.y + be.y;
-            o.z = (v[i].z - mean) * rstd * g.z + be.z;
-            o.w = (v[i].w - mean) * rstd * g.w + be.w;
+            o.x = (v[i].x - mean) * rstd * g[i].x + be[i].x;
+            o.y = (v[i].y - mean) * rstd * g[i].y + be[i].y;
+            o.z = (v[i].z - mean) * rstd * g[i].z + be[i].z;
+            o.w = (v[i].w - mean) * rstd * g[i].w + be[i].w;
             *reinterpret_cast<float4*>(xr + c) = o;
             uint2 w;
             w.x = pack_bf16x2(o.x, o.y);
@@ -347,17 +354,23 @@ __device__ __forceinline__ void setup_body(const uint8_t* __restrict__ tmask, co
                                            const float* __restrict__ cls_token, float* __restrict__ x,
                                            float* __restrict__ key_add, float* __restrict__ bert_add,
                                            int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what, int b) {
-    const int fl = (int)flag[b];
+    const int fl = (int)sload_u32(flag + b);                          // low word of the int64 flag
+    // the text mask is read unconditionally at a clamped index (no branch around the load, no wait per key group)
+    const uint8_t* tm = skip_text ? reinterpret_cast<const uint8_t*>(g_zero_row) : tmask + (size_t)b * T;
     if (what & 2) {
-        for (int t = threadIdx.x; t < 64; t += 256)
-            bert_add[(size_t)b * 64 + t] = (t < T) ? (tmask[(size_t)b * T + t] ? 0.f : -10000.f) : -INFINITY;
+        for (int t = threadIdx.x; t < 64; t += 256) {
+            const uint8_t mk = tm[t < T ? t : 0];
+            bert_add[(size_t)b * 64 + t] = (t < T) ? (mk ? 0.f : -10000.f) : -INFINITY;
+        }
     }
     if (!(what & 1)) return;
     for (int i = threadIdx.x; i < npad; i += 256) {
+        const int ti = i - nv;
+        const uint8_t mk = tm[ti < 0 ? 0 : (ti < T ? ti : T - 1)];
         float a;
         if (i < 1 + nz) a = (fl == 1) ? -1e10f : 0.f;                 // cls + template keys
         else if (i < nv) a = 0.f;                                     // search keys are never masked
-        else if (i < nj) a = (skip_text || fl == 0 || tmask[(size_t)b * T + (i - nv)] == 0) ? -1e10f : 0.f;
+        else if (i < nj) a = (skip_text || fl == 0 || mk == 0) ? -1e10f : 0.f;
         else a = -INFINITY;
         key_add[(size_t)b * npad + i] = a;
     }
@@ -905,55 +918,75 @@ hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_
 // Tracker decode on the device (lib/test/tracker/uvltrack.py:116-125,167-173 + box_ops.clip_box :117-126): replaces the
 // three .cpu() round trips per frame with one tiny kernel.  One workgroup per sample.
 // ------------------------------------------------------------------------------------------------
+// Every operand (the position's scores and box, the sample's state / scale / frame size) is requested before the first use; the
+// thread that owns the winning position finishes the box from its own registers.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
     __shared__ float red_v[256];
     __shared__ int red_i[256];
     const int b = blockIdx.x;
-    float best = -INFINITY;
+    const bool has_cont = p.cont != nullptr;
+    const float* st = p.state + (size_t)b * 4;
+    const float s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3];
+    const float rf = p.resize_factor[b];
+    const float H = p.image_hw[2 * b], W = p.image_hw[2 * b + 1];
+    float best = -INFINITY, best_pc = 1.f, best_cls = 0.f;
     int best_i = 0x7fffffff;
+    float4 best_net = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = threadIdx.x; s < p.S; s += 256) {
+        const size_t bs = (size_t)b * p.S + s;
+        const float* cr = has_cont ? p.cont + bs * p.cont_ch : p.cls + bs;      // valid address either way
+        float cs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cs[k] = cr[(has_cont && k < p.cont_ch) ? k : 0];
+        const float cl = p.cls[bs], wn = p.window[s];
+        const float4 net = *reinterpret_cast<const float4*>(p.bbox_map + bs * 4);
         float pc = 1.0f;
-        if (p.cont) {
-            const float* cs = p.cont + ((size_t)b * p.S + s) * p.cont_ch;
+        if (has_cont) {
             float mx = cs[0];
-            for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k]);
+            for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k < 3 ? k : 0]);
             float den = 0.f;
-            for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k] - mx);
+            for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k < 3 ? k : 0] - mx);
             pc = __expf(cs[0] - mx) / den;
         }
-        const float m = p.cls[(size_t)b * p.S + s] * p.window[s] * pc;
-        if (m > best) { best = m; best_i = s; }
+        const float m = cl * wn * pc;
+        if (m > best) { best = m; best_i = s; best_pc = pc; best_cls = cl; best_net = net; }
     }
     red_v[threadIdx.x] = best;
     red_i[threadIdx.x] = best_i;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) {
-            const float ov = red_v[threadIdx.x + st];
-            const int oi = red_i[threadIdx.x + st];
+    for (int stp = 128; stp > 0; stp >>= 1) {
+        if (threadIdx.x < stp) {
+            const float ov = red_v[threadIdx.x + stp];
+            const int oi = red_i[threadIdx.x + stp];
             if (ov > red_v[threadIdx.x] || (ov == red_v[threadIdx.x] && oi < red_i[threadIdx.x])) { red_v[threadIdx.x] = ov; red_i[threadIdx.x] = oi; }
         }
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
-    const int i = red_i[0] < p.S ? red_i[0] : 0;
-    const float* net = p.bbox_map + ((size_t)b * p.S + i) * 4;
-    float pc = 1.0f;
-    if (p.cont) {
-        const float* cs = p.cont + ((size_t)b * p.S + i) * p.cont_ch;
-        float mx = cs[0];
-        for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k]);
-        float den = 0.f;
-        for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k] - mx);
-        pc = __expf(cs[0] - mx) / den;
+    const bool found = red_i[0] < p.S;           // false only when nothing compared greater than -inf (NaN everywhere): position 0
+    const int i = found ? red_i[0] : 0;
+    if (found ? (best_i != i) : (threadIdx.x != 0)) return;
+    if (!found) {                                // thread 0 owns position 0: recompute its operands
+        const size_t bs = (size_t)b * p.S;
+        best_net = *reinterpret_cast<const float4*>(p.bbox_map + bs * 4);
+        best_cls = p.cls[bs];
+        best_pc = 1.0f;
+        if (has_cont) {
+            const float* cs = p.cont + bs * p.cont_ch;
+            float mx = cs[0];
+            for (int k = 1; k < p.cont_ch; ++k) mx = fmaxf(mx, cs[k]);
+            float den = 0.f;
+            for (int k = 0; k < p.cont_ch; ++k) den += __expf(cs[k] - mx);
+            best_pc = __expf(cs[0] - mx) / den;
+        }
     }
-    const float rf = p.resize_factor[b], sc = p.search_size / rf;
+    const float net[4] = {best_net.x, best_net.y, best_net.z, best_net.w};
+    const float pc = best_pc;
+    const float sc = p.search_size / rf;
     const float cx = net[0] * sc, cy = net[1] * sc, w = net[2] * sc, h = net[3] * sc;
-    const float* st = p.state + (size_t)b * 4;
     const float half_side = 0.5f * p.search_size / rf;
-    float x1 = cx + (st[0] + 0.5f * st[2] - half_side) - 0.5f * w;       // map_box_back
-    float y1 = cy + (st[1] + 0.5f * st[3] - half_side) - 0.5f * h;
-    const float H = p.image_hw[2 * b], W = p.image_hw[2 * b + 1], mg = p.margin;
+    float x1 = cx + (s0 + 0.5f * s2 - half_side) - 0.5f * w;       // map_box_back
+    float y1 = cy + (s1 + 0.5f * s3 - half_side) - 0.5f * h;
+    const float mg = p.margin;
     float x2 = x1 + w, y2 = y1 + h;                                       // clip_box
     x1 = fminf(fmaxf(0.f, x1), W - mg);
     x2 = fminf(fmaxf(mg, x2), W);
@@ -961,7 +994,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
     y2 = fminf(fmaxf(mg, y2), H);
     float* o = p.new_state + (size_t)b * 4;
     o[0] = x1; o[1] = y1; o[2] = fmaxf(mg, x2 - x1); o[3] = fmaxf(mg, y2 - y1);
-    if (p.score) p.score[b] = p.cls[(size_t)b * p.S + i] * pc;
+    if (p.score) p.score[b] = best_cls * pc;
     if (p.box_net) for (int k = 0; k < 4; ++k) p.box_net[(size_t)b * 4 + k] = net[k];
     if (p.index) p.index[b] = i;
 }
