@@ -23,7 +23,9 @@ __device__ __forceinline__ float4 sel4(bool c, const float4& a) { return c ? a :
 
 // FULL: D == NV * 256 (the real models): no column guard at all.  The row index is made wave-uniform explicitly, so the row's
 // addresses, the slab count and the pre-add selection live in scalar registers.
-template <int NV, bool FULL>
+// SLABS / CT: the launch has split-K slabs to fold / a contrastive job riding on it (host-known); without them their operand
+// slots cost neither registers nor load issue (batched frames: no slabs, LayerNorm is HBM-bound there).
+template <int NV, bool FULL, bool SLABS, bool CT>
 __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = bx * (int)(blockDim.x >> 6) + wave;     // one row per wave, blockDim.x / 64 rows per workgroup
@@ -33,12 +35,13 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     float* xr = const_cast<float*>(p.x) + xrow * p.D;
     const float* xin = (p.x_alt && t >= p.split) ? p.x_alt + ((size_t)b * p.x_alt_rows + (t - p.split)) * p.D : xr;
     const float* padd = (t < p.split) ? p.pre_add0 : p.pre_add1;
-    const int nsp = (t < p.part_rows) ? p.nsplit : 0;       // rows beyond part_rows were not produced by that GEMM
+    const int nsp = (SLABS && t < p.part_rows) ? p.nsplit : 0;       // rows beyond part_rows were not produced by that GEMM
     const size_t pm = (size_t)b * p.part_rows + t;           // compact row index inside a slab
     // ---- phase 1: every load of the row, no use in between ----
+    constexpr int NSL = SLABS ? LN_MAX_SLABS : 0;
     const float* slab[LN_MAX_SLABS];
 #pragma unroll
-    for (int sp = 0; sp < LN_MAX_SLABS; ++sp)
+    for (int sp = 0; sp < NSL; ++sp)
         slab[sp] = (sp < nsp) ? p.part + (size_t)sp * p.part_stride + pm * p.D : g_zero_row;
     const float* pa = padd ? padd : g_zero_row;
     float4 v[NV], sl[NV][LN_MAX_SLABS], ad[NV], g[NV], be[NV];
@@ -50,13 +53,13 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
         const int c = ok[i] ? c0 : 0;
         v[i] = *reinterpret_cast<const float4*>(xin + c);
 #pragma unroll
-        for (int sp = 0; sp < LN_MAX_SLABS; ++sp) sl[i][sp] = *reinterpret_cast<const float4*>(slab[sp] + c);
+        for (int sp = 0; sp < NSL; ++sp) sl[i][sp] = *reinterpret_cast<const float4*>(slab[sp] + c);
         ad[i] = *reinterpret_cast<const float4*>(pa + c);
         g[i] = *reinterpret_cast<const float4*>(p.gamma + c);
         be[i] = *reinterpret_cast<const float4*>(p.beta + c);
     }
     // the second job's operands (contrastive logits of the previous layer, see below) are independent of the row: same round trip
-    const bool do_ct = p.ct_x && t >= 1 + p.ct_nz && t < p.ct_nv;
+    const bool do_ct = CT && p.ct_x && t >= 1 + p.ct_nz && t < p.ct_nv;
     float4 ca[NV], cv[NV], cq[NV];
     float ct_ls = 0.f;
     int ct_fl = 0;
@@ -83,7 +86,7 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
         const int c = (lane + 64 * i) * 4;
         v[i] = sel4(ok[i], v[i]);
 #pragma unroll
-        for (int sp = 0; sp < LN_MAX_SLABS; ++sp) {
+        for (int sp = 0; sp < NSL; ++sp) {
             const float4 a = sl[i][sp];
             const bool on = ok[i] && sp < nsp;
             v[i].x = on ? v[i].x + a.x : v[i].x; v[i].y = on ? v[i].y + a.y : v[i].y;
@@ -162,16 +165,16 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     }
 }
 
-template <int NV, bool FULL>
-__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) { ln_body<NV, FULL>(p, blockIdx.x); }
+template <int NV, bool FULL, bool SLABS, bool CT>
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) { ln_body<NV, FULL, SLABS, CT>(p, blockIdx.x); }
 
 // Two independent LayerNorm problems in one launch (batch-1 frames pair every text-branch kernel with the visual kernel
 // of the same kind, see uvl_api.hip): workgroups [0, split) work on pa, the rest on pb.
-template <int NV, bool FULL>
+template <int NV, bool FULL, bool SLABS, bool CT>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
-    if ((int)blockIdx.x < split) ln_body<NV, FULL>(pa, (int)blockIdx.x);
-    else ln_body<NV, FULL>(pb, (int)blockIdx.x - split);
+    if ((int)blockIdx.x < split) ln_body<NV, FULL, SLABS, CT>(pa, (int)blockIdx.x);
+    else ln_body<NV, FULL, SLABS, false>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
 }
 
 // Rows (= waves) per workgroup: 4.  One or two rows per workgroup measure the same within noise (1114 / 1119-1125 / 1122-1131
@@ -183,27 +186,46 @@ static int ln_waves_per_block(int) {
     return 4;
 }
 
+template <int NV, bool FULL>
+static void launch_ln_variant(const LnParams& p, int grid, int wpb, hipStream_t s) {
+    const bool slabs = p.nsplit > 0, ct = p.ct_x != nullptr;
+    if (slabs && ct) hipLaunchKernelGGL((ln_kernel<NV, FULL, true, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else if (slabs) hipLaunchKernelGGL((ln_kernel<NV, FULL, true, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else if (ct) hipLaunchKernelGGL((ln_kernel<NV, FULL, false, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else hipLaunchKernelGGL((ln_kernel<NV, FULL, false, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
+}
+
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
-    if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0 || p.nsplit > LN_MAX_SLABS) return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(p.M);
     const int grid = (p.M + wpb - 1) / wpb;
-    if (p.D == 768) hipLaunchKernelGGL((ln_kernel<3, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
-    else if (p.D == 1024) hipLaunchKernelGGL((ln_kernel<4, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
-    else if (p.D <= 256) hipLaunchKernelGGL((ln_kernel<1, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
-    else if (p.D <= 768) hipLaunchKernelGGL((ln_kernel<3, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
-    else hipLaunchKernelGGL((ln_kernel<4, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    if (p.D == 768) launch_ln_variant<3, true>(p, grid, wpb, s);
+    else if (p.D == 1024) launch_ln_variant<4, true>(p, grid, wpb, s);
+    else if (p.D <= 256) launch_ln_variant<1, false>(p, grid, wpb, s);
+    else if (p.D <= 768) launch_ln_variant<3, false>(p, grid, wpb, s);
+    else launch_ln_variant<4, false>(p, grid, wpb, s);
     return hipGetLastError();
 }
 
+template <int NV, bool FULL>
+static void launch_ln_pair_variant(const LnParams& a, const LnParams& b, int ga, int gb, int wpb, hipStream_t s) {
+    const bool slabs = a.nsplit > 0 || b.nsplit > 0, ct = a.ct_x != nullptr;
+    if (slabs && ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else if (slabs) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else if (ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+}
+
 hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s) {
-    if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0) return hipErrorInvalidValue;
+    if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0 || a.nsplit > LN_MAX_SLABS || b.nsplit > LN_MAX_SLABS || b.ct_x)
+        return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(a.M);
     const int ga = (a.M + wpb - 1) / wpb, gb = (b.M + wpb - 1) / wpb;
-    if (a.D == 768) hipLaunchKernelGGL((ln_pair_kernel<3, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
-    else if (a.D == 1024) hipLaunchKernelGGL((ln_pair_kernel<4, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
-    else if (a.D <= 256) hipLaunchKernelGGL((ln_pair_kernel<1, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
-    else if (a.D <= 768) hipLaunchKernelGGL((ln_pair_kernel<3, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
-    else hipLaunchKernelGGL((ln_pair_kernel<4, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    if (a.D == 768) launch_ln_pair_variant<3, true>(a, b, ga, gb, wpb, s);
+    else if (a.D == 1024) launch_ln_pair_variant<4, true>(a, b, ga, gb, wpb, s);
+    else if (a.D <= 256) launch_ln_pair_variant<1, false>(a, b, ga, gb, wpb, s);
+    else if (a.D <= 768) launch_ln_pair_variant<3, false>(a, b, ga, gb, wpb, s);
+    else launch_ln_pair_variant<4, false>(a, b, ga, gb, wpb, s);
     return hipGetLastError();
 }
 
