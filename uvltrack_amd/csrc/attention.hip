@@ -46,6 +46,9 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
     constexpr int LPW = KV_PER_WAVE + 1;                 // + one key_add DMA, issued only by the slot's owner wave (qw == 0)
     constexpr int NSM2 = NS >= 2 ? NS - 2 : 0;           // NS == 1: "single shot" -- every key tile of the head is resident at once
     static_assert((16 * KS) % NWAVES == 0 && LPW * NSM2 <= 63, "geometry");
+    // single shot with one query block: a wave stages the 16 pieces of ITS OWN key tile (piece index = compile-time constant, no
+    // K / V^T selection per instruction) and consumes nothing else before the merge -- no barrier in front of the tile either
+    constexpr bool OWN = (NS == 1 && QW == 1);
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,7 +76,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
     const bf16_t* src[KV_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < KV_PER_WAVE; ++i) {
-        const int g = wave + NWAVES * i, piece = g & 15;
+        const int g = OWN ? 16 * ks + i : wave + NWAVES * i, piece = OWN ? i : (g & 15);
         const int row = 8 * (piece & 7) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);               // logical chunk that belongs at this physical slot
         src[i] = (piece < 8) ? K + (size_t)row * 64 + chunk * 8 : Vt + (size_t)row * Npad + chunk * 8;
@@ -82,7 +85,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
         char* st = smem + (r % NS) * STAGE;
 #pragma unroll
         for (int i = 0; i < KV_PER_WAVE; ++i) {
-            const int g = wave + NWAVES * i, slot = g >> 4, piece = g & 15;
+            const int g = OWN ? 16 * ks + i : wave + NWAVES * i, slot = OWN ? ks : (g >> 4), piece = OWN ? i : (g & 15);
             int kt = r * KS + slot;
             kt = kt < nt ? kt : nt - 1;                                // tile does not exist: harmless re-read, never consumed
             const size_t off = (piece < 8) ? (size_t)kt * 64 * 64 : (size_t)kt * 64;
@@ -111,7 +114,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
         }
 #pragma unroll
         for (int i = 0; i < KV_PER_WAVE; ++i) {
-            const int g = wave + NWAVES * i, slot = g >> 4, piece = g & 15;
+            const int g = OWN ? 16 * ks + i : wave + NWAVES * i, slot = OWN ? ks : (g >> 4), piece = OWN ? i : (g & 15);
             const int k0 = (r * KS + slot) * 64;
             if (k0 < N && k0 + 64 > N) {                               // wave-uniform: only the tail tile
                 const int row = 8 * (piece & 7) + (lane >> 3);
@@ -175,7 +178,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
         }
         fixup(rd);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fix-up's LDS writes are done before the barrier
-        __builtin_amdgcn_s_barrier();
+        if (!OWN) __builtin_amdgcn_s_barrier();              // OWN: the tile was staged and fixed up by this wave alone
         if (NS >= 2 && rd + NS - 1 < rounds) issue(rd + NS - 1);     // its stage was last read in round rd-1
         if (rd * KS + ks < nt) {
             const char* sK = smem + (rd % NS) * STAGE + ks * SLOT;
