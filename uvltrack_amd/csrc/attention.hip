@@ -49,6 +49,10 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
     // single shot with one query block: a wave stages the 16 pieces of ITS OWN key tile (piece index = compile-time constant, no
     // K / V^T selection per instruction) and consumes nothing else before the merge -- no barrier in front of the tile either
     constexpr bool OWN = (NS == 1 && QW == 1);
+    // otherwise instruction i of wave w covers piece (w + NWAVES * i) & 15; when NWAVES divides 8, whether that is a K piece (< 8)
+    // or a V^T piece depends on i alone -- a compile-time choice per instruction instead of a per-wave select
+    constexpr bool P2 = (8 % NWAVES == 0);
+#define ATTN_IS_K(i, piece) (OWN ? ((i) < 8) : (P2 ? (((i) % (16 / NWAVES)) < (8 / NWAVES)) : ((piece) < 8)))
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,7 +83,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
         const int g = OWN ? 16 * ks + i : wave + NWAVES * i, piece = OWN ? i : (g & 15);
         const int row = 8 * (piece & 7) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);               // logical chunk that belongs at this physical slot
-        src[i] = (piece < 8) ? K + (size_t)row * 64 + chunk * 8 : Vt + (size_t)row * Npad + chunk * 8;
+        src[i] = ATTN_IS_K(i, piece) ? K + (size_t)row * 64 + chunk * 8 : Vt + (size_t)row * Npad + chunk * 8;
     }
     auto issue = [&](int r) __attribute__((always_inline)) {
         char* st = smem + (r % NS) * STAGE;
@@ -88,7 +92,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
             const int g = OWN ? 16 * ks + i : wave + NWAVES * i, slot = OWN ? ks : (g >> 4), piece = OWN ? i : (g & 15);
             int kt = r * KS + slot;
             kt = kt < nt ? kt : nt - 1;                                // tile does not exist: harmless re-read, never consumed
-            const size_t off = (piece < 8) ? (size_t)kt * 64 * 64 : (size_t)kt * 64;
+            const size_t off = ATTN_IS_K(i, piece) ? (size_t)kt * 64 * 64 : (size_t)kt * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + off),
                                              (__attribute__((address_space(3))) void*)(st + slot * SLOT + piece * 1024), 16, 0, 0);
         }
@@ -119,7 +123,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
             if (k0 < N && k0 + 64 > N) {                               // wave-uniform: only the tail tile
                 const int row = 8 * (piece & 7) + (lane >> 3);
                 char* at = st + slot * SLOT + piece * 1024 + lane * 16;
-                if (piece < 8) {
+                if (ATTN_IS_K(i, piece)) {
                     if (k0 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
                 } else {
                     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
