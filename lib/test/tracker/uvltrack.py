@@ -51,6 +51,7 @@ class UVLTrack(BaseTracker):
         self.max_query_len = self.cfg.MODEL.BACKBONE.LANGUAGE.BERT.MAX_QUERY_LEN
         self._uploader = None
         self._meta_host = None
+        self._res_host = None
 
     # ------------------------------------------------------------------ helpers
     def _tok(self):
@@ -90,15 +91,26 @@ class UVLTrack(BaseTracker):
         half_side = 0.5 * self.params.search_size / resize_factor
         return [cx + (cx_prev - half_side) - 0.5 * w, cy + (cy_prev - half_side) - 0.5 * h, w, h]
 
-    def _search_image(self, image, box, factor, size):
-        """Normalised crop [1,3,size,size] + resize factor: crop window upload for host frames, full-frame kernel for device frames."""
+    def _search_image(self, image, box, factor, size, with_meta=False):
+        """Normalised crop [1,3,size,size] + resize factor: crop window upload for host frames, full-frame kernel for device frames.
+        `with_meta`: also the decode kernel's operands (box, resize factor, frame size) as a device tensor [7] -- for host frames
+        they ride in the window upload."""
         if isinstance(image, np.ndarray):
             if self._uploader is None:
                 self._uploader = WindowUploader(max_side=2048, device=self.device)
-            r = self._uploader.sample_target(image, box, factor, size)
+            r = self._uploader.sample_target(image, box, factor, size, with_meta=with_meta)
         else:
             r = sample_target_fused(image, box, factor, size, want_patch=False, want_mask=False)
-        return r["image"], r["resize_factor"]
+        if not with_meta:
+            return r["image"], r["resize_factor"]
+        meta = r.get("meta")
+        if meta is None:
+            H, W = image.shape[:2]
+            if self._meta_host is None:
+                self._meta_host = torch.empty(7, dtype=torch.float32).pin_memory()
+            self._meta_host.copy_(torch.tensor([float(v) for v in box] + [float(r["resize_factor"]), float(H), float(W)], dtype=torch.float32))
+            meta = self._meta_host.to(self.device, non_blocking=True)
+        return r["image"], r["resize_factor"], meta
 
     # ------------------------------------------------------------------ tracker:45-62
     def grounding(self, image, info: dict):
@@ -159,19 +171,18 @@ class UVLTrack(BaseTracker):
     def track(self, image, info: dict = None):
         H, W, _ = image.shape
         self.frame_id += 1
-        search, resize_factor = self._search_image(image, self.state, self.params.search_factor, self.params.search_size)
+        # the decode operands (previous state, resize factor, frame size) travel with the crop window: one upload per frame
+        search, resize_factor, meta = self._search_image(image, self.state, self.params.search_factor, self.params.search_size, with_meta=True)
         with torch.no_grad():
             out_dict = self.network.forward_test(self.template, search, self.text, self.prompt, self.flag)
-            # argmax of cls * hann * softmax(cont)[0], box back to the frame, clip (tracker:116-125): one kernel, one read-back
-            # previous state, resize factor and frame size travel in ONE 7-float upload from pinned memory
-            if self._meta_host is None:
-                self._meta_host = torch.empty(7, dtype=torch.float32).pin_memory()
-            self._meta_host[:4] = torch.tensor(self.state, dtype=torch.float32)
-            self._meta_host[4], self._meta_host[5], self._meta_host[6] = float(resize_factor), float(H), float(W)
-            meta = self._meta_host.to(self.device, non_blocking=True)
-            new_state, score, box_net, idx = self.network.decode(out_dict, self._window_dev, meta[:4].reshape(1, 4), meta[4:5], meta[5:7].reshape(1, 2),
-                                                                 margin=10.0, has_cont=self.has_cont)
-            host = torch.cat([new_state.reshape(-1), score.reshape(-1), box_net.reshape(-1)]).cpu()
+            # argmax of cls * hann * softmax(cont)[0], box back to the frame, clip (tracker:116-125): one kernel that writes its nine
+            # floats straight into pinned host memory -- one stream synchronisation per frame, no read-back copy
+            if self._res_host is None:
+                self._res_host = torch.zeros(9, dtype=torch.float32).pin_memory()
+            _, _, _, idx = self.network.decode(out_dict, self._window_dev, meta[:4].reshape(1, 4), meta[4:5], meta[5:7].reshape(1, 2),
+                                               margin=10.0, has_cont=self.has_cont, host_out=self._res_host)
+            torch.cuda.current_stream(self.device).synchronize()
+            host = self._res_host.clone()
         self.state = [float(v) for v in host[:4]]
         score = float(host[4])
         pred_box_net = host[5:9].clone()

@@ -295,17 +295,25 @@ class HipEngine:
         self._keep_prompt = (tem, ctx, vis, txt, flag, tm, cm)
         return prompt
 
-    def decode(self, out_dict, window, state, resize_factor, image_hw, margin: float = 10.0, has_cont: bool = True):
-        """Tracker post-processing on the device (tracker:116-125): returns (new_state [B,4] xywh, score [B], box_net [B,4], idx [B])."""
+    def decode(self, out_dict, window, state, resize_factor, image_hw, margin: float = 10.0, has_cont: bool = True, host_out=None):
+        """Tracker post-processing on the device (tracker:116-125): returns (new_state [B,4] xywh, score [B], box_net [B,4], idx [B]).
+        `host_out`: a pinned float32 CPU tensor of 9*B elements -- the kernel then writes new_state | score | box_net straight into
+        host memory (valid after a stream synchronisation) and the returned tensors are views of it: no read-back copy."""
         cls = out_dict["cls_score_test"].to(torch.float32).contiguous()
         B = cls.shape[0]
         cont = out_dict["cont_score"].to(torch.float32).contiguous() if has_cont else None
         bbox = out_dict["bbox_map"].to(torch.float32).contiguous()
         f = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         window, state, resize_factor, image_hw = f(window).reshape(-1), f(state).reshape(B, 4), f(resize_factor).reshape(B), f(image_hw).reshape(B, 2)
-        new_state = torch.empty(B, 4, device=self.device)
-        score = torch.empty(B, device=self.device)
-        net = torch.empty(B, 4, device=self.device)
+        if host_out is not None:
+            if not (host_out.is_pinned() and host_out.dtype == torch.float32 and host_out.is_contiguous() and host_out.numel() >= 9 * B):
+                raise ValueError("host_out must be a pinned, contiguous float32 tensor with at least 9 * B elements")
+            flat = host_out.reshape(-1)
+            new_state, score, net = flat[:4 * B].view(B, 4), flat[4 * B:5 * B], flat[5 * B:9 * B].view(B, 4)
+        else:
+            new_state = torch.empty(B, 4, device=self.device)
+            score = torch.empty(B, device=self.device)
+            net = torch.empty(B, 4, device=self.device)
         idx = torch.empty(B, dtype=torch.int64, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(self.device):

@@ -150,11 +150,11 @@ class UVLTrack(nn.Module):
         out.pop("argmax", None)
         return out
 
-    def decode(self, out_dict, window, state, resize_factor, image_hw, margin: float = 10.0, has_cont: bool = True):
+    def decode(self, out_dict, window, state, resize_factor, image_hw, margin: float = 10.0, has_cont: bool = True, host_out=None):
         """The tracker's per-frame post-processing on the device (lib/test/tracker/uvltrack.py:116-125,167-173): returns
         (new_state [B,4] xywh, score [B], pred_box_net [B,4], index [B]) as device tensors."""
         eng = self._get_engine(out_dict["bbox_map"].device)
-        return eng.decode(out_dict, window, state, resize_factor, image_hw, margin=margin, has_cont=has_cont)
+        return eng.decode(out_dict, window, state, resize_factor, image_hw, margin=margin, has_cont=has_cont, host_out=host_out)
 
     def forward_prompt(self, out_dict, template_mask, context_mask):
         """Reference uvltrack.py:33-38: new (target, distractor, background) prompt from a forward_test output dict."""

@@ -84,7 +84,9 @@ class WindowUploader:
         self.max_side = max_side
 
     def sample_target(self, im: np.ndarray, target_bb, search_area_factor: float, output_sz: int, image_out: torch.Tensor = None,
-                      want_patch: bool = False, want_mask: bool = False):
+                      want_patch: bool = False, want_mask: bool = False, with_meta: bool = False):
+        """`with_meta`: the 7 floats the tracker's decode kernel needs -- target_bb (4), resize factor, frame H, frame W -- ride
+        behind the window bytes in the same host-to-device copy; returned as `meta` (float32 device tensor [7])."""
         if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
             raise ValueError("WindowUploader expects an HxWx3 uint8 numpy frame")
         lib = _native.load()
@@ -98,20 +100,31 @@ class WindowUploader:
         nbytes = wh * ww * 3
         stage = self.stage[:nbytes]
         np.copyto(stage.numpy().reshape(wh, ww, 3), im[y0:y1, x0:x1])   # host gather into pinned memory
-        dwin = self.dev[:nbytes]
-        dwin.copy_(stage, non_blocking=True)
         out = int(output_sz)
+        bb = [float(v) for v in (target_bb.tolist() if hasattr(target_bb, "tolist") else target_bb)]
+        meta = None
+        if with_meta:
+            off = (nbytes + 255) // 256 * 256
+            if off + 28 > self.stage.numel():
+                raise ValueError("crop window %dx%d leaves no room for the decode operands" % (ww, wh))
+            self.stage[off:off + 28].view(torch.float32).copy_(torch.tensor(bb + [out / float(g.crop_sz), float(H), float(W)], dtype=torch.float32))
+            self.dev[:off + 28].copy_(self.stage[:off + 28], non_blocking=True)
+            meta = self.dev[off:off + 28].view(torch.float32)
+            dwin = self.dev[:nbytes]
+        else:
+            dwin = self.dev[:nbytes]
+            dwin.copy_(stage, non_blocking=True)
         dev = self.dev.device
         patch = torch.empty((out, out, 3), dtype=torch.uint8, device=dev) if want_patch else None
         att = torch.empty((out, out), dtype=torch.uint8, device=dev) if want_mask else None
         norm = image_out if image_out is not None else torch.empty((1, 3, out, out), dtype=torch.float32, device=dev)
-        bb = [float(v) for v in (target_bb.tolist() if hasattr(target_bb, "tolist") else target_bb)]
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
         gg = _native.UvlCropGeometry()
         _native.check(lib.uvl_sample_target_window(ptr(dwin), x0, y0, ww, wh, ww * 3, H, W, (C.c_float * 4)(*bb),
                                                    float(search_area_factor), out, ptr(patch), ptr(norm), ptr(att), C.byref(gg), _stream()),
                       "uvl_sample_target_window")
-        return dict(patch=patch, image=norm, att_mask=att.bool() if att is not None else None, resize_factor=out / float(gg.crop_sz), geometry=gg)
+        return dict(patch=patch, image=norm, att_mask=att.bool() if att is not None else None, resize_factor=out / float(gg.crop_sz), geometry=gg,
+                    meta=meta)
 
 
 def sample_target(im, target_bb, search_area_factor, output_sz=None, mask=None, return_bbox=False):
