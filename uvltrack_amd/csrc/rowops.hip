@@ -177,13 +177,14 @@ __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const L
     else ln_body<NV, FULL, SLABS, false>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
 }
 
-// Rows (= waves) per workgroup: 4.  One or two rows per workgroup measure the same within noise (1114 / 1119-1125 / 1122-1131
-// frames/s for 4 / 1 / 2 at one sequence, identical at 32); UVL_LN_WPB = 1 | 2 | 4 overrides for experiments.
-static int ln_waves_per_block(int) {
+// Rows (= waves) per workgroup.  With one memory round trip per row, one sequence of UVLTrack-B (553 rows) is 1.5-2.6 % faster in
+// the frame with one row per workgroup (553 workgroups over the 256 CUs instead of 139: 1231-1243 vs 1212-1214 frames/s);
+// from 873 rows on (UVLTrack-L, two or more sequences) 1 and 4 measure the same.  UVL_LN_WPB = 1 | 2 | 4 overrides.
+static int ln_waves_per_block(int M) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("UVL_LN_WPB"); forced = e ? atoi(e) : 0; }
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return 4;
+    return M <= 768 ? 1 : 4;
 }
 
 template <int NV, bool FULL>
