@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
+// NTW: the weight tiles are requested non-temporal (aux = 2).  For the text-branch riders of a one-sequence frame (M = 40 rows: every
+// weight byte is read once, by one CU) -- see the note at gemm_glds_pair_kernel.
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk, const int g, char* smem) {
     constexpr int BK = 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -437,8 +439,12 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
                 const char* gp = (i < LPT_A ? ab : wb) + loff[i];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
+                if (NTW && i >= LPT_A)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                     (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                     (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
             }
         }
     };
@@ -498,6 +504,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmPar
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
 // visual GEMM of the same kind).  1-D grid: problem A owns [0, blocks_a) = tiles_a x splitk_a, problem B the rest; tile
 // counts are multiples of 8, so the workgroup -> XCD relation of both tile maps is preserved.
+// Problem B -- the rider -- loads its WEIGHT tiles non-temporal: the frame's weights (ViT 170 MB + BERT 85 MB + head 17 MB) do not fit
+// the 256 MB Infinity Cache together, and cycling through 273 MB evicts everything before its reuse in the next frame; the rider's
+// weights are read once, by one CU each, so taking them out of the allocation stream leaves the rest resident across frames
+// (measured on one box: 1207 -> 1282-1290 frames/s; non-temporal on ALL weights: no gain, and 1402 -> 1273 when the text branch
+// is reused, because the nine M tiles of a visual GEMM share each weight tile through L2).
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
         gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false>(pa, id - sk * tiles_a, sk, 0, smem);
     } else {
         const int id = (int)blockIdx.x - blocks_a, sk = id / tiles_b;
-        gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false>(pb, id - sk * tiles_b, sk, 0, smem);
+        gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false, true>(pb, id - sk * tiles_b, sk, 0, smem);
     }
 }
 
