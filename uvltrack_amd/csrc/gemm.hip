@@ -495,10 +495,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
+    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
 }
 
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false>
 static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
@@ -532,7 +532,7 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     else if (MT >= 16) p.group_m = 8;
     const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * 128;
-    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV>;
+    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -540,7 +540,7 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
+    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
@@ -577,6 +577,14 @@ int g_tune_gemm_gm = -1;
 
 template <int EPI>
 static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) {
+    if (p.w_stream) {                      // the configurations the text branch resolves to (M = 40 rows per sequence)
+        switch (cfg) {
+            case 4: return launch_glds<64, 64, 2, 2, EPI, 3, false, true>(p, s);
+            case 9: return launch_glds<128, 64, 2, 2, EPI, 2, false, true>(p, s);
+            case 10: return launch_glds<64, 128, 2, 2, EPI, 2, false, true>(p, s);
+            default: break;
+        }
+    }
     switch (cfg) {
         case 0: return launch_glds<64, 64, 2, 2, EPI, 4>(p, s);
         case 1: return launch_glds<128, 64, 2, 2, EPI, 4>(p, s);

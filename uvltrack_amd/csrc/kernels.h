@@ -28,6 +28,8 @@ struct GemmParams {
     int splitk = 1; size_t part_stride = 0;      // split-K: slab sk of C (f32, + sk*part_stride elements) holds partial sums of K-range sk
     int conv_F = 0, cin_g = 0;                   // conv mode: feature-map side, input channels per group
     int a_goff[4] = {0, 0, 0, 0};                // conv mode: channel offset of each group's input inside a row
+    int w_stream = 0;                            // 1: W is read once per frame and should not displace resident weights in the
+                                                 // Infinity Cache (text branch): non-temporal weight-tile loads where instantiated
     int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
 };
