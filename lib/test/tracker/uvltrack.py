@@ -52,6 +52,11 @@ class UVLTrack(BaseTracker):
         self._uploader = None
         self._meta_host = None
         self._res_host = None
+        self._step = None            # forward_test bound to this sequence's buffers (model.make_frame_step)
+        self._step_key = None
+        self._search_buf = None
+        self._prompt_buf = None
+        self._prompt_src = None
 
     # ------------------------------------------------------------------ helpers
     def _tok(self):
@@ -91,16 +96,16 @@ class UVLTrack(BaseTracker):
         half_side = 0.5 * self.params.search_size / resize_factor
         return [cx + (cx_prev - half_side) - 0.5 * w, cy + (cy_prev - half_side) - 0.5 * h, w, h]
 
-    def _search_image(self, image, box, factor, size, with_meta=False):
+    def _search_image(self, image, box, factor, size, with_meta=False, image_out=None):
         """Normalised crop [1,3,size,size] + resize factor: crop window upload for host frames, full-frame kernel for device frames.
         `with_meta`: also the decode kernel's operands (box, resize factor, frame size) as a device tensor [7] -- for host frames
         they ride in the window upload."""
         if isinstance(image, np.ndarray):
             if self._uploader is None:
                 self._uploader = WindowUploader(max_side=2048, device=self.device)
-            r = self._uploader.sample_target(image, box, factor, size, with_meta=with_meta)
+            r = self._uploader.sample_target(image, box, factor, size, with_meta=with_meta, image_out=image_out)
         else:
-            r = sample_target_fused(image, box, factor, size, want_patch=False, want_mask=False)
+            r = sample_target_fused(image, box, factor, size, want_patch=False, want_mask=False, image_out=image_out)
         if not with_meta:
             return r["image"], r["resize_factor"]
         meta = r.get("meta")
@@ -111,6 +116,26 @@ class UVLTrack(BaseTracker):
             self._meta_host.copy_(torch.tensor([float(v) for v in box] + [float(r["resize_factor"]), float(H), float(W)], dtype=torch.float32))
             meta = self._meta_host.to(self.device, non_blocking=True)
         return r["image"], r["resize_factor"], meta
+
+    def _frame_step(self):
+        """forward_test of this sequence as a pre-validated step on fixed buffers: the search crop is written into
+        `_search_buf` by the pre-processing kernel, the prompt lives in `_prompt_buf` (refreshed in place when it changes)."""
+        size = self.params.search_size
+        if self._search_buf is None or self._search_buf.shape[-1] != size:
+            self._search_buf = torch.empty(1, 3, size, size, dtype=torch.float32, device=self.device)
+            self._step = None
+        if self._prompt_buf is None or self._prompt_buf.shape != self.prompt.shape:
+            self._prompt_buf = torch.empty_like(self.prompt, dtype=torch.float32)
+            self._step = None
+        key = (self.template, self.text, self.flag)
+        if self._step is None or any(a is not b for a, b in zip(key, self._step_key)):
+            self._step = self.network.make_frame_step(self.template, self._search_buf, self.text, self._prompt_buf, self.flag)
+            self._step_key = key
+            self._prompt_src = None
+        if self._prompt_src is not self.prompt:          # new prompt (initialisation, update every UPDATE_INTERVAL frames)
+            self._prompt_buf.copy_(self.prompt)
+            self._prompt_src = self.prompt
+        return self._step
 
     # ------------------------------------------------------------------ tracker:45-62
     def grounding(self, image, info: dict):
@@ -172,9 +197,11 @@ class UVLTrack(BaseTracker):
         H, W, _ = image.shape
         self.frame_id += 1
         # the decode operands (previous state, resize factor, frame size) travel with the crop window: one upload per frame
-        search, resize_factor, meta = self._search_image(image, self.state, self.params.search_factor, self.params.search_size, with_meta=True)
+        step = self._frame_step()
+        search, resize_factor, meta = self._search_image(image, self.state, self.params.search_factor, self.params.search_size, with_meta=True,
+                                                         image_out=self._search_buf)
         with torch.no_grad():
-            out_dict = self.network.forward_test(self.template, search, self.text, self.prompt, self.flag)
+            out_dict = step()        # = self.network.forward_test(self.template, search, self.text, self.prompt, self.flag) on fixed buffers
             # argmax of cls * hann * softmax(cont)[0], box back to the frame, clip (tracker:116-125): one kernel that writes its nine
             # floats straight into pinned host memory -- one stream synchronisation per frame, no read-back copy
             if self._res_host is None:
@@ -190,7 +217,9 @@ class UVLTrack(BaseTracker):
 
         if score > self.max_score and self.has_cont:
             self.pred_box_net = pred_box_net
-            self.out_dict = out_dict
+            # the step hands out the same output tensors every frame: keep copies of what forward_prompt will read
+            self.out_dict = {k: (out_dict[k].clone() if k in ("template", "search", "vis_token", "txt_token") else out_dict[k])
+                             for k in ("template", "search", "vis_token", "txt_token", "flag")}
             self.max_score = score
             self.best_frame = self.frame_id
 

@@ -53,6 +53,7 @@ class HipEngine:
         self._ws_batch = 0
         self._graph_io = None
         self._text_primed = None                          # see _text_key
+        self._txt_owner = None
         self.weights_loaded = False
 
     def close(self):
@@ -94,7 +95,7 @@ class HipEngine:
             _native.check(self.lib.uvl_finalize_weights(self.handle, self._stream()), "uvl_finalize_weights")
         self.weights_loaded = True
         self._graph_io = None
-        self._text_primed = None
+        self._set_primed(None)
         return unknown
 
     # ------------------------------------------------------------------ forward
@@ -104,13 +105,20 @@ class HipEngine:
             self._ws = torch.empty(n + 256, dtype=torch.uint8, device=self.device)
             self._ws_batch = B
             self._graph_io = None
-            self._text_primed = None
-        if self._text_primed is not None and self._text_primed[0] != B:
-            self._text_primed = None                      # the workspace is carved per batch size: another B overwrites the kept rows
+            self._set_primed(None)
+        if getattr(self, "_ws_user_B", None) != B:
+            self._set_primed(None)                      # the workspace is carved per batch size: another B overwrites the kept rows
+            self._ws_user_B = B
         return self._ws
 
     # The text branch below the first fusion layer depends on the text alone; `forward(..., reuse_text=True)` skips it when the
     # workspace still holds the rows of a call with the very same text tensors (same objects, not modified since).
+    def _set_primed(self, key):
+        """Record whose text rows the workspace holds (None: unknown).  A pre-packed step (make_eager_step) owns them only while
+        nothing else has run on the workspace: `_txt_owner` is its token, cleared by every other user."""
+        self._text_primed = key
+        self._txt_owner = None
+
     @staticmethod
     def _text_key(B, ids, mask):
         return (B, ids, ids._version, mask, mask._version)
@@ -186,7 +194,7 @@ class HipEngine:
                 outs = self.alloc_outputs(B)
             reuse = bool(reuse_text) and key is not None and self._text_matches(key)
             if key is not None:
-                self._text_primed = key                   # this call leaves (or keeps) that text's rows in the workspace
+                self._set_primed(key)                   # this call leaves (or keeps) that text's rows in the workspace
             i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text, reuse)
             n = self.lib.uvl_workspace_bytes(self.handle, B)
             if profile:
@@ -204,27 +212,41 @@ class HipEngine:
         return outs
 
     def make_eager_step(self, template, search, ids, mask, prompt, flag, skip_text: bool = False, outs=None, reuse_text: bool = False):
-        """Pre-validate the inputs once and return a zero-argument callable that enqueues one frame (the benchmark's
-        steady-state loop: same device buffers every step, no per-step Python work besides one ctypes call).  `reuse_text`: one
-        full frame is run here, every step then reuses its text branch."""
-        if reuse_text and not skip_text:
-            outs = self.forward(template, search, ids, mask, prompt, flag, outs=outs)
+        """Pre-validate the inputs once and return a zero-argument callable that enqueues one frame on the SAME device buffers
+        every time (the benchmark's steady-state loop, the tracker's per-frame call): no per-step Python work besides one ctypes
+        call.  `reuse_text`: the step recomputes the text branch only when something else has used the workspace since its last
+        call (first call included); otherwise it passes uvl_inputs.reuse_text."""
         template, search, ids, mask, prompt, flag = self._canon_inputs(template, search, ids, mask, prompt, flag)
         B = search.shape[0]
+        reuse_text = bool(reuse_text) and not skip_text and ids is not None
         with torch.cuda.device(self.device):
             ws = self._workspace(B)
             if outs is None:
                 outs = self.alloc_outputs(B)
-            i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text, reuse_text and not skip_text)
-            self._text_primed = None                      # the step's text is not tracked
+            i, o = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text, False)
+            i_reuse, _ = self._pack_io(template, search, ids, mask, prompt, flag, outs, skip_text, True)
             n = self.lib.uvl_workspace_bytes(self.handle, B)
         outs["flag"], outs["prompt"], outs["prompts"] = flag, prompt, prompt
-        keep = (template, search, ids, mask, prompt, flag, ws, outs, i, o)
-        fwd, h, wsp, bi, bo = self.lib.uvl_forward_test, self.handle, C.c_void_p(self._ws_ptr(ws)), C.byref(i), C.byref(o)
+        keep = (template, search, ids, mask, prompt, flag, ws, outs, i, i_reuse, o)
+        fwd, h, wsp, bo = self.lib.uvl_forward_test, self.handle, C.c_void_p(self._ws_ptr(ws)), C.byref(o)
+        bi_full, bi_reuse = C.byref(i), C.byref(i_reuse)
         stream = self._stream()
+        token = object()
+        eng = self
 
         def step(_keep=keep):
-            rc = fwd(h, bi, bo, wsp, n, stream)
+            if eng._ws is not ws:
+                raise _native.NativeLibraryError("the engine's workspace was reallocated (a larger batch ran): rebuild the step")
+            if getattr(eng, "_ws_user_B", None) != B:
+                eng._set_primed(None)                     # another batch size carved the workspace differently in between
+                eng._ws_user_B = B
+            if reuse_text and eng._txt_owner is token:
+                rc = fwd(h, bi_reuse, bo, wsp, n, stream)
+            else:
+                rc = fwd(h, bi_full, bo, wsp, n, stream)
+                if not skip_text:
+                    eng._set_primed(None)                 # this step's text rows are in the workspace now ...
+                    eng._txt_owner = token                # ... and stay valid until anything else runs on it
             if rc < 0:
                 _native.check(rc, "uvl_forward_test")
             return outs
@@ -254,7 +276,7 @@ class HipEngine:
             outs = self.alloc_outputs(B)
             outs["cont_score"] = torch.empty(B, s.nx, 2, dtype=torch.float32, device=self.device)
             prompts = torch.empty(B, 3, s.dim, dtype=torch.float32, device=self.device)
-            self._text_primed = None                      # this call's text branch overwrites the kept rows
+            self._set_primed(None)                      # this call's text branch overwrites the kept rows
             i, o = self._pack_io(template, search, ids, mask, dummy, flag, outs, False)
             n = self.lib.uvl_workspace_bytes(self.handle, B)
             p = lambda t: C.c_void_p(t.data_ptr())
@@ -344,7 +366,7 @@ class HipEngine:
                       mask=None if mask is None else mask.clone(), prompt=prompt.clone(), flag=flag.clone())
             outs = self.alloc_outputs(B)
             ws = self._workspace(B)
-            self._text_primed = None
+            self._set_primed(None)
             i, o = self._pack_io(st["template"], st["search"], st["ids"], st["mask"], st["prompt"], st["flag"], outs, skip_text)
             n = self.lib.uvl_workspace_bytes(self.handle, B)
             torch.cuda.synchronize(self.device)
@@ -356,6 +378,6 @@ class HipEngine:
     def replay(self):
         if self._graph_io is None:
             raise _native.NativeLibraryError("no captured graph")
-        self._text_primed = None
+        self._set_primed(None)
         _native.check(self.lib.uvl_graph_launch(self.handle, self._stream()), "uvl_graph_launch")
         return self._graph_io[1]

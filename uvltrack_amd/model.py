@@ -136,6 +136,25 @@ class UVLTrack(nn.Module):
         out.pop("argmax", None)
         return out
 
+    def make_frame_step(self, template, search, text, prompt, flag):
+        """forward_test bound to fixed device buffers: returns a zero-argument callable that enqueues one frame and returns the
+        output dict (the SAME tensors every call -- copy what must outlive the next call).  For per-frame loops that rewrite
+        `search` in place (the tracker classes): no argument checking, allocation or packing per frame.  Honours `cache_text`."""
+        if not search.is_cuda:
+            raise NativeLibraryError("make_frame_step needs tensors on a HIP device (got %s); there is no CPU fallback" % search.device)
+        eng = self._get_engine(search.device)
+        ids, mask = text.tensors, text.mask
+        if mask is None:
+            mask = torch.ones_like(ids)
+        step = eng.make_eager_step(template, search, ids, mask, prompt, flag, reuse_text=bool(getattr(self, "cache_text", False)))
+        weights_version = self._weights_version
+
+        def run():
+            if self._weights_version != weights_version or self._engine is not eng:
+                raise RuntimeError("the model's weights or device changed: build a new frame step")
+            return step()
+        return run
+
     def forward(self, template, search, text, template_mask, context_mask, flag):
         """Reference uvltrack.py:18-24 in eval mode -- the tracker's grounding call (lib/test/tracker/uvltrack.py:57).  The
         head takes its no-prompt branch: `cont_score` is [B,S,2], `prompts` the inline prompter's output.  Training
