@@ -173,6 +173,14 @@ int uvl_sample_target(const uint8_t* d_image, int height, int width, int row_str
 int uvl_sample_target_window(const uint8_t* d_window, int win_x0, int win_y0, int win_width, int win_height, int row_stride_bytes,
                              int frame_height, int frame_width, const float box_xywh[4], float search_area_factor, int output_sz,
                              uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, uvl_crop_geometry* geometry_out, void* stream);
+/* The window form with the upload included: the host has gathered the window rows (win_width * 3 bytes each, no padding) into
+ * pinned memory at h_stage + header_bytes; header_bytes + window bytes are copied to d_stage on `stream` in ONE transfer and the
+ * kernel then reads the window at d_stage + header_bytes.  The header (a multiple of 16 bytes, may be 0) is the caller's: the
+ * tracker puts the seven floats of uvl_decode's operands there so they need no upload of their own. */
+int uvl_sample_target_staged(const uint8_t* h_stage, uint8_t* d_stage, size_t header_bytes, int win_x0, int win_y0, int win_width,
+                             int win_height, int frame_height, int frame_width, const float box_xywh[4], float search_area_factor,
+                             int output_sz, uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, uvl_crop_geometry* geometry_out,
+                             void* stream);
 /* grounding_resize (lib/train/data/processing_utils.py:60-141; tracker:48): the whole frame resized with its aspect ratio
  * kept (long side = output_sz, OpenCV INTER_LINEAR -- see oracle/preprocess_oracle.py::grounding_resize on the reference's
  * swallowed `interpolation` argument), centred on a zero canvas; d_att_mask = 1 on the padding.

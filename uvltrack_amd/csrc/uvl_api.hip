@@ -1098,6 +1098,18 @@ extern "C" int uvl_sample_target_window(const uint8_t* d_window, int win_x0, int
                               search_area_factor, output_sz, d_patch_hwc, d_norm_chw, d_att_mask, geometry_out, stream);
 }
 
+extern "C" int uvl_sample_target_staged(const uint8_t* h_stage, uint8_t* d_stage, size_t header_bytes, int win_x0, int win_y0, int win_width,
+                                        int win_height, int frame_height, int frame_width, const float box_xywh[4], float search_area_factor,
+                                        int output_sz, uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask,
+                                        uvl_crop_geometry* geometry_out, void* stream) {
+    if (!h_stage || !d_stage || header_bytes % 16 != 0 || win_width <= 0 || win_height <= 0)
+        return fail(UVL_EINVAL, "uvl_sample_target_staged: bad argument");
+    const size_t nbytes = header_bytes + (size_t)win_width * win_height * 3;
+    HIPCHK(hipMemcpyAsync(d_stage, h_stage, nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return sample_target_impl(d_stage + header_bytes, win_x0, win_y0, win_width, win_height, win_width * 3, frame_height, frame_width, box_xywh,
+                              search_area_factor, output_sz, d_patch_hwc, d_norm_chw, d_att_mask, geometry_out, stream);
+}
+
 // grounding_resize (processing_utils.py:77-104 for the integer geometry; Python int() truncates towards zero)
 extern "C" int uvl_grounding_resize(const uint8_t* d_image, int height, int width, int row_stride_bytes, int output_sz,
                                     uint8_t* d_patch_hwc, float* d_norm_chw, uint8_t* d_att_mask, int32_t image_top_coords[4], void* stream) {

@@ -76,55 +76,55 @@ def sample_target_fused(im, target_bb, search_area_factor: float, output_sz: int
 
 class WindowUploader:
     """Uploads only the part of a host frame that a crop needs (about crop_sz^2 * 3 bytes instead of H*W*3) through a
-    pinned staging buffer, then runs the fused kernel on that window (`uvl_sample_target_window`)."""
+    pinned staging buffer, then runs the fused kernel on that window: gather on the host, ONE library call
+    (`uvl_sample_target_staged` = one host-to-device copy + one launch).  The first HEADER bytes of both buffers belong to the
+    caller's small operands (`with_meta`)."""
+
+    HEADER = 256
 
     def __init__(self, max_side: int = 2048, device="cuda"):
-        self.stage = torch.empty(max_side * max_side * 3, dtype=torch.uint8).pin_memory()     # flat: every window is one contiguous copy
-        self.dev = torch.empty(max_side * max_side * 3, dtype=torch.uint8, device=device)
+        n = self.HEADER + max_side * max_side * 3
+        self.stage = torch.empty(n, dtype=torch.uint8).pin_memory()       # flat: every window is one contiguous copy
+        self.dev = torch.empty(n, dtype=torch.uint8, device=device)
         self.max_side = max_side
+        self._stage_np = self.stage.numpy()                               # views made once: no tensor slicing per frame
+        self._meta_np = self._stage_np[:28].view(np.float32)
+        self._meta_dev = self.dev[:28].view(torch.float32)
+        self._h_ptr, self._d_ptr = C.c_void_p(self.stage.data_ptr()), C.c_void_p(self.dev.data_ptr())
 
     def sample_target(self, im: np.ndarray, target_bb, search_area_factor: float, output_sz: int, image_out: torch.Tensor = None,
                       want_patch: bool = False, want_mask: bool = False, with_meta: bool = False):
         """`with_meta`: the 7 floats the tracker's decode kernel needs -- target_bb (4), resize factor, frame H, frame W -- ride
-        behind the window bytes in the same host-to-device copy; returned as `meta` (float32 device tensor [7])."""
+        in the header of the same host-to-device copy; returned as `meta` (float32 device tensor [7], a view of the staging
+        buffer: valid until the next call)."""
         if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
             raise ValueError("WindowUploader expects an HxWx3 uint8 numpy frame")
         lib = _native.load()
         H, W = im.shape[:2]
-        g = crop_geometry(target_bb, search_area_factor, output_sz, H, W)
+        bb = [float(v) for v in (target_bb.tolist() if hasattr(target_bb, "tolist") else target_bb)]
+        g = crop_geometry(bb, search_area_factor, output_sz, H, W)
         x0, x1 = g.x1 + g.x1_pad, g.x1 + g.crop_sz - g.x2_pad
         y0, y1 = g.y1 + g.y1_pad, g.y1 + g.crop_sz - g.y2_pad
         ww, wh = x1 - x0, y1 - y0
         if ww > self.max_side or wh > self.max_side:
             raise ValueError("crop window %dx%d exceeds the staging buffer" % (ww, wh))
         nbytes = wh * ww * 3
-        stage = self.stage[:nbytes]
-        np.copyto(stage.numpy().reshape(wh, ww, 3), im[y0:y1, x0:x1])   # host gather into pinned memory
+        hdr = self.HEADER
+        np.copyto(self._stage_np[hdr:hdr + nbytes].reshape(wh, ww, 3), im[y0:y1, x0:x1])   # host gather into pinned memory
         out = int(output_sz)
-        bb = [float(v) for v in (target_bb.tolist() if hasattr(target_bb, "tolist") else target_bb)]
-        meta = None
         if with_meta:
-            off = (nbytes + 255) // 256 * 256
-            if off + 28 > self.stage.numel():
-                raise ValueError("crop window %dx%d leaves no room for the decode operands" % (ww, wh))
-            self.stage[off:off + 28].view(torch.float32).copy_(torch.tensor(bb + [out / float(g.crop_sz), float(H), float(W)], dtype=torch.float32))
-            self.dev[:off + 28].copy_(self.stage[:off + 28], non_blocking=True)
-            meta = self.dev[off:off + 28].view(torch.float32)
-            dwin = self.dev[:nbytes]
-        else:
-            dwin = self.dev[:nbytes]
-            dwin.copy_(stage, non_blocking=True)
+            self._meta_np[:] = (bb[0], bb[1], bb[2], bb[3], out / float(g.crop_sz), float(H), float(W))
         dev = self.dev.device
         patch = torch.empty((out, out, 3), dtype=torch.uint8, device=dev) if want_patch else None
         att = torch.empty((out, out), dtype=torch.uint8, device=dev) if want_mask else None
         norm = image_out if image_out is not None else torch.empty((1, 3, out, out), dtype=torch.float32, device=dev)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
         gg = _native.UvlCropGeometry()
-        _native.check(lib.uvl_sample_target_window(ptr(dwin), x0, y0, ww, wh, ww * 3, H, W, (C.c_float * 4)(*bb),
+        _native.check(lib.uvl_sample_target_staged(self._h_ptr, self._d_ptr, hdr, x0, y0, ww, wh, H, W, (C.c_float * 4)(*bb),
                                                    float(search_area_factor), out, ptr(patch), ptr(norm), ptr(att), C.byref(gg), _stream()),
-                      "uvl_sample_target_window")
+                      "uvl_sample_target_staged")
         return dict(patch=patch, image=norm, att_mask=att.bool() if att is not None else None, resize_factor=out / float(gg.crop_sz), geometry=gg,
-                    meta=meta)
+                    meta=self._meta_dev if with_meta else None)
 
 
 def sample_target(im, target_bb, search_area_factor, output_sz=None, mask=None, return_bbox=False):
