@@ -15,7 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     """'void uvl::gemm_glds_kernel<64, 64, 2, 2, 1, 3, false>(uvl::GemmParams)' -> 'gemm_glds_kernel<64,64,2,2,1,3,0>'"""
     n = name.split("(")[0].replace("void ", "").replace("uvl::", "").replace(" ", "")
-    return n.replace("false", "0").replace("true", "1")
+    n = n.replace("false", "0").replace("true", "1")
+    m = re.match(r"^(gemm_glds_kernel<\d+,\d+,\d+,\d+,\d+,\d+,\d+),(\d+)>$", n)
+    if m:          # the non-temporal-weights flag: written the way the library names its launches (bench.py keys on that name)
+        n = m.group(1) + (",nt>" if m.group(2) == "1" else ">")
+    return n
 
 
 def agg(path):
