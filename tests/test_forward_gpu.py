@@ -198,6 +198,39 @@ def test_reused_text_branch_is_bit_identical(name, batch):
         assert not torch.equal(got2["text"], want["text"])    # the sentence did matter
 
 
+@pytest.mark.parametrize("name,batch", [("tiny_mixed", None), ("b_z256_x256", 1)])
+def test_prevalidated_step_reprimes_its_text_branch(name, batch):
+    """make_eager_step(reuse_text=True): the step recomputes the text branch on its first call and whenever anything else has run
+    on the engine's workspace in between (another sentence, another batch size, the no-prompt forward); otherwise it reuses it.
+    Every call must equal the plain forward on the same inputs, bit for bit."""
+    meta, spec, _ = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    if batch is not None:
+        inp = {k: v[:batch].copy() for k, v in inp.items()}
+    eng = _engine(meta, spec)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inp.items()}
+    B = t["search"].shape[0]
+    keys = ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "text", "txt_token", "pred_boxes")
+    full = lambda: {k: v.clone() for k, v in eng.forward(t["template"], t["search"], t["ids"], t["mask"], t["prompt"], t["flag"]).items() if k in keys}
+    want = full()
+    step = eng.make_eager_step(t["template"], t["search"], t["ids"], t["mask"], t["prompt"], t["flag"], reuse_text=True)
+    same = lambda got: all(torch.equal(got[k], want[k]) for k in keys)
+    assert same(step())                                           # first call: full frame
+    assert eng._txt_owner is not None
+    assert same(step()) and same(step())                          # reused
+    other_ids = (t["ids"] + 5) % spec.vocab
+    eng.forward(t["template"], t["search"], other_ids, t["mask"], t["prompt"], t["flag"])     # someone else's sentence lands in the workspace
+    assert eng._txt_owner is None
+    assert same(step()) and same(step())                          # noticed, recomputed, then reused again
+    if B > 1:                                                     # another batch size carves the workspace differently
+        eng.forward(t["template"][:1], t["search"][:1], t["ids"][:1], t["mask"][:1], t["prompt"][:1], t["flag"][:1])
+        assert same(step()) and same(step())
+    g = torch.Generator().manual_seed(3)
+    t["search"].copy_(torch.randn(t["search"].shape, generator=g).cuda())     # next frame: the buffers the step is bound to are rewritten
+    want = full()
+    assert same(step()) and same(step())
+
+
 def test_cpu_tensors_fail_loudly():
     from uvltrack_amd import _native
     meta, spec, _ = load_case("tiny_mixed")
