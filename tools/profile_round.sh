@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
 cd $REPO
 python bench.py --steps 300 --warmup 50 --profile-json $O/bench_profile.json > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --batch 2 --steps 200 --warmup 30 --no-cpu-baseline > $O/bench_b2.json 2>/dev/null
+python bench.py --batch 4 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_b4.json 2>/dev/null
 python bench.py --batch 8 --steps 60 --warmup 10 --no-cpu-baseline --profile-json $O/bench_profile_b8.json > $O/bench_b8.json 2>/dev/null
 python bench.py --batch 32 --steps 30 --warmup 5 --no-cpu-baseline --profile-json $O/bench_profile_b32.json > $O/bench_b32.json 2>/dev/null
 python bench.py --model L --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_L.json 2>/dev/null
@@ -37,5 +39,5 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INST
 cd $REPO
 python tools/pmc_report.py $O/attn attn_kernel > $O/attn_pmc.txt 2>&1
 python tools/attn_bench.py > $O/attn_bench.txt 2>&1
-for f in default b8 b32 L L_b8 bbox bbox_notext reuse_text reuse_text_b8 nl z128 L_z128; do tail -1 $O/bench_$f.json | cut -c1-140; done
+for f in default b2 b4 b8 b32 L L_b8 bbox bbox_notext reuse_text reuse_text_b8 nl z128 L_z128; do tail -1 $O/bench_$f.json | cut -c1-140; done
 ls $O/stats $O/pmc_mfma | head -20
