@@ -53,7 +53,8 @@ class HipEngine:
         self._ws_batch = 0
         self._graph_io = None
         self._text_primed = None                          # see _text_key
-        self._txt_owner = None
+        self._txt_owner = None                            # see _set_primed
+        self._ws_user_B = None                            # batch size the workspace was last carved for
         self.weights_loaded = False
 
     def close(self):
@@ -106,7 +107,7 @@ class HipEngine:
             self._ws_batch = B
             self._graph_io = None
             self._set_primed(None)
-        if getattr(self, "_ws_user_B", None) != B:
+        if self._ws_user_B != B:
             self._set_primed(None)                      # the workspace is carved per batch size: another B overwrites the kept rows
             self._ws_user_B = B
         return self._ws
@@ -237,7 +238,7 @@ class HipEngine:
         def step(_keep=keep):
             if eng._ws is not ws:
                 raise _native.NativeLibraryError("the engine's workspace was reallocated (a larger batch ran): rebuild the step")
-            if getattr(eng, "_ws_user_B", None) != B:
+            if eng._ws_user_B != B:
                 eng._set_primed(None)                     # another batch size carved the workspace differently in between
                 eng._ws_user_B = B
             if reuse_text and eng._txt_owner is token:
