@@ -42,6 +42,7 @@ struct AttnParams {
     const float* key_add = nullptr; int key_add_stride = 0;   // [B, stride] additive per-key score term
     bf16_t* o = nullptr;                                      // [B*N, H*64]
     int B = 0, H = 0, N = 0, Npad = 0;
+    int xcd_map = 0;                                          // set by the launcher: query blocks of a head share an XCD (see attn_decode_block)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 hipError_t launch_attention_pair(const AttnParams& a, const AttnParams& b, hipStream_t s);   // b (few keys) rides on a's configuration
