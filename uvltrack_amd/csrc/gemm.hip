@@ -353,14 +353,15 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     const int xcd = bx & 7, idx = bx >> 3;
     int nt, mt;
     if (p.group_m == 0) {
-        // small M: an XCD owns whole N panels, so every weight byte enters exactly one L2; the few A rows are shared by all
+        // panel map (UVL_GEMM_GM=0 only; the default of the first builds): an XCD owns whole N panels, so every weight byte enters
+        // exactly one L2 -- but XCDs get unequal shares unless N / BN is a multiple of 8, see launch_glds
         nt = (idx / MT) * 8 + xcd;
         mt = idx % MT;
         if (nt >= NT) return;
     } else {
-        // large M: A is the bigger operand.  Tiles are ordered in groups of group_m M-tiles x all N-tiles (M fastest), the
-        // order is cut into 8 contiguous runs, one per XCD: the ~64 tiles resident on an XCD form a near-square patch, so
-        // its L2 holds group_m A tiles + a few W panels instead of re-streaming all of A once per N panel.
+        // Tiles are ordered in groups of group_m M-tiles x all N-tiles (M fastest) and the order is cut into 8 contiguous runs,
+        // one per XCD.  Large M (group_m = 8): the ~64 tiles resident on an XCD form a near-square patch, so its L2 holds 8 A
+        // tiles + a few W panels instead of re-streaming all of A once per N panel.  Few M tiles (group_m = MT): N-major order.
         const int T = MT * NT, base = T >> 3, rem = T & 7;
         const int cnt = base + (xcd < rem ? 1 : 0);
         if (idx >= cnt) return;
