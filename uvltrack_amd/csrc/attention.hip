@@ -439,11 +439,15 @@ static int pick_attn_cfg(const AttnParams& p) {
         // its 32-query workgroups fit the chip in one round; everything in between takes 64 queries x 2 key halves
         const long wg4 = (long)((p.N + 127) / 128) * p.H * p.B;
         const long wg1 = (long)((p.N + 31) / 32) * p.H * p.B;
+        const long wg2 = (long)((p.N + 63) / 64) * p.H * p.B;
         const int nt = (p.N + 63) / 64;
         if (wg4 >= 256 && nt >= 11) cfg = 3;         // long sequences (UVLTrack-L): a third ring stage pays (+4..8 %)
         else if (wg4 >= 256 || nt < 2) cfg = 0;
         else if (wg1 <= 288 && nt >= 5 && nt <= 6) cfg = 5;
         else if (wg1 <= 288 && nt >= 7 && nt <= 9) cfg = 6;
+        else if (wg2 <= 256 && nt >= 10) cfg = 7;    // one round of 64-query workgroups, 10+ key tiles (UVLTrack-L, one sequence): four key
+                                                     // quarters -- 14.8 -> 13.4 us at N = 873, 13.2 -> 10.9 at N = 681 in isolation, 0..+1.7 % on
+                                                     // the frame; two UVLTrack-B sequences (9 tiles) lose 3.6 % with it in the two-stream frame
         else cfg = 1;
     }
     return cfg;
@@ -457,6 +461,7 @@ hipError_t launch_attention_pair(const AttnParams& a, const AttnParams& b, hipSt
     // the rider must fit the configuration's key capacity: single-shot variants hold 6 / 9 key tiles, the ring variants any number
     switch (cfg) {
         case 1: return launch_attn_pair_cfg<2, 2, 2>(a, b, s);
+        case 7: return launch_attn_pair_cfg<2, 4, 2>(a, b, s);
         case 5: if (ntb <= 6) return launch_attn_pair_cfg<1, 6, 1>(a, b, s); break;
         case 6: if (ntb <= 9) return launch_attn_pair_cfg<1, 9, 1>(a, b, s); break;
         default: break;
@@ -476,6 +481,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 4: return launch_attn_cfg<1, 4, 3>(p, s);
         case 5: return launch_attn_cfg<1, 6, 1>(p, s);     // single shot, up to 6 key tiles (N <= 384)
         case 6: return launch_attn_cfg<1, 9, 1>(p, s);     // single shot, up to 9 key tiles (N <= 576): 150 KB of LDS
+        case 7: return launch_attn_cfg<2, 4, 2>(p, s);     // 64 queries x 4 key quarters (8 waves, 133 KB of LDS)
     }
     return hipErrorInvalidValue;
 }
