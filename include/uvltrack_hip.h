@@ -235,14 +235,19 @@ int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
 /* Fused multi-head self-attention core of Attention.forward (block.py:50-58) and BertSelfAttention
  * (bert_backbone.py:311-324): softmax(q k^T / sqrt(64) + key_add) v.
  * d_q, d_k: [B,H,Npad,64] bf16; d_vt: [B,H,64,Npad] bf16 (V transposed); d_key_add: [B,Npad] f32 additive
- * per-key term (-1e10 reproduces masked_fill for |score| < 512, -10000 is BERT's mask); d_o: [B*N, H*64] bf16. */
+ * per-key term (-1e10 reproduces masked_fill for |score| < 512, -10000 is BERT's mask); d_o: [B*N, H*64] bf16.
+ * q_prescaled != 0: d_q already carries the factor UVL_ATTN_QSCALE = log2(e)/sqrt(64) (the kernels work in the log2 domain;
+ * the frame's QKV projection applies it before rounding q to bf16, uvl_qkv_project with q_scale = UVL_ATTN_QSCALE does the
+ * same); 0: d_q is the plain projection and the kernel applies the factor itself. */
+#define UVL_ATTN_QSCALE 0.18033688011112042f
 int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o,
-                  int B, int H, int N, int Npad, void* stream);
+                  int B, int H, int N, int Npad, int q_prescaled, void* stream);
 
 /* QKV projection with the scatter epilogue the attention kernel consumes (block.py:49-50):
- * d_x [B*N, D] bf16, d_w [3D, D] bf16, d_bias [3D] f32 -> q,k [B,H,Npad,64], vt [B,H,64,Npad]. */
+ * d_x [B*N, D] bf16, d_w [3D, D] bf16, d_bias [3D] f32 -> q,k [B,H,Npad,64], vt [B,H,64,Npad]; q is multiplied by
+ * q_scale before it is rounded (1.0f = the plain projection). */
 int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
-                    int B, int N, int Npad, int D, void* stream);
+                    int B, int N, int Npad, int D, float q_scale, void* stream);
 
 /* nn.LayerNorm / BertLayerNorm over the last dim (block.py:30-31 eps 1e-6; bert_backbone.py:231-244 eps 1e-12).
  * d_x [M,D] f32 -> d_y_bf16 [M,D] bf16 (may be NULL) and d_y_f32 [M,D] f32 (may be NULL, may alias d_x). */

@@ -45,6 +45,12 @@ def cases():
     c["b_z128_x256"] = dict(spec=spec_b(128, 256), seed=0, in_seed=10, batch=3, flags=[0, 1, 2])
     c["b_z256_x256"] = dict(spec=spec_b(256, 256), seed=0, in_seed=11, batch=3, flags=[2, 0, 1])
     c["l_z128_x384"] = dict(spec=spec_l(128, 384), seed=0, in_seed=12, batch=2, flags=[2, 1])
+    # the batched regime (grouped GEMM tile order, 128-wide tiles, streaming attention kernel): 8 sequences, mixed flags, one
+    # sample whose text is all padding -- reference batches are independent (extractor.py:43-50,52-77), so this pins the
+    # kernels BASELINE configs[4] runs per GPU to the reference and not to this library's own one-sequence runs
+    c["b_z256_x256_b8"] = dict(spec=spec_b(256, 256), seed=0, in_seed=13, batch=8, flags=[2, 0, 1, 2, 2, 1, 0, 2], zero_text_rows=[5])
+    # UVLTrack-L at the north-star sizes (template 256, search 384: 833 -> 873 tokens)
+    c["l_z256_x384"] = dict(spec=spec_l(256, 384), seed=0, in_seed=14, batch=2, flags=[2, 0])
     return c
 
 
@@ -53,6 +59,8 @@ def case_inputs(case):
     inp = wg.make_inputs(spec, batch=case["batch"], seed=case["in_seed"], flags=case["flags"])
     if case.get("zero_text"):
         inp["mask"][1:, :] = False          # a sample whose text is entirely padding (edge case)
+    for r in case.get("zero_text_rows", ()):
+        inp["mask"][r, :] = False
     return inp
 
 
@@ -74,6 +82,7 @@ def run_case(name, case):
     out = {"meta": np.frombuffer(json.dumps({
         "name": name, "spec": spec.to_dict(), "weight_seed": case["seed"], "input_seed": case["in_seed"],
         "batch": case["batch"], "flags": case["flags"], "zero_text": bool(case.get("zero_text")),
+        "zero_text_rows": list(case.get("zero_text_rows", ())),
         "oracle_maxabs_dev": dev,
         "weight_checksums": {k: float(np.asarray(sd[k], dtype=np.float64).sum()) for k in
                              ("backbone.vit.blocks.0.attn.qkv.weight", "box_head.conv_cls.0.0.weight",

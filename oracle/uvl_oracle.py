@@ -15,6 +15,14 @@ atol 2e-4 (fp32 re-association only).
 
 Every function cites the reference file:line it restates.  Weights are a dict
 name -> float32 ndarray in the reference's state_dict schema.
+
+bf16-emulating mode (`with emulate_bf16(): ...` or `emulate_bf16=True` on the forward functions): the same
+restatement with the roundings of the HIP path inserted at the same places -- every GEMM / conv operand rounded to bf16
+(RNE), f32 accumulation, q scaled by log2(e)/8 before its rounding, the un-normalised softmax numerators rounded before
+P V, BatchNorm folded into the conv weights before their rounding, everything else (residual stream, LayerNorm, softmax,
+GELU, sigmoid, normalisations) in f32.  It separates quantisation from defects: HIP-vs-emulated is gated an order of
+magnitude tighter than HIP-vs-fp32 (tests/parity_util.py).  It is NOT pinned to the reference (there is no bf16
+reference); the fp32 mode is.
 """
 from __future__ import annotations
 
@@ -22,14 +30,44 @@ import numpy as np
 from scipy.special import erf as _erf
 
 f32 = np.float32
+_EMU = False          # bf16-emulating mode (see the module docstring)
+QSCALE = f32(0.18033688011112042)      # log2(e) / sqrt(64): the HIP attention kernels work in the log2 domain
+
+
+class emulate_bf16:
+    """Context manager: run the oracle with the HIP path's bf16 roundings."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _EMU
+        self.prev, _EMU = _EMU, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _EMU
+        _EMU = self.prev
+        return False
+
+
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even) -> float32, as v_cvt_pk_bf16_f32 rounds."""
+    u = np.ascontiguousarray(x, dtype=f32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(f32)
+
+
+def _r(x):
+    return bf16_round(x) if _EMU else x
 
 
 # --------------------------------------------------------------------------
 # primitives
 # --------------------------------------------------------------------------
 def linear(x, w, b=None):
-    """nn.Linear: y = x W^T + b, W is [out, in]."""
-    y = x @ w.T
+    """nn.Linear: y = x W^T + b, W is [out, in].  (bf16 mode: both operands rounded, f32 accumulate, f32 bias.)"""
+    y = _r(x) @ _r(w).T
     if b is not None:
         y = y + b
     return y.astype(f32, copy=False)
@@ -116,12 +154,32 @@ def vit_attention(sd, pre, x, key_mask, heads):
     hd = C // heads
     qkv = linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(B, N, 3, heads, hd).transpose(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    attn = (q @ k.transpose(0, 1, 3, 2)) * f32(hd ** -0.5)
-    if key_mask is not None:
-        attn = np.where(key_mask[:, None, None, :], f32(-1e10), attn)
-    attn = softmax(attn.astype(f32), -1)
-    o = (attn @ v).transpose(0, 2, 1, 3).reshape(B, N, C)
+    if _EMU:
+        o = _attention_bf16(q, k, v, None if key_mask is None else np.where(key_mask, f32(-1e10), f32(0.0)))
+    else:
+        attn = (q @ k.transpose(0, 1, 3, 2)) * f32(hd ** -0.5)
+        if key_mask is not None:
+            attn = np.where(key_mask[:, None, None, :], f32(-1e10), attn)
+        attn = softmax(attn.astype(f32), -1)
+        o = attn @ v
+    o = o.transpose(0, 2, 1, 3).reshape(B, N, C)
     return linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+
+
+def _attention_bf16(q, k, v, key_add):
+    """The fused attention of the HIP path (uvltrack_amd/csrc/attention.hip) with its roundings: q * log2(e)/8, k, v in
+    bf16; scores in the log2 domain (f32); numerators exp2(s - max) rounded to bf16 for P V, row sum over the f32
+    numerators; output rounded to bf16.  key_add [B, N] is the additive per-key term in the natural-log domain."""
+    hd = q.shape[-1]
+    assert hd == 64
+    qs = bf16_round(q * QSCALE)
+    s = qs @ bf16_round(k).transpose(0, 1, 3, 2)
+    if key_add is not None:
+        s = s + (key_add * f32(1.4426950408889634))[:, None, None, :]
+    s = s.astype(f32)
+    p = np.exp2(s - s.max(-1, keepdims=True)).astype(f32)
+    l = p.sum(-1, keepdims=True, dtype=f32)
+    return bf16_round((bf16_round(p) @ bf16_round(v)) / l)
 
 
 def vit_block(sd, i, x, key_mask, heads):
@@ -145,10 +203,13 @@ def bert_layer(sd, i, y, bert_mask, heads):
     q = split(linear(y, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"]))
     k = split(linear(y, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"]))
     v = split(linear(y, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"]))
-    s = (q @ k.transpose(0, 1, 3, 2)) / f32(np.sqrt(hd))
-    s = s + bert_mask
-    pr = softmax(s.astype(f32), -1)
-    ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, T, C)
+    if _EMU:
+        ctx = _attention_bf16(q, k, v, bert_mask[:, 0, 0, :]).transpose(0, 2, 1, 3).reshape(B, T, C)
+    else:
+        s = (q @ k.transpose(0, 1, 3, 2)) / f32(np.sqrt(hd))
+        s = s + bert_mask
+        pr = softmax(s.astype(f32), -1)
+        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, T, C)
     a = linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
     a = layer_norm(a + y, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], 1e-12)
     h = gelu(linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
@@ -221,6 +282,12 @@ def conv3x3_bn_relu(sd, pre, x):
     for kh in range(3):
         for kw in range(3):
             cols[:, :, :, :, kh, kw] = xp[:, :, kh:kh + H, kw:kw + W].transpose(0, 2, 3, 1)
+    if _EMU:     # BatchNorm folded into the weights before they are rounded (rowops.hip::fold_conv_bn_kernel), bf16 activations
+        scale = (sd[pre + "1.weight"] / np.sqrt(sd[pre + "1.running_var"] + f32(1e-5))).astype(f32)
+        wf = bf16_round(w * scale[:, None, None, None])
+        bf = ((b - sd[pre + "1.running_mean"]) * scale + sd[pre + "1.bias"]).astype(f32)
+        y = bf16_round(cols).reshape(B * H * W, C * 9) @ wf.reshape(w.shape[0], -1).T + bf
+        return np.maximum(y, f32(0.0)).astype(f32).reshape(B, H, W, -1).transpose(0, 3, 1, 2)
     y = cols.reshape(B * H * W, C * 9) @ w.reshape(w.shape[0], -1).T + b
     y = (y - sd[pre + "1.running_mean"]) / np.sqrt(sd[pre + "1.running_var"] + f32(1e-5)) * sd[pre + "1.weight"] + sd[pre + "1.bias"]
     y = np.maximum(y, f32(0.0)).astype(f32)
@@ -233,7 +300,7 @@ def tower(sd, name, x):
         x = conv3x3_bn_relu(sd, "box_head.%s.%d." % (name, l), x)
     w, b = sd["box_head.%s.4.weight" % name], sd["box_head.%s.4.bias" % name]
     B, C, H, W = x.shape
-    y = x.transpose(0, 2, 3, 1).reshape(-1, C) @ w.reshape(w.shape[0], C).T + b
+    y = _r(x).transpose(0, 2, 3, 1).reshape(-1, C) @ w.reshape(w.shape[0], C).T + b      # bf16 mode: bf16 activations, f32 1x1 weights
     return y.reshape(B, H, W, -1).transpose(0, 3, 1, 2).astype(f32)
 
 
@@ -312,17 +379,23 @@ def head_forward(sd, spec, out, prompt, cont=None):
     return res
 
 
-def forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps=None):
+def forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps=None, emulate_bf16_mode=False):
     """UVLTrack.forward_test (uvltrack.py:41-45), eval semantics."""
+    if emulate_bf16_mode:
+        with emulate_bf16():
+            return forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps)
     sd = {k: (np.asarray(v, dtype=f32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in sd.items()}
     out = backbone_forward(sd, spec, template.astype(f32), search.astype(f32), np.asarray(ids), np.asarray(tmask),
                            np.asarray(flag).reshape(-1, 1), taps)
     return head_forward(sd, spec, out, prompt.astype(f32))
 
 
-def forward(sd, spec, template, search, ids, tmask, tem_mask, ctx_mask, flag):
+def forward(sd, spec, template, search, ids, tmask, tem_mask, ctx_mask, flag, emulate_bf16_mode=False):
     """UVLTrack.forward (uvltrack.py:18-24) in eval mode: backbone, then the head on its no-prompt branch.  This is what the
     tracker's grounding() runs at sequence init in NL mode (lib/test/tracker/uvltrack.py:45-62)."""
+    if emulate_bf16_mode:
+        with emulate_bf16():
+            return forward(sd, spec, template, search, ids, tmask, tem_mask, ctx_mask, flag)
     sd = {k: (np.asarray(v, dtype=f32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in sd.items()}
     out = backbone_forward(sd, spec, template.astype(f32), search.astype(f32), np.asarray(ids), np.asarray(tmask),
                            np.asarray(flag).reshape(-1, 1))

@@ -26,6 +26,8 @@ def rebuild_inputs(meta, spec):
     inp = wg.make_inputs(spec, batch=meta["batch"], seed=meta["input_seed"], flags=meta["flags"])
     if meta.get("zero_text"):
         inp["mask"][1:, :] = False
+    for r in meta.get("zero_text_rows", ()):
+        inp["mask"][r, :] = False
     for k, v in meta["input_checksums"].items():
         got = float(np.asarray(inp[k], dtype=np.float64).sum())
         assert abs(got - v) <= 1e-6 * max(1.0, abs(v)), "input %s does not regenerate bit-identically" % k

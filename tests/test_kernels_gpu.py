@@ -12,7 +12,11 @@ pytestmark = pytest.mark.gpu
 def lib():
     from uvltrack_amd import _native
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
-    return _native.load()
+    handle = _native.load()
+    import os
+    if os.environ.get("UVL_TEST_ATTN_CFG"):      # development aid: run the attention cases on one forced kernel variant
+        handle.uvl_tune_set(b"attn_cfg", int(os.environ["UVL_TEST_ATTN_CFG"]))
+    return handle
 
 
 def _stream():
@@ -80,7 +84,10 @@ def test_layernorm(lib, M, D):
         assert (yb.float() - ref).abs().max().item() < 3e-2
 
 
-def _attention_case(lib, B, H, N, mode, seed):
+QSCALE = 0.18033688011112042          # UVL_ATTN_QSCALE = log2(e) / sqrt(64)
+
+
+def _attention_case(lib, B, H, N, mode, seed, prescaled=True):
     D = H * 64
     Npad = (N + 63) // 64 * 64
     x = _rand((B * N, D), seed).bfloat16()
@@ -90,10 +97,11 @@ def _attention_case(lib, B, H, N, mode, seed):
     q = torch.full((B, H, Npad, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     k = torch.full_like(q, float("nan"))
     vt = torch.full((B, H, 64, Npad), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_qkv_project(_p(x), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, N, Npad, D, _stream()), lib)
+    _chk(lib.uvl_qkv_project(_p(x), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(QSCALE if prescaled else 1.0), _stream()), lib)
     qkv = (x.float() @ w.float().t() + bias).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     torch.cuda.synchronize()
-    for got, ref in ((q[:, :, :N], qkv[0]), (k[:, :, :N], qkv[1]), (vt[:, :, :, :N].transpose(2, 3), qkv[2])):
+    qs = QSCALE if prescaled else 1.0
+    for got, ref in ((q[:, :, :N], qkv[0] * qs), (k[:, :, :N], qkv[1]), (vt[:, :, :, :N].transpose(2, 3), qkv[2])):
         err = (got.float() - ref).abs()
         assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "qkv scatter max err %g" % float(err.max())
     g = torch.Generator(device="cpu").manual_seed(seed + 3)
@@ -108,10 +116,10 @@ def _attention_case(lib, B, H, N, mode, seed):
         add[:, :N] = -10000.0
     add[:, N:] = float("nan")           # must be ignored
     o = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, _stream()), lib)
+    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, int(prescaled), _stream()), lib)
     torch.cuda.synchronize()
     qf, kf, vf = q[:, :, :N].float(), k[:, :, :N].float(), vt[:, :, :, :N].transpose(2, 3).float()
-    s = (qf @ kf.transpose(-1, -2)) * 0.125
+    s = (qf @ kf.transpose(-1, -2)) * (math.log(2.0) if prescaled else 0.125)      # pre-scaled q: q k^T is the score in log2 units
     if mode == "fill":
         s = s.masked_fill(masked[:, None, None, :], -1e10)
     else:
@@ -127,27 +135,39 @@ def test_attention_token_counts(lib, N):
 
 
 @pytest.mark.parametrize("mode", ["none", "fill", "bert", "bert_all"])
-@pytest.mark.parametrize("B,H,N", [(1, 12, 553), (3, 12, 40), (8, 16, 681), (2, 12, 321)])
+@pytest.mark.parametrize("B,H,N", [(1, 12, 553), (3, 12, 40), (8, 16, 681), (2, 12, 321), (32, 12, 553), (24, 16, 873)])
 def test_attention_modes(lib, B, H, N, mode):
     _attention_case(lib, B, H, N, mode, 77)
 
 
-def test_attention_spike_forces_rescale(lib):
-    """A late key with a huge score forces the online-softmax rescale branch (rare on random data)."""
-    B, H, N = 1, 1, 200
-    Npad = 256
+@pytest.mark.parametrize("B,H,N", [(1, 12, 553), (32, 12, 361), (24, 16, 681)])
+def test_attention_raw_q(lib, B, H, N):
+    """q_prescaled = 0: the kernel applies log2(e)/8 itself (single-sequence and streaming kernels)."""
+    _attention_case(lib, B, H, N, "fill", 78, prescaled=False)
+
+
+@pytest.mark.parametrize("B,H,N,tile", [(1, 1, 200, 2), (40, 8, 520, 5), (40, 8, 520, 8)])
+def test_attention_spike_forces_rescale(lib, B, H, N, tile):
+    """A late key with a huge score forces the online-softmax rescale (attn_body) / the redo of a speculative tile
+    (attn_stream_kernel: B*H large enough for the batched heuristic) -- rare on random data, so it is forced here.
+    q is pre-scaled as in the frame (one rounding of q; with scores of +-500 a second rounding of q alone moves them by 0.1)."""
+    Npad = (N + 63) // 64 * 64
     g = torch.Generator(device="cpu").manual_seed(5)
     q = torch.zeros((B, H, Npad, 64), dtype=torch.bfloat16, device="cuda")
     k = torch.zeros_like(q)
     vt = torch.zeros((B, H, 64, Npad), dtype=torch.bfloat16, device="cuda")
-    q[:, :, :N] = torch.randn((B, H, N, 64), generator=g).cuda().bfloat16()
+    q[:, :, :N] = (torch.randn((B, H, N, 64), generator=g) * QSCALE).cuda().bfloat16()
     k[:, :, :N] = torch.randn((B, H, N, 64), generator=g).cuda().bfloat16()
     vt[:, :, :, :N] = torch.randn((B, H, 64, N), generator=g).cuda().bfloat16()
-    k[0, 0, 150] = q[0, 0, 7] * 4.0            # key 150 (third tile) dominates query 7
+    key = 64 * tile + 5
+    for bb in range(0, B, 7):
+        k[bb, bb % H, key] = q[bb, bb % H, 7 + bb] * (4.0 / QSCALE)          # this key dominates query 7 + bb of head bb % H
+    k[B - 1, H - 1, key + 1] = q[B - 1, H - 1, 3] * (40.0 / QSCALE)          # and one that overflows exp2 against the stale maximum
     add = torch.zeros((B, Npad), device="cuda")
-    o = torch.empty((B * N, 64), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, _stream()), lib)
+    o = torch.empty((B * N, H * 64), dtype=torch.bfloat16, device="cuda")
+    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, 1, _stream()), lib)
     torch.cuda.synchronize()
-    s = (q[:, :, :N].float() @ k[:, :, :N].float().transpose(-1, -2)) * 0.125
-    ref = (s.softmax(-1) @ vt[:, :, :, :N].transpose(2, 3).float()).reshape(N, 64)
+    s = (q[:, :, :N].float() @ k[:, :, :N].float().transpose(-1, -2)) * math.log(2.0)
+    ref = (s.softmax(-1) @ vt[:, :, :, :N].transpose(2, 3).float()).transpose(1, 2).reshape(B * N, H * 64)
+    assert torch.isfinite(o.float()).all()
     assert (o.float() - ref).abs().max().item() < 3e-2

@@ -16,33 +16,51 @@ def p(t):
 
 
 def main():
+    """usage: attn_bench.py [B H N] [--cfgs 3,8,9]   (cfg -1 = the library's heuristic)"""
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    shapes = [(1, 12, 553), (8, 12, 553), (64, 12, 553), (1, 16, 681), (8, 16, 681), (8, 16, 873), (64, 16, 681)]
-    if len(sys.argv) > 3:
-        shapes = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
-    if len(sys.argv) > 4:
-        lib.uvl_tune_set(b"attn_cfg", int(sys.argv[4]))
+    shapes = [(1, 12, 553), (8, 12, 553), (64, 12, 553), (1, 16, 681), (8, 16, 681), (8, 16, 873), (32, 16, 681), (64, 16, 681)]
+    args = sys.argv[1:]
+    cfgs = [-1]
+    if "--cfgs" in args:
+        i = args.index("--cfgs")
+        cfgs = [int(c) for c in args[i + 1].split(",")]
+        del args[i:i + 2]
+    abls = [0]
+    if "--abl" in args:       # ablation bits of attn_pipe_kernel (1 = no DMA in the loop, 2 = no compute): timing only, results are garbage
+        i = args.index("--abl")
+        abls = [int(c) for c in args[i + 1].split(",")]
+        del args[i:i + 2]
+    if len(args) >= 3:
+        shapes = [(int(args[0]), int(args[1]), int(args[2]))]
     for B, H, N in shapes:
         Npad = (N + 63) // 64 * 64
-        q = torch.randn(B, H, Npad, 64, device="cuda").bfloat16()
+        q = (torch.randn(B, H, Npad, 64, device="cuda") * 0.18033688).bfloat16()     # pre-scaled by log2(e)/8, as the frame's QKV GEMM leaves it
         k = torch.randn(B, H, Npad, 64, device="cuda").bfloat16()
         vt = torch.randn(B, H, 64, Npad, device="cuda").bfloat16()
         add = torch.zeros(B, Npad, device="cuda")
         o = torch.empty(B * N, H * 64, device="cuda", dtype=torch.bfloat16)
-        fn = lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, st)
-        for _ in range(5):
-            fn()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        it = 30
-        a.record()
-        for _ in range(it):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
-        us = a.elapsed_time(b) / it * 1e3
-        flops = 4.0 * N * N * H * 64 * B
-        print("attention B=%3d H=%2d N=%4d  %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)" % (B, H, N, us, flops / us / 1e6, flops / us / 1e6 / 25))
+        fn = lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, 1, st)
+        for cfg, abl in [(c, a) for c in cfgs for a in abls]:
+            lib.uvl_tune_set(b"attn_cfg", cfg)
+            lib.uvl_tune_set(b"attn_abl", abl)
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            best = 1e30
+            for _rep in range(3):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                it = 30
+                a.record()
+                for _ in range(it):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) / it * 1e3)
+            us = best
+            flops = 4.0 * N * N * H * 64 * B
+            print("attention B=%3d H=%2d N=%4d cfg %2d%s  %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)" % (B, H, N, cfg, (" abl %d" % abl) if abl else "", us, flops / us / 1e6, flops / us / 1e6 / 25), flush=True)
+    lib.uvl_tune_set(b"attn_cfg", -1)
+    lib.uvl_tune_set(b"attn_abl", 0)
 
 
 if __name__ == "__main__":

@@ -102,8 +102,8 @@ def load():
     lib.uvl_tune_set.argtypes = [C.c_char_p, i32]
     lib.uvl_linear_splitk.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.uvl_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
-    lib.uvl_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    lib.uvl_qkv_project.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.uvl_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.uvl_qkv_project.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     lib.uvl_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, vp]
     lib.uvl_f32_to_bf16.argtypes = [vp, vp, C.c_size_t, vp]
     _lib = lib

@@ -163,7 +163,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;                 // log2-domain running max, per-lane partial row sum
-    constexpr float CS = 0.125f * ATTN_LOG2E;             // score scale folded with log2(e)
+    const float CS = p.q_prescaled ? 1.0f : 0.125f * ATTN_LOG2E;   // score scale folded with log2(e) (already in q when pre-scaled)
 
     if (NS == 1) issue(0);                                // single shot: rounds == 1, all tiles requested at once
 #pragma unroll
@@ -386,6 +386,1035 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_pair_ker
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// attn_stream_kernel<NS>: the batched shape (at least one 128-query workgroup per CU).  Same data layout and MFMA operand
+// trick as attn_body (S^T = K Q^T, P^T is the B operand of V^T P^T with no data movement), but the steady-state tile is
+// stripped to what the MFMA and the exponentials need:
+//   * Q arrives PRE-SCALED by log2(e)/8 (the QKV GEMM epilogue multiplies its q columns before rounding to bf16), and the
+//     running maximum enters the score MFMA as its C operand: a persistent register block holds -m broadcast, so the MFMA
+//     chain delivers s - m directly.  No scale, no subtract, no max in the common tile: exp2, row-sum add, bf16 pack.
+//   * the common tile is SPECULATIVE: it assumes the running max is still good enough.  If some lane's partial row sum of
+//     the tile exceeds 2^8 (or is inf / NaN) nothing has been committed yet -- the tile is redone on the exact path (scores
+//     with C = 0, true row max, rescale of l and O, new -m block).  Tiles that carry a mask term, the first tile and the
+//     tail tile take the exact path directly.  Same deferral bound as attn_body's ATTN_DEFER.
+//   * LDS addressing is lane-constant: the loop is unrolled by the ring depth, so a stage is an immediate offset of every
+//     ds_read and a DMA costs one SGPR base update per tile (K / V^T / key_add bases walk by 8192 / 128 / 256 bytes)
+//   * every wave stages its own copy of the tile's key_add row by DMA (4 bytes per lane, all-DMA loop: no ordinary load for
+//     hipcc to drain the ring for) and derives the tile's "carries a mask" flag from it; waves whose 32 queries lie beyond
+//     N serve DMA and barriers only
+// ------------------------------------------------------------------------------------------------
+template <int V_> struct AttnIC { static constexpr int value = V_; };
+
+template <int NS>
+__global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p) {
+    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
+    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
+    constexpr int VM = 5;                                 // VMEM operations per wave and tile: 2 K + 2 V^T pieces + the key_add row
+    static_assert(NS == 2 || NS == 3, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nqb = (p.N + 127) / 128;
+    int qb, h, b;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, Npad = p.Npad;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
+    const char* Kb = reinterpret_cast<const char*>(p.k + bh * Npad * 64);
+    const char* Vb = reinterpret_cast<const char*>(p.vt + bh * 64 * Npad);
+    const char* Ab = reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride);
+    const int nt = (N + 63) >> 6;
+    const int q0 = (qb * 4 + wave) * 32;
+    const bool active = q0 < N;                           // wave-uniform
+    const int qrow = q0 + (lane & 31);
+    const int qld = qrow < N ? qrow : N - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
+    if (!p.q_prescaled) {                                 // test entry point: raw q, scaled (and rounded once more) here
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[kk][e] = f2bf(bf2f(qf[kk][e]) * (0.125f * ATTN_LOG2E));
+    }
+
+    // DMA plan: instruction i of wave w fills piece w + 4 (i & 1) (8 rows) of the K tile (i < 2) or of the V^T tile
+    uint32_t voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave + 4 * (i & 1);
+        const int row = 8 * piece + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        voff[i] = i < 2 ? (uint32_t)(row * 128 + chunk * 16) : (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
+    }
+    auto pin = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+#define ATTN_GLDS(src, dst, bytes) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                                                    (__attribute__((address_space(3))) void*)(dst), bytes, 0, 0)
+    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+        const char* kt = pin(Kb + (size_t)t * 8192);
+        const char* vt = pin(Vb + (size_t)t * 128);
+        const char* at = pin(Ab + (size_t)t * 256);
+        char* st = smem + ST * STAGE;
+        ATTN_GLDS(kt + voff[0], st + wave * 1024, 16);
+        ATTN_GLDS(kt + voff[1], st + (wave + 4) * 1024, 16);
+        ATTN_GLDS(vt + voff[2], st + 8192 + wave * 1024, 16);
+        ATTN_GLDS(vt + voff[3], st + 8192 + (wave + 4) * 1024, 16);
+        ATTN_GLDS(at + lane * 4, smem + KADD0 + (ST * 4 + wave) * 256, 4);
+    };
+
+    // lane-constant fragment offsets (see attn_body): K chunk 2kk+half of row perm(lane & 31), V^T chunk 4jb+2t+half of row lane & 31
+    const int m31 = lane & 31;
+    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
+    int koff[4], voff2[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = swz128(kperm, 2 * kk + half);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) voff2[jb][t] = swz128(m31, 4 * jb + 2 * t + half);
+
+    f32x16 o[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto tile = [&](const int t, auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+        char* sK = smem + ST * STAGE;
+        char* sV = sK + 8192;
+        float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
+        // this wave's DMAs of tile t have landed; the next tile's may stay in flight
+        if (NS == 3 && t + 1 < nt) attn_wait_vmcnt<VM>();
+        else attn_wait_vmcnt<0>();
+        const int k0 = t * 64;
+        if (t == nt - 1 && (N & 63)) {                    // tail tile: zero K rows / V^T columns beyond N in LDS (own pieces)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wave + 4 * (i & 1);
+                const int row = 8 * piece + (lane >> 3);
+                char* at = sK + (i < 2 ? 0 : 8192) + piece * 1024 + lane * 16;
+                if (i < 2) {
+                    if (k0 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
+                } else {
+                    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                    const int kb = k0 + chunk * 8;
+                    if (kb + 8 > N) {
+                        u32x4 v = *reinterpret_cast<u32x4*>(at);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            uint32_t wv = v[e];
+                            if (kb + 2 * e >= N) wv &= 0xffff0000u;
+                            if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
+                            v[e] = wv;
+                        }
+                        *reinterpret_cast<u32x4*>(at) = v;
+                    }
+                }
+            }
+        }
+        float ka = 0.f;
+        if (active) ka = sA[lane];                        // own DMA, own wait: no barrier needed for this row
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NS - 1 < nt) issue(t + NS - 1, AttnIC<(ST + NS - 1) % NS>{});   // its stage was last read in iteration t-1
+        if (!active) return;
+
+        ka = (k0 + lane < N) ? ka * ATTN_LOG2E : -INFINITY;                     // log2 domain; keys beyond N never count
+        const bool masked = __any(ka != 0.f);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 s[2];
+        float psum = 0.f;
+        bool redo = masked || t == 0;
+        if (!redo) {
+            // ---- speculative tile: s - m straight from the MFMA, exp2, row-sum partials ----
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
+                    s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? negm : s[jb], 0, 0, 0);
+                }
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};           // four short add chains instead of one long one
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
+                s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
+                ps[r & 1] += s[0][r];
+                ps[2 + (r & 1)] += s[1][r];
+            }
+            psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            redo = !__all(psum <= 256.0f);                // also catches inf / NaN
+        }
+        if (redo) {
+            // ---- exact tile: scores with C = 0, mask term, true row max, rescale ----
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
+                    s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : s[jb], 0, 0, 0);
+                }
+            if (masked) {                                 // + key_add * log2(e), read from the staged row (no LDS write: that would drain the ring)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {      // registers 4gq..4gq+3 = keys 16(gq>>1) + 8g + 4(gq&1) + 0..3
+                        const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
+                        const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[jb][4 * gq + e] = fmaf(av[e], ATTN_LOG2E, s[jb][4 * gq + e]);
+                    }
+                if (k0 + 64 > N) {                        // tail tile: keys beyond N never count (their key_add may be anything)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = k0 + 32 * jb + 16 * (r >> 3) + 8 * half + (r & 7);
+                            s[jb][r] = key < N ? s[jb][r] : -INFINITY;
+                        }
+                }
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; negm[r] = -m_new; }
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[0][r] = __builtin_amdgcn_exp2f(s[0][r] - m_new);
+                s[1][r] = __builtin_amdgcn_exp2f(s[1][r] - m_new);
+                ps[r & 1] += s[0][r];
+                ps[2 + (r & 1)] += s[1][r];
+            }
+            psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        }
+        l_run += psum;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t2 + 2 * e], s[jb][8 * t2 + 2 * e + 1]);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + db * 4096 + voff2[jb][t2]);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[db], 0, 0, 0);
+                }
+            }
+    };
+
+    issue(0, AttnIC<0>{});
+    if (NS == 3 && nt > 1) issue(1, AttnIC<1>{});
+    for (int t0 = 0; t0 < nt; t0 += NS) {
+        tile(t0, AttnIC<0>{});
+        if (t0 + 1 < nt) tile(t0 + 1, AttnIC<1>{});
+        if (NS == 3 && t0 + 2 < nt) tile(t0 + 2, AttnIC<2 % NS>{});
+    }
+#undef ATTN_GLDS
+
+    if (qrow < N) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = 32 * db + 8 * gq + 4 * half;
+                uint2 w;
+                w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
+                w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
+                *reinterpret_cast<uint2*>(dst + d0) = w;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attn_pipe_kernel: attn_stream_kernel's tile with the LDS round trips taken off the critical path.  PMC of the version above
+// (profiles/r02_attention_pmc.md): a wave spends 35 % of its cycles in s_waitcnt -- hipcc places every fragment read directly
+// in front of the MFMA that consumes it, eight exposed LDS latencies per tile.  Here ONE 8-fragment register block is
+// time-shared between the K and the V^T fragments of a tile (K fragments are dead once the score MFMAs have issued, V^T
+// fragments once the output MFMAs have), and every read is issued a phase ahead of its use:
+//     top of tile t : the K fragments of tile t are already in registers (requested during the previous tile's P V phase)
+//     A  8 score MFMAs, C operand = -m (+ the key_add term on a tile that carries a mask)
+//     B  request the 8 V^T fragments of tile t into the same registers
+//     C  exp2 / row sums (speculative, see attn_stream_kernel), 64 VALU instructions that cover B's latency
+//     D  own DMAs of tile t+1 landed (vmcnt), barrier, request tile t+2 by DMA into the stage tile t-1 has left
+//     E  bf16 packing + 8 output MFMAs
+//     F  request the K fragments of tile t+1
+// The barrier sits between C and E: a wave that reaches it has finished P V of tile t-1, so that stage is free, and everyone's
+// share of tile t+1 is in LDS before anyone reads it in F.  LDS-DMA is issued from inline asm with an SGPR base and a 32-bit lane
+// offset (the builtin form makes hipcc rebuild a 64-bit VGPR address per instruction inside the loop).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void attn_dma16(uint32_t voff, const char* sbase, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void attn_dma4(uint32_t voff, const char* sbase, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+__device__ __forceinline__ bf16x8 lds_read16(uint32_t addr) { return *reinterpret_cast<__attribute__((address_space(3))) const bf16x8*>((lds_cptr)(uintptr_t)addr); }
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(const AttnParams p) {
+    constexpr int NS = 3;
+    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
+    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nqb = (p.N + 127) / 128;
+    int qb, h, b;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, Npad = p.Npad;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
+    const int nt = (N + 63) >> 6;
+    const int q0 = (qb * 4 + wave) * 32;
+    const bool active = q0 < N && !(p.ablate & 2);        // wave-uniform
+    const int qrow = q0 + (lane & 31);
+    const int qld = qrow < N ? qrow : N - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
+    if (!p.q_prescaled) {                                 // test entry point: raw q, scaled (and rounded once more) here
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[kk][e] = f2bf(bf2f(qf[kk][e]) * (0.125f * ATTN_LOG2E));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // q is in registers before the first DMA: the loop's vmcnt counts only DMAs
+
+    // DMA plan: instruction i of wave w fills piece w + 4 (i & 1) (8 rows) of the K tile (i < 2) or of the V^T tile
+    uint32_t voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave + 4 * (i & 1);
+        const int row = 8 * piece + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        voff[i] = i < 2 ? (uint32_t)(row * 128 + chunk * 16) : (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
+    }
+    auto pin = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    const char* Kb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
+    const char* Vb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
+    const char* Ab = pin(reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem;      // LDS byte address of the ring (0 unless something static precedes it)
+    const uint32_t lds_w = lds0 + wave * 1024;
+    const uint32_t lds_a = lds0 + KADD0 + wave * 256;
+    const uint32_t lane4 = lane * 4;
+    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+        const char* kt = Kb + (size_t)t * 8192;
+        const char* vt = Vb + (size_t)t * 128;
+        const char* at = Ab + (size_t)t * 256;
+        attn_dma16(voff[0], kt, lds_w + ST * STAGE);
+        attn_dma16(voff[1], kt, lds_w + ST * STAGE + 4096);
+        attn_dma16(voff[2], vt, lds_w + ST * STAGE + 8192);
+        attn_dma16(voff[3], vt, lds_w + ST * STAGE + 8192 + 4096);
+        attn_dma4(lane4, at, lds_a + ST * 1024);
+    };
+
+    // lane-constant LDS addresses of the fragments: K chunk 2kk+half of row perm(lane & 31), V^T chunk 4jb+2t+half of row lane & 31
+    const int m31 = lane & 31;
+    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
+    uint32_t kaddr[4], vaddr[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
+
+    f32x16 o[2], negm;                                     // negm: -m broadcast, the C operand of a plain tile's score MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    bf16x8 fr[8];                                          // the shared K / V^T fragment block
+
+    auto read_k = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + kk] = K fragment (key block jb, d step kk)
+        constexpr int ST = decltype(stc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) fr[4 * jb + kk] = lds_read16(kaddr[kk] + ST * STAGE + jb * 4096);
+    };
+    auto read_v = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + 2 t2 + db] = V^T fragment (d block db, keys 32 jb + 16 t2 ..)
+        constexpr int ST = decltype(stc)::value;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) fr[4 * jb + 2 * t2 + db] = lds_read16(vaddr[jb][t2] + ST * STAGE + db * 4096);
+    };
+
+    auto tile = [&](const int t, auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+        const int k0 = t * 64;
+        f32x16 s[2];
+        float psum = 0.f;
+        if (active) {
+            const float* sA = reinterpret_cast<const float*>(smem + KADD0 + ST * 1024 + wave * 256);
+            const float ka_raw = sA[lane];
+            const bool tail = k0 + 64 > N;                                          // wave-uniform
+            const bool masked = __any((k0 + lane < N) ? (ka_raw != 0.f) : true);    // a mask term, or keys beyond N
+            // C operand of the score MFMAs: (key_add * log2 e, -inf beyond N) - m; all registers equal -m on a plain tile
+            auto c_operand = [&](float base, f32x16 (&c)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {      // registers 4gq..4gq+3 = keys 32jb + 16(gq>>1) + 8 half + 4(gq&1) + 0..3
+                        const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
+                        const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = fmaf(av[e], ATTN_LOG2E, base);
+                            if (tail) v = (k0 + kq + e < N) ? v : -INFINITY;
+                            c[jb][4 * gq + e] = v;
+                        }
+                    }
+            };
+            auto scores = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kk], qf[kk], kk == 0 ? c0 : s[0], 0, 0, 0);
+                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 + kk], qf[kk], kk == 0 ? c1 : s[1], 0, 0, 0);
+                }
+            };
+            auto exp_sum = [&]() __attribute__((always_inline)) {
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};       // four short add chains instead of one long one
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
+                    s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
+                    ps[r & 1] += s[0][r];
+                    ps[2 + (r & 1)] += s[1][r];
+                }
+                psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            };
+            bool redo = (t == 0);
+            if (!redo) {
+                // ---- A..C, speculative: s - m straight from the MFMA ----
+                if (masked) {
+                    c_operand(-m_run, s);
+                    scores(s[0], s[1]);
+                } else {
+                    scores(negm, negm);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                read_v(stc);
+                __builtin_amdgcn_sched_barrier(0);
+                exp_sum();
+                redo = !__all(psum <= 256.0f);            // also catches inf / NaN
+                if (redo) read_k(stc);                    // the exact path needs the K fragments again (LDS still holds the tile)
+            }
+            if (redo) {
+                // ---- exact tile: scores with C = mask term only, true row max, rescale of l and O ----
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (masked) {
+                    c_operand(0.f, s);
+                    scores(s[0], s[1]);
+                } else {
+                    scores(zero16, zero16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                read_v(stc);
+                __builtin_amdgcn_sched_barrier(0);
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                if (t != 0) {                             // first tile: l = 0, O = 0
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                }
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[0][r] -= m_new; s[1][r] -= m_new; negm[r] = -m_new; }
+                exp_sum();
+            }
+            l_run += psum;
+        }
+        // ---- D: tile t+1 is complete in LDS for everyone, the stage of tile t-1 is free ----
+        attn_wait_vmcnt<0>();
+        if (t + 1 == nt - 1 && (N & 63)) {                // tile t+1 is the tail tile: zero its K rows / V^T columns beyond N (own pieces)
+            constexpr int SN = (ST + 1) % NS;
+            const int k1 = (t + 1) * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wave + 4 * (i & 1);
+                const int row = 8 * piece + (lane >> 3);
+                char* at = smem + SN * STAGE + (i < 2 ? 0 : 8192) + piece * 1024 + lane * 16;
+                if (i < 2) {
+                    if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
+                } else {
+                    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                    const int kb = k1 + chunk * 8;
+                    if (kb + 8 > N) {
+                        u32x4 v = *reinterpret_cast<u32x4*>(at);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            uint32_t wv = v[e];
+                            if (kb + 2 * e >= N) wv &= 0xffff0000u;
+                            if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
+                            v[e] = wv;
+                        }
+                        *reinterpret_cast<u32x4*>(at) = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt && !(p.ablate & 1)) issue(t + 2, AttnIC<(ST + 2) % NS>{});
+        if (!active) return;
+        // ---- E: O^T += V^T P^T ----
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t2 + 2 * e], s[jb][8 * t2 + 2 * e + 1]);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 * jb + 2 * t2 + db], pf.v, o[db], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- F: K fragments of the next tile ----
+        if (t + 1 < nt) read_k(AttnIC<(ST + 1) % NS>{});
+    };
+
+    // prologue: tiles 0 and 1 requested; tile 0 complete (tail fix-up if it is the only tile) before its K fragments are read
+    issue(0, AttnIC<0>{});
+    if (nt > 1) { issue(1, AttnIC<1>{}); attn_wait_vmcnt<5>(); } else { attn_wait_vmcnt<0>(); }
+    if (nt == 1 && (N & 63)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 4 * (i & 1);
+            const int row = 8 * piece + (lane >> 3);
+            char* at = smem + (i < 2 ? 0 : 8192) + piece * 1024 + lane * 16;
+            if (i < 2) {
+                if (row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                const int kb = chunk * 8;
+                if (kb + 8 > N) {
+                    u32x4 v = *reinterpret_cast<u32x4*>(at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t wv = v[e];
+                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
+                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
+                        v[e] = wv;
+                    }
+                    *reinterpret_cast<u32x4*>(at) = v;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) read_k(AttnIC<0>{});
+    for (int t0 = 0; t0 < nt; t0 += NS) {
+        tile(t0, AttnIC<0>{});
+        if (t0 + 1 < nt) tile(t0 + 1, AttnIC<1>{});
+        if (t0 + 2 < nt) tile(t0 + 2, AttnIC<2>{});
+    }
+
+    if (qrow < N) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = 32 * db + 8 * gq + 4 * half;
+                uint2 w;
+                w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
+                w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
+                *reinterpret_cast<uint2*>(dst + d0) = w;
+            }
+    }
+}
+
+template <int OCC>
+static hipError_t launch_attn_pipe(const AttnParams& p_in, hipStream_t s) {
+    constexpr size_t lds = (size_t)3 * 16384 + (size_t)3 * 4 * 256;
+    auto kern = attn_pipe_kernel<OCC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    g_last_kernel = OCC == 3 ? "attn_pipe_kernel<3>" : "attn_pipe_kernel<2>";
+    const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
+    AttnParams p = p_in;
+    p.xcd_map = total >= 400 ? 1 : 0;
+    p.ablate = g_tune_attn_abl;
+    hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// attn_persist_kernel<NW, NS>: attn_pipe_kernel's tile inside PERSISTENT workgroups.  Ablation of the one-item-per-workgroup
+// kernels at B = 32, H = 16, N = 681 (profiles/r02_attention_pmc.md): skeleton without DMA or arithmetic (q load, barriers,
+// output stores) 34 us, DMA + barriers alone 53 us, arithmetic alone ~58 us, everything 109 us -- the phases ADD, because
+// every workgroup of a round loads q at the same moment, computes at the same moment and stores at the same moment.  Here a
+// workgroup walks a list of (sample, head, query block) items and its K / V^T tile stream never stops: the DMA cursor runs
+// NS-1 tiles ahead of the arithmetic ACROSS item boundaries, the next item's q fragments are requested during the current
+// item's last tile, and the output stores of an item drain while the next item's first tiles are computed.
+// NW waves x 32 queries share a tile (NW = 4: two workgroups per CU; NW = 8: one, half the L2 -> LDS traffic per query).
+// ------------------------------------------------------------------------------------------------
+template <int NW, int NS>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_persist_kernel(const AttnParams p) {
+    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
+    constexpr int KADD0 = NS * STAGE;                     // [NS][NW waves][64] f32 key_add rows
+    constexpr int QB = 32 * NW;                           // queries per item
+    constexpr int NP = 8 / NW;                            // K pieces (and V^T pieces) per wave and tile: 2 or 1
+    constexpr int VM = 2 * NP + 1;                        // VMEM operations per wave and tile
+    static_assert((NW == 4 || NW == 8) && NS >= 3 && NS <= 6, "geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, Npad = p.Npad, H = p.H;
+    const int nt = (N + 63) >> 6;                         // >= 2 (the launcher sends shorter sequences elsewhere)
+    const int nqb = (N + QB - 1) / QB;
+    const int total = nqb * H * p.B;
+    // item list of this workgroup: workgroup w runs on XCD w % 8 (speed only); an XCD owns a contiguous run of the head-major
+    // item order and its workgroups take the run's items round-robin, so the items in flight on an XCD are neighbours
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int per = (total + 7) >> 3;
+    const int run0 = xcd * per, run_n = min(per, total - run0);
+    const int n_my = widx < run_n ? (run_n - widx + wpx - 1) / wpx : 0;
+    if (n_my <= 0) return;
+
+    auto pin = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    struct Item { int qb, h, b; };
+    auto decode = [&](int k) __attribute__((always_inline)) {
+        const int L = run0 + widx + k * wpx;
+        Item it;
+        it.qb = L % nqb;
+        const int r = L / nqb;
+        it.h = r % H;
+        it.b = r / H;
+        return it;
+    };
+
+    // DMA plan: wave w fills K pieces w (+ 4) and V^T pieces w (+ 4) of a tile and its own copy of the key_add row
+    uint32_t voff_k[NP], voff_v[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = wave + NW * i;
+        const int row = 8 * piece + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        voff_k[i] = (uint32_t)(row * 128 + chunk * 16);
+        voff_v[i] = (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem;
+    const uint32_t lds_w = lds0 + wave * 1024;
+    const uint32_t lds_a = lds0 + KADD0 + wave * 256;
+    const uint32_t lane4 = lane * 4;
+    // DMA cursor: next tile of the stream to request
+    int dk = 0, dt = 0;
+    const char *dKb, *dVb, *dAb;
+    auto dma_item = [&](int k) __attribute__((always_inline)) {
+        const Item it = decode(k);
+        const size_t bh = (size_t)it.b * H + it.h;
+        dKb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
+        dVb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
+        dAb = pin(reinterpret_cast<const char*>(p.key_add + (size_t)it.b * p.key_add_stride));
+    };
+    auto issue = [&](auto stc) __attribute__((always_inline)) {       // request stream tile (dk, dt) into stage ST, advance the cursor
+        constexpr int ST = decltype(stc)::value;
+        if (dk >= n_my) return;
+        const char* kt = dKb + (size_t)dt * 8192;
+        const char* vt = dVb + (size_t)dt * 128;
+        const char* at = dAb + (size_t)dt * 256;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) attn_dma16(voff_k[i], kt, lds_w + ST * STAGE + i * (NW * 1024));
+#pragma unroll
+        for (int i = 0; i < NP; ++i) attn_dma16(voff_v[i], vt, lds_w + ST * STAGE + 8192 + i * (NW * 1024));
+        attn_dma4(lane4, at, lds_a + ST * (NW * 256));
+        if (++dt == nt) { dt = 0; ++dk; if (dk < n_my) dma_item(dk); }
+    };
+
+    // lane-constant LDS addresses of the fragments: K chunk 2kk+half of row perm(lane & 31), V^T chunk 4jb+2t+half of row lane & 31
+    const int m31 = lane & 31;
+    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
+    uint32_t kaddr[4], vaddr[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
+
+    // compute cursor: item ck, tile ct; per-item state
+    int ck = 0, ct = 0;
+    bool active = false;
+    int qrow = 0;
+    size_t obase = 0;                                      // element offset of this lane's output row
+    bf16x8 qf[4], qn[4];
+    const float qs = 0.125f * ATTN_LOG2E;
+    auto load_q = [&](int k, bf16x8 (&dst)[4]) __attribute__((always_inline)) {
+        const Item it = decode(k);
+        const bf16_t* Q = p.q + ((size_t)it.b * H + it.h) * Npad * 64;
+        const int qr = (it.qb * NW + wave) * 32 + (lane & 31);
+        const int qld = qr < N ? qr : N - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
+    };
+    auto begin_item = [&](int k) __attribute__((always_inline)) {
+        const Item it = decode(k);
+        const int q0 = (it.qb * NW + wave) * 32;
+        active = q0 < N && !(p.ablate & 2);
+        qrow = q0 + (lane & 31);
+        obase = ((size_t)it.b * N + (qrow < N ? qrow : 0)) * (size_t)(H * 64) + (size_t)it.h * 64;
+    };
+    auto scale_q = [&](bf16x8 (&q)[4]) __attribute__((always_inline)) {
+        if (!p.q_prescaled) {                             // test entry point: raw q, scaled (and rounded once more) here
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[kk][e] = f2bf(bf2f(q[kk][e]) * qs);
+        }
+    };
+
+    f32x16 o[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    bf16x8 fr[8];                                          // the shared K / V^T fragment block
+#ifdef UVL_ATTN_TRACE
+    // tools/probes/attn_trace.hip: shader-clock stamps of one wave at the phase boundaries, 64 per register (one per lane)
+    int tr_v[3] = {0, 0, 0}, tr_n = 0;
+    const bool tr_on = p.trace && blockIdx.x == (unsigned)p.trace_block && wave == p.trace_wave;
+#define ATTN_WL(dst, val, idx) dst = (lane == (idx)) ? (val) : dst
+#define ATTN_STAMP()                                                                                          \
+    if (tr_on && tr_n < 192) {                                                                               \
+        const int tt_ = __builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());         \
+        const int ix_ = __builtin_amdgcn_readfirstlane(tr_n & 63);                                           \
+        if (tr_n < 64) { ATTN_WL(tr_v[0], tt_, ix_); }                                                       \
+        else if (tr_n < 128) { ATTN_WL(tr_v[1], tt_, ix_); }                                                 \
+        else { ATTN_WL(tr_v[2], tt_, ix_); }                                                                 \
+        ++tr_n;                                                                                              \
+    }
+#else
+#define ATTN_STAMP()
+#endif
+
+    auto read_k = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + kk] = K fragment (key block jb, d step kk)
+        constexpr int ST = decltype(stc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) fr[4 * jb + kk] = lds_read16(kaddr[kk] + ST * STAGE + jb * 4096);
+    };
+    auto read_v = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + 2 t2 + db] = V^T fragment (d block db, keys 32 jb + 16 t2 ..)
+        constexpr int ST = decltype(stc)::value;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) fr[4 * jb + 2 * t2 + db] = lds_read16(vaddr[jb][t2] + ST * STAGE + db * 4096);
+    };
+    // zero the K rows / V^T columns beyond N of the tile in stage SN (this wave's own pieces, after its own vmcnt wait)
+    auto tail_fix = [&](auto snc, int k1) __attribute__((always_inline)) {
+        constexpr int SN = decltype(snc)::value;
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) {
+            const bool isk = i < NP;
+            const int piece = wave + NW * (i % NP);
+            const int row = 8 * piece + (lane >> 3);
+            char* at = smem + SN * STAGE + (isk ? 0 : 8192) + piece * 1024 + lane * 16;
+            if (isk) {
+                if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                const int kb = k1 + chunk * 8;
+                if (kb + 8 > N) {
+                    u32x4 v = *reinterpret_cast<u32x4*>(at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t wv = v[e];
+                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
+                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
+                        v[e] = wv;
+                    }
+                    *reinterpret_cast<u32x4*>(at) = v;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    auto tile = [&](auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+        const int t = ct;
+        const int k0 = t * 64;
+        f32x16 s[2];
+        float psum = 0.f;
+        ATTN_STAMP();                                      // 0: top of tile
+        if (active) {
+            const float* sA = reinterpret_cast<const float*>(smem + KADD0 + ST * (NW * 256) + wave * 256);
+            const float ka_raw = sA[lane];
+            const bool tail = k0 + 64 > N;                                          // wave-uniform
+            const bool masked = __any((k0 + lane < N) ? (ka_raw != 0.f) : true);    // a mask term, or keys beyond N
+            // C operand of the score MFMAs: (key_add * log2 e, -inf beyond N) - m; all registers equal -m on a plain tile
+            auto c_operand = [&](float base, f32x16 (&c)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {      // registers 4gq..4gq+3 = keys 32jb + 16(gq>>1) + 8 half + 4(gq&1) + 0..3
+                        const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
+                        const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = fmaf(av[e], ATTN_LOG2E, base);
+                            if (tail) v = (k0 + kq + e < N) ? v : -INFINITY;
+                            c[jb][4 * gq + e] = v;
+                        }
+                    }
+            };
+            auto scores = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kk], qf[kk], kk == 0 ? c0 : s[0], 0, 0, 0);
+                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 + kk], qf[kk], kk == 0 ? c1 : s[1], 0, 0, 0);
+                }
+            };
+            auto exp_sum = [&]() __attribute__((always_inline)) {
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};       // four short add chains instead of one long one
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
+                    s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
+                    ps[r & 1] += s[0][r];
+                    ps[2 + (r & 1)] += s[1][r];
+                }
+                psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            };
+            bool redo = (t == 0);
+            if (!redo) {
+                // ---- A..C, speculative: s - m straight from the MFMA ----
+                if (masked) {
+                    c_operand(-m_run, s);
+                    scores(s[0], s[1]);
+                } else {
+                    scores(negm, negm);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ATTN_STAMP();                             // 1: score MFMAs issued
+                read_v(stc);
+                __builtin_amdgcn_sched_barrier(0);
+                exp_sum();
+                redo = !__all(psum <= 256.0f);            // also catches inf / NaN
+                ATTN_STAMP();                             // 2: exp / sums done
+                if (redo) read_k(stc);                    // the exact path needs the K fragments again (LDS still holds the tile)
+            }
+            if (redo) {
+                // ---- exact tile: scores with C = mask term only, true row max, rescale of l and O ----
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (masked) {
+                    c_operand(0.f, s);
+                    scores(s[0], s[1]);
+                } else {
+                    scores(zero16, zero16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                read_v(stc);
+                __builtin_amdgcn_sched_barrier(0);
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                if (t != 0) {                             // first tile: l = 0, O = 0
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                }
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[0][r] -= m_new; s[1][r] -= m_new; negm[r] = -m_new; }
+                exp_sum();
+            }
+            l_run += psum;
+        }
+        // ---- D: the next tile of the stream is complete in LDS for everyone, the stage of the previous one is free ----
+        // (t == 0: the previous item's output stores are in the queue behind the DMAs; stores and loads do not retire in order
+        //  with each other, so no counted wait there)
+        // (the counted form also needs the full complement of younger tiles in the queue: not once the stream's last tile has been
+        //  requested, and not behind the q prefetch below, which is younger than the tiles)
+        ATTN_STAMP();                                      // 3 (1 on an exact tile): before the DMA wait
+        if (NS > 3 && t != 0 && t != nt - 1 && dk < n_my) attn_wait_vmcnt<(NS - 3) * VM>(); else attn_wait_vmcnt<0>();
+        ATTN_STAMP();                                      // 4: DMA landed
+        if (t + 1 == nt - 1 && (N & 63)) tail_fix(AttnIC<(ST + 1) % NS>{}, (t + 1) * 64);
+        __builtin_amdgcn_s_barrier();
+        ATTN_STAMP();                                      // 5: past the barrier
+        if (!(p.ablate & 1)) issue(AttnIC<(ST + NS - 1) % NS>{});
+        if (t == nt - 2 && ck + 1 < n_my) load_q(ck + 1, qn);          // next item's q: a whole tile to land before the next wait
+        ATTN_STAMP();                                      // 6: DMA issued
+        if (active) {
+            // ---- E: O^T += V^T P^T ----
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t2 + 2 * e], s[jb][8 * t2 + 2 * e + 1]);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 * jb + 2 * t2 + db], pf.v, o[db], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ATTN_STAMP();                                      // 7: output MFMAs issued
+        // ---- end of an item: normalise, store, switch to the next item (its q fragments were requested at the top of this tile) ----
+        const bool last_tile = (t == nt - 1);
+        if (last_tile) {
+            if (active && qrow < N) {
+                const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+                const float inv = 1.0f / l_tot;
+                bf16_t* dst = p.o + obase;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int d0 = 32 * db + 8 * gq + 4 * half;
+                        uint2 w;
+                        w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
+                        w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
+                        *reinterpret_cast<uint2*>(dst + d0) = w;
+                    }
+            }
+            ++ck;
+            ct = 0;
+            if (ck < n_my) {
+                begin_item(ck);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+                scale_q(qf);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+                m_run = -INFINITY;
+                l_run = 0.f;
+            } else {
+                active = false;
+            }
+        } else {
+            ct = t + 1;
+        }
+        // ---- F: K fragments of the next tile of the stream ----
+        if (active) read_k(AttnIC<(ST + 1) % NS>{});
+    };
+
+    // prologue: q of the first item, the first NS-1 tiles of the stream requested, tile 0 complete for everyone
+    begin_item(0);
+    load_q(0, qf);
+    scale_q(qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma_item(0);
+    issue(AttnIC<0>{});
+    issue(AttnIC<1>{});
+    if (NS > 3) issue(AttnIC<2 % NS>{});
+    if (NS > 4) issue(AttnIC<3 % NS>{});
+    if (NS > 5) issue(AttnIC<4 % NS>{});
+    if (dk < n_my) attn_wait_vmcnt<(NS - 2) * VM>(); else attn_wait_vmcnt<0>();      // short stream: everything requested already
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) read_k(AttnIC<0>{});
+    const int total_tiles = n_my * nt;
+    for (int g = 0; g < total_tiles; g += NS) {
+        tile(AttnIC<0>{});
+        if (g + 1 < total_tiles) tile(AttnIC<1>{});
+        if (g + 2 < total_tiles) tile(AttnIC<2>{});
+        if (NS > 3 && g + 3 < total_tiles) tile(AttnIC<3 % NS>{});
+        if (NS > 4 && g + 4 < total_tiles) tile(AttnIC<4 % NS>{});
+        if (NS > 5 && g + 5 < total_tiles) tile(AttnIC<5 % NS>{});
+    }
+#ifdef UVL_ATTN_TRACE
+    if (tr_on) { p.trace[lane] = tr_v[0]; p.trace[64 + lane] = tr_v[1]; p.trace[128 + lane] = tr_v[2]; p.trace[192] = tr_n; }
+#endif
+#undef ATTN_STAMP
+}
+
+template <int NW, int NS>
+static hipError_t launch_attn_persist(const AttnParams& p_in, hipStream_t s) {
+    constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * NW * 256;
+    auto kern = attn_persist_kernel<NW, NS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[40];
+    if (!name[0]) snprintf(name, sizeof(name), "attn_persist_kernel<%d,%d>", NW, NS);
+    g_last_kernel = name;
+    const int total = ((p_in.N + 32 * NW - 1) / (32 * NW)) * p_in.H * p_in.B;
+    AttnParams p = p_in;
+    p.ablate = g_tune_attn_abl;
+    const int slots = 256 * (NW == 4 ? 2 : 1);            // resident workgroups on the chip
+    const int grid = total < slots ? 8 * ((total + 7) / 8) : slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int NS>
+static hipError_t launch_attn_stream(const AttnParams& p_in, hipStream_t s) {
+    constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256;
+    auto kern = attn_stream_kernel<NS>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[40];
+    if (!name[0]) snprintf(name, sizeof(name), "attn_stream_kernel<%d>", NS);
+    g_last_kernel = name;
+    const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
+    AttnParams p = p_in;
+    p.xcd_map = total >= 400 ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 template <int QW, int KS, int NS>
 static hipError_t launch_attn_pair_cfg(const AttnParams& a, const AttnParams& b, hipStream_t s) {
     constexpr size_t ring = (size_t)NS * KS * (8192 + 8192 + 256 + 16);
@@ -430,6 +1459,7 @@ static hipError_t launch_attn_cfg(const AttnParams& p_in, hipStream_t s) {
 }
 
 int g_tune_attn_cfg = -1;      // tools/attn_bench.py override
+int g_tune_attn_abl = 0;       // tools/attn_bench.py: ablation bits of attn_pipe_kernel (1 = no DMA in the loop, 2 = no compute); results are garbage
 
 static int pick_attn_cfg(const AttnParams& p) {
     int cfg = g_tune_attn_cfg;
@@ -441,8 +1471,8 @@ static int pick_attn_cfg(const AttnParams& p) {
         const long wg1 = (long)((p.N + 31) / 32) * p.H * p.B;
         const long wg2 = (long)((p.N + 63) / 64) * p.H * p.B;
         const int nt = (p.N + 63) / 64;
-        if (wg4 >= 256 && nt >= 11) cfg = 3;         // long sequences (UVLTrack-L): a third ring stage pays (+4..8 %)
-        else if (wg4 >= 256 || nt < 2) cfg = 0;
+        if (wg4 >= 256 && nt >= 2) cfg = 8;          // batched: the streaming kernel, 3-stage ring, 3 workgroups per CU
+        else if (nt < 2) cfg = 0;
         else if (wg1 <= 288 && nt >= 5 && nt <= 6) cfg = 5;
         else if (wg1 <= 288 && nt >= 7 && nt <= 9) cfg = 6;
         else if (wg2 <= 256 && nt >= 10) cfg = 7;    // one round of 64-query workgroups, 10+ key tiles (UVLTrack-L, one sequence): four key
@@ -482,6 +1512,14 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 5: return launch_attn_cfg<1, 6, 1>(p, s);     // single shot, up to 6 key tiles (N <= 384)
         case 6: return launch_attn_cfg<1, 9, 1>(p, s);     // single shot, up to 9 key tiles (N <= 576): 150 KB of LDS
         case 7: return launch_attn_cfg<2, 4, 2>(p, s);     // 64 queries x 4 key quarters (8 waves, 133 KB of LDS)
+        case 8: return launch_attn_stream<3>(p, s);        // batched: 128 queries per workgroup, speculative tiles
+        case 9: return launch_attn_stream<2>(p, s);
+        case 10: return launch_attn_pipe<3>(p, s);         // + fragment reads a phase ahead of their use
+        case 11: return launch_attn_pipe<2>(p, s);         // the same with 2 waves per SIMD (256 registers: nothing spills)
+        case 12: return launch_attn_persist<4, 3>(p, s);   // persistent workgroups, 128 queries per item
+        case 13: return launch_attn_persist<4, 4>(p, s);
+        case 14: return launch_attn_persist<8, 4>(p, s);   // 256 queries per item, one workgroup per CU
+        case 15: return launch_attn_persist<8, 6>(p, s);
     }
     return hipErrorInvalidValue;
 }

@@ -104,6 +104,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
     constexpr int RPI = 64 / LPR;                               // rows per store instruction
     const int colw = n0 + wn * WN;                              // first column of this wave's sub-tile
     const bool vpart = EPI == EPI_QKV && colw >= 2 * p.D;       // wave-uniform: D % 64 == 0 and WN divides 64
+    const float qs = (EPI == EPI_QKV && colw < p.D) ? p.q_scale : 1.0f;   // q columns carry the attention's log2(e)/8 (wave-uniform)
     __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
     char* cw = smem + wave * (32 * RS);
 #pragma unroll
@@ -132,6 +133,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 const int cl = j * 32 + 8 * q + 4 * (lane >> 5);
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 if (has_bias) v += bv[j][q];
+                if (EPI == EPI_QKV) v *= qs;
                 if (EPI == EPI_F32) {
                     *reinterpret_cast<f32x4*>(cw + (lane & 31) * RS + cl * 4) = v;
                 } else {

@@ -378,6 +378,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
 
 // ---- workspace ------------------------------------------------------------------------------------
 #define UVL_SKMAX 4
+#define UVL_QSCALE UVL_ATTN_QSCALE            // log2(e) / sqrt(64): the attention kernels work in the log2 domain (attention.hip)
 #define UVL_CONV_SKMAX 8
 
 // Split-K factor for an `x += A W^T` GEMM that would otherwise leave most CUs idle (batch-1 shapes): each split
@@ -652,12 +653,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             {
                 GemmParams p;
                 p.A = w.Tn; p.lda = D; p.W = bw.wqkv; p.ldw = D; p.bias = bw.bqkv; p.M = Mt; p.N = 3 * D; p.K = D;
-                p.epi = 2; p.rpb = T; p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.H = H; p.Npad = 64; p.D = D;
+                p.epi = 2; p.rpb = T; p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.H = H; p.Npad = 64; p.D = D; p.q_scale = UVL_QSCALE;
                 run_gemm(sa, p, "gemm.bert_qkv", true);
             }
             {
                 AttnParams p;
-                p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64;
+                p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64; p.q_prescaled = 1;
                 run_attn(sa, p, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, true);
             }
             residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, true, true);
@@ -744,12 +745,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         {
             GemmParams p;
             p.A = w.Xn; p.lda = D; p.W = vw.wqkv; p.ldw = D; p.bias = vw.bqkv; p.M = M; p.N = 3 * D; p.K = D;
-            p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D;
+            p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D; p.q_scale = UVL_QSCALE;
             run_gemm(s, p, "gemm.qkv", false);
         }
         {
             AttnParams p;
-            p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad;
+            p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad; p.q_prescaled = 1;
             run_attn(s, p, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, false);
         }
         residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true);
@@ -927,6 +928,7 @@ extern "C" int uvl_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_cfg")) { uvl::g_tune_gemm_cfg = value; return UVL_OK; }
     if (!strcmp(key, "gemm_gm")) { uvl::g_tune_gemm_gm = value; return UVL_OK; }
     if (!strcmp(key, "attn_cfg")) { uvl::g_tune_attn_cfg = value; return UVL_OK; }
+    if (!strcmp(key, "attn_abl")) { uvl::g_tune_attn_abl = value; return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown tuning key '%s'", key);
 }
 
@@ -1157,20 +1159,20 @@ extern "C" int uvl_linear_splitk(const void* d_x, const void* d_w, const float* 
     return UVL_OK;
 }
 
-extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o, int B, int H, int N, int Npad, void* stream) {
+extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o, int B, int H, int N, int Npad, int q_prescaled, void* stream) {
     if (!d_q || !d_k || !d_vt || !d_key_add || !d_o) return fail(UVL_EINVAL, "uvl_attention: null pointer");
     AttnParams p;
     p.q = (const bf16_t*)d_q; p.k = (const bf16_t*)d_k; p.vt = (const bf16_t*)d_vt; p.key_add = d_key_add; p.key_add_stride = Npad;
-    p.o = (bf16_t*)d_o; p.B = B; p.H = H; p.N = N; p.Npad = Npad;
+    p.o = (bf16_t*)d_o; p.B = B; p.H = H; p.N = N; p.Npad = Npad; p.q_prescaled = q_prescaled ? 1 : 0;
     HIPCHK(launch_attention(p, (hipStream_t)stream));
     return UVL_OK;
 }
 
-extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, void* stream) {
+extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream) {
     if (!d_x || !d_w || !d_q || !d_k || !d_vt || D % 64 != 0) return fail(UVL_EINVAL, "uvl_qkv_project: bad argument");
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = D; p.W = (const bf16_t*)d_w; p.ldw = D; p.bias = d_bias; p.M = B * N; p.N = 3 * D; p.K = D;
-    p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D;
+    p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale;
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
