@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     std::vector<int> ht(256);
     hipMemcpy(ht.data(), trace, 1024, hipMemcpyDeviceToHost);
     const int n = ht[192];
-    printf("trace of block %d wave %d: %d stamps (8 per plain tile: top, scores issued, exp done, pre-wait, DMA landed, past barrier, DMA issued, PV issued)\n", blk, wv, n);
+    printf("trace of block %d wave %d: %d stamps\n", blk, wv, n);
     for (int i = 0; i + 1 < n && i < 191; ++i) {
         printf("%6u%s", (unsigned)(ht[i + 1] - ht[i]), ((i + 1) % 8 == 0) ? "\n" : " ");
     }
