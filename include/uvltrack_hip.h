@@ -249,6 +249,19 @@ int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const floa
 int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
                     int B, int N, int Npad, int D, float q_scale, void* stream);
 
+/* One layer of the box head's four 3x3 conv towers, conv(3x3, pad 1) + BatchNorm2d(eval) + ReLU (heads/utils.py:126-131;
+ * towers of modality_adaptive_box_head.py:28-50), as the frame runs it: BatchNorm folded into bf16 weights, the four towers as
+ * groups of one implicit GEMM over NHWC tokens.
+ * uvl_fold_conv_bn: d_w [cout,cin,3,3] f32, conv bias and BatchNorm weight/bias/running_mean/running_var [cout] (eps 1e-5)
+ *   -> d_w_packed bf16 [cout][9][cin] (tap-major, as the kernel reads it) and d_bias_folded f32 [cout], for ONE tower.
+ * uvl_conv_tower_layer: d_x bf16 [batch*feat*feat, x_ld] NHWC tokens; tower g reads channels [x_group_offset[g], +cin);
+ *   d_w_packed [4][cout][9*cin] bf16, d_bias_folded [4*cout] -> d_y bf16 [batch*feat*feat, 4*cout] (tower-major channels).
+ *   d_slabs: optional f32 scratch of 8 * batch*feat*feat * 4*cout elements; when given, small batches split K as the frame does. */
+int uvl_fold_conv_bn(const float* d_w, const float* d_b, const float* d_bn_w, const float* d_bn_b, const float* d_bn_mean,
+                     const float* d_bn_var, void* d_w_packed, float* d_bias_folded, int cout, int cin, void* stream);
+int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_ld, const int32_t x_group_offset[4], int cin, int cout,
+                         const void* d_w_packed, const float* d_bias_folded, void* d_y, float* d_slabs, void* stream);
+
 /* nn.LayerNorm / BertLayerNorm over the last dim (block.py:30-31 eps 1e-6; bert_backbone.py:231-244 eps 1e-12).
  * d_x [M,D] f32 -> d_y_bf16 [M,D] bf16 (may be NULL) and d_y_f32 [M,D] f32 (may be NULL, may alias d_x). */
 int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps,

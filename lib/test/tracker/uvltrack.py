@@ -102,7 +102,7 @@ class UVLTrack(BaseTracker):
         they ride in the window upload."""
         if isinstance(image, np.ndarray):
             if self._uploader is None:
-                self._uploader = WindowUploader(max_side=2048, device=self.device)
+                self._uploader = WindowUploader(device=self.device)
             r = self._uploader.sample_target(image, box, factor, size, with_meta=with_meta, image_out=image_out)
         else:
             r = sample_target_fused(image, box, factor, size, want_patch=False, want_mask=False, image_out=image_out)

@@ -19,7 +19,7 @@ class BatchUVLTrack(object):
         self.B = int(n_sequences)
         self.update_interval = self.single.update_interval
         self.threshold, self.has_cont = self.single.threshold, self.single.has_cont
-        self._uploaders = [WindowUploader(max_side=2048, device=self.device) for _ in range(self.B)]
+        self._uploaders = [WindowUploader(device=self.device) for _ in range(self.B)]
         self.frame_id = 0
 
     def initialize(self, images, infos):

@@ -38,3 +38,38 @@ def test_roundtrip_and_gates(tmp_path):
     torch.save({"model": sd}, path)
     with pytest.raises(KeyError):
         load_checkpoint(_model(spec), path)
+
+
+class _Evil:
+    def __reduce__(self):
+        import os
+        return (os.getenv, ("HOME",))
+
+
+def test_rejected_pickle_is_not_reloaded_unsafely(tmp_path):
+    """A checkpoint the restricted loader rejects must not be re-read with the full unpickler behind the caller's back."""
+    import pickle
+    path = str(tmp_path / "tampered.pth.tar")
+    torch.save({"net": {"w": torch.zeros(1)}, "extra": _Evil()}, path)
+    with pytest.raises(pickle.UnpicklingError, match="allow_unsafe_pickle"):
+        read_checkpoint(path)
+    assert set(read_checkpoint(path, allow_unsafe_pickle=True)) == {"w"}      # explicit opt-in for a trusted file
+
+
+def test_submodule_weight_changes_invalidate_the_packed_copy():
+    """The reference reads parameters live; here the HIP library holds a packed copy, so every nn.Module route to the weights --
+    on the model or on a sub-module -- must tick the model's weight clock, and in-place parameter writes its version sum."""
+    spec = spec_tiny()
+    m = _model(spec)
+    v0, t0 = m._weights_version, m._tensor_versions()
+    m.backbone.load_state_dict(m.backbone.state_dict())
+    assert m._weights_version > v0
+    v1 = m._weights_version
+    m.box_head.conv_cls.float()                                # _apply on a grand-child
+    assert m._weights_version > v1
+    with torch.no_grad():
+        next(m.box_head.parameters()).mul_(1.0)
+    assert m._tensor_versions() > t0
+    v2 = m._weights_version
+    m.mark_weights_dirty()
+    assert m._weights_version > v2

@@ -39,7 +39,33 @@ def test_forward_matches_reference_fixture(name):
     assert ok, "\n" + fmt_report(rep)
 
 
-@pytest.mark.parametrize("name", [c for c in list_cases() if not c.startswith("l_")])
+@pytest.mark.parametrize("name", ["tiny_mixed", "tiny_switches", "tiny_allmasked_text", "b_z128_x256", "b_z256_x256_b8", "l_z256_x384"])
+def test_error_is_explained_by_bf16_quantisation(name):
+    """Separates quantisation from defects.  Three tensors per output: the reference (fp32), the oracle in its bf16-emulating mode
+    (a plain numpy forward with the HIP path's roundings at the same places, no HIP involved) and the HIP result.  bf16 rounding
+    is chaotic -- two correct bf16 implementations with different summation orders differ from each other by about as much as
+    each differs from fp32 -- so the gate is relative: the HIP error against the reference may not exceed 1.5x the emulation's own
+    error (+5e-4), and HIP and emulation may not be further apart than twice that error.  A kernel defect of a few 1e-3 on the box
+    maps would break the first bound; the absolute gates of parity_util (1e-2) could hide it."""
+    from oracle import uvl_oracle as O
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    got = _run(_engine(meta, spec), inp)
+    sd = rebuild_weights(meta, spec, include_unused=False)
+    emu = O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"], emulate_bf16_mode=True)
+    rep, ok = {}, True
+    for k in ("bbox_map", "cls_score_test", "cont_score", "logits"):
+        e_emu = float(np.abs(emu[k] - ref[k]).max())
+        e_hip = float(np.abs(got[k] - ref[k]).max())
+        e_he = float(np.abs(got[k] - emu[k]).max())
+        slack = 5e-4 if k in ("bbox_map", "cls_score_test") else 5e-3
+        rep[k] = "emulation-vs-fp32 %.2e   HIP-vs-fp32 %.2e   HIP-vs-emulation %.2e" % (e_emu, e_hip, e_he)
+        ok &= np.isfinite(got[k]).all() and e_hip <= 1.5 * e_emu + slack and e_he <= 2.0 * e_emu + slack
+    print(name, rep)
+    assert ok, "\n" + "\n".join("%-16s %s" % kv for kv in rep.items())
+
+
+@pytest.mark.parametrize("name", list_cases())
 def test_prompter_matches_reference_fixture(name):
     """forward_prompt_init = backbone + prompter against the reference's output for the same box masks."""
     from oracle import uvl_oracle as O
@@ -59,7 +85,7 @@ def test_prompter_matches_reference_fixture(name):
     assert np.isfinite(got).all() and err <= tol, "prompt err %g > %g (abs-max %g)" % (err, tol, np.abs(want).max())
 
 
-@pytest.mark.parametrize("name", [c for c in list_cases() if not c.startswith("l_")])
+@pytest.mark.parametrize("name", list_cases())
 def test_forward_no_prompt_branch_matches_reference_fixture(name):
     """UVLTrack.forward in eval mode (the grounding call) against the reference's outputs for the same masks:
     inline prompter on the batch-rolled context, two-channel cont_score, then the usual head."""

@@ -171,3 +171,41 @@ def test_attention_spike_forces_rescale(lib, B, H, N, tile):
     ref = (s.softmax(-1) @ vt[:, :, :, :N].transpose(2, 3).float()).transpose(1, 2).reshape(B * N, H * 64)
     assert torch.isfinite(o.float()).all()
     assert (o.float() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("B,F,cin,cout,slabs", [(1, 16, 768, 256, True), (1, 16, 768, 256, False), (16, 16, 256, 128, True), (2, 24, 1024, 256, True),
+                                                (16, 24, 128, 64, False), (1, 16, 64, 32, False), (16, 16, 64, 32, True)])
+def test_conv_tower_layer(lib, B, F, cin, cout, slabs):
+    """One layer of the four conv towers (implicit GEMM over NHWC tokens, zero-page padding, towers as groups, BatchNorm folded)
+    against F.conv2d -> BatchNorm2d(eval) -> ReLU in fp32 (heads/utils.py:126-131) at batch 1 and 16: the one-sequence split-K
+    variant, the 64x64 and the 128x128 tile variants, and the 32-channel last layer."""
+    S = F * F
+    first = cin in (768, 1024)                     # first layer: the four towers read the same channels
+    x_ld = cin if first else 4 * cin
+    goff = (C.c_int32 * 4)(*([0, 0, 0, 0] if first else [g * cin for g in range(4)]))
+    x = (_rand((B, S, x_ld), 31, 1.0)).bfloat16()
+    wpk = torch.empty((4, cout, 9 * cin), dtype=torch.bfloat16, device="cuda")
+    bpk = torch.empty((4 * cout,), device="cuda")
+    ref = []
+    for g in range(4):
+        w = _rand((cout, cin, 3, 3), 40 + g, 1.0 / math.sqrt(9 * cin))
+        b = _rand((cout,), 50 + g, 0.1)
+        bn_w = _rand((cout,), 60 + g, 0.2) + 1.0
+        bn_b = _rand((cout,), 70 + g, 0.1)
+        mu = _rand((cout,), 80 + g, 0.1)
+        var = _rand((cout,), 90 + g, 0.1).abs() + 0.5
+        _chk(lib.uvl_fold_conv_bn(_p(w), _p(b), _p(bn_w), _p(bn_b), _p(mu), _p(var), C.c_void_p(wpk[g].data_ptr()),
+                                  C.c_void_p(bpk[g * cout:].data_ptr()), cout, cin, _stream()), lib)
+        xg = x[:, :, goff[g]:goff[g] + cin].float().reshape(B, F, F, cin).permute(0, 3, 1, 2)
+        y = torch.nn.functional.conv2d(xg, w, b, padding=1)
+        y = torch.nn.functional.batch_norm(y, mu, var, bn_w, bn_b, training=False, eps=1e-5)
+        ref.append(torch.relu(y).permute(0, 2, 3, 1).reshape(B * S, cout))
+    ref = torch.cat(ref, dim=1)
+    y = torch.full((B * S, 4 * cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    scratch = torch.empty((8 * B * S * 4 * cout,), device="cuda") if slabs else None
+    _chk(lib.uvl_conv_tower_layer(_p(x), B, F, x_ld, goff, cin, cout, _p(wpk), _p(bpk), _p(y),
+                                  C.c_void_p(scratch.data_ptr() if slabs else 0), _stream()), lib)
+    torch.cuda.synchronize()
+    err = (y.float() - ref).abs()
+    assert bool(torch.isfinite(y.float()).all())
+    assert bool((err <= 2e-2 * ref.abs() + 2e-2).all()), "conv tower max err %g" % float(err.max())

@@ -92,6 +92,52 @@ def test_oracle_clip_box_matches_reference_when_available():
         assert O.clip_box(list(box), H, W, margin=10) == ns["clip_box"](list(box), H, W, margin=10)
 
 
+def test_tracker_decode_against_reference_lines():
+    """The rest of the decode row: the reference's own post-processing statements of UVLTrack.track
+    (lib/test/tracker/uvltrack.py:116-125) and its map_box_back (:167-173) are extracted from the reference file and EXECUTED
+    (nothing is copied into this repository; the tracker module itself cannot be imported, it needs cv2) on random head outputs;
+    oracle.tracker_decode must reproduce box, score and argmax."""
+    from oracle import ref_import as R
+    if not R.reference_available():
+        pytest.skip("reference tree not present (GPU box)")
+    import os
+    import re
+    import textwrap
+    import types
+    import torch
+    src = open(os.path.join(R.REF_ROOT, "lib", "test", "tracker", "uvltrack.py")).read()
+    body = re.search(r"( +pred_boxes = out_dict\['bbox_map'\].*?\n +self\.state = clip_box\(.*?\n)", src, re.S)
+    mbb = re.search(r"( +def map_box_back\(self, pred_box: list, resize_factor: float\):.*?\n +return \[.*?\]\n)", src, re.S)
+    clip = re.search(r"def clip_box\(.*?\n    return \[x1, y1, w, h\]\n", open(os.path.join(R.REF_ROOT, "lib", "utils", "box_ops.py")).read(), re.S)
+    assert body and mbb and clip, "reference statements not found"
+    ns = {"torch": torch}
+    exec(compile(clip.group(0), "ref_clip_box", "exec"), ns)
+    exec(compile(textwrap.dedent(mbb.group(1)), "ref_map_box_back", "exec"), ns)
+    code = compile(textwrap.dedent(body.group(1)), "ref_track_lines", "exec")
+    rng = np.random.RandomState(3)
+    for F, search_size in ((16, 256), (24, 384)):
+        S = F * F
+        window = O.hann_window(F)
+        for trial in range(20):
+            cls = rng.uniform(0.05, 0.95, (1, F, F)).astype(np.float32)
+            cont = rng.normal(0, 1.5, (1, S, 3)).astype(np.float32)
+            bbox = rng.uniform(0.05, 0.95, (1, S, 4)).astype(np.float32)
+            state = [float(rng.uniform(-20, 500)), float(rng.uniform(-20, 400)), float(rng.uniform(5, 200)), float(rng.uniform(5, 200))]
+            rf = float(rng.uniform(0.5, 3.0))
+            H, W = int(rng.randint(200, 800)), int(rng.randint(200, 1300))
+            me = types.SimpleNamespace(state=list(state), has_cont=True, window=torch.from_numpy(window),
+                                       params=types.SimpleNamespace(search_size=search_size))
+            me.map_box_back = types.MethodType(ns["map_box_back"], me)
+            loc = {"self": me, "out_dict": {"bbox_map": torch.from_numpy(bbox), "cls_score_test": torch.from_numpy(cls), "cont_score": torch.from_numpy(cont)},
+                   "resize_factor": rf, "H": H, "W": W}
+            exec(code, dict(ns), loc)
+            e_state, e_score, e_net, e_idx = O.tracker_decode(cls, cont, bbox, window, np.asarray([state], np.float32), np.asarray([rf], np.float32),
+                                                              np.asarray([[H, W]], np.float32), search_size)
+            np.testing.assert_allclose(np.asarray(me.state, np.float64), e_state[0], rtol=0, atol=2e-4)
+            assert abs(float(loc["score"]) - float(e_score[0])) < 1e-6
+            np.testing.assert_array_equal(loc["pred_box_net"].numpy(), e_net[0])
+
+
 def test_hann_window_shape_and_symmetry():
     w = O.hann_window(16).reshape(16, 16)
     assert w.shape == (16, 16) and np.allclose(w, w.T) and w[0].max() == 0.0 and abs(w.max() - np.hanning(16).max() ** 2) < 1e-7

@@ -47,7 +47,7 @@ def test_window_upload_matches_oracle(case):
     H, W, box, factor, out = case
     img = _rand_img(H, W, seed=H + W + out)
     patch, rf, att, _ = P.sample_target(img, box, factor, out)
-    up = WindowUploader(max_side=2048)
+    up = WindowUploader()
     r = up.sample_target(img, box, factor, out, want_patch=True, want_mask=True)
     torch.cuda.synchronize()
     assert np.array_equal(r["patch"].cpu().numpy(), patch)

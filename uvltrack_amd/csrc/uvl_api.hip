@@ -477,6 +477,34 @@ static hipError_t tramp(void* ctx, hipStream_t s) { return F(*(const P_*)ctx, s)
 #define RUN_GEMM(L, s, p, what) (L).run((s), (what), 2.0 * (p).M * (p).N * (p).K * ((p).groups > 0 ? (p).groups : 1), \
     2.0 * ((double)(p).M * (p).K + (double)(p).N * (p).K * ((p).groups > 0 ? (p).groups : 1)), tramp<GemmParams, launch_gemm>, &(p))
 
+// One layer of the four conv towers (heads/utils.py:126-131 with BatchNorm folded, modality_adaptive_box_head.py:28-50): grouped
+// implicit GEMM over NHWC tokens; few output tiles and a long K (9 * Cin) split K into f32 slabs that a small kernel folds (+ReLU).
+static void run_conv_layer(Launcher& L, hipStream_t s, int layer, const bf16_t* x, int in_ld, const int goff[4], const bf16_t* wpk, const float* bias,
+                           int B, int F, int cin, int cout, bf16_t* y, float* slabs) {
+    static const char* const conv_site[4] = {"conv3x3.0", "conv3x3.1", "conv3x3.2", "conv3x3.3"};
+    GemmParams p;
+    p.A = x; p.lda = in_ld; p.W = wpk; p.ldw = 9 * cin; p.bias = bias;
+    p.M = B * F * F; p.N = cout; p.K = 9 * cin; p.ldc = 4 * cout;
+    p.groups = 4; p.conv_F = F; p.cin_g = cin;
+    for (int g = 0; g < 4; ++g) p.a_goff[g] = goff[g];
+    const long tiles = (long)((p.M + 63) / 64) * (p.N / 64 > 0 ? p.N / 64 : 1) * 4;
+    const int nk = p.K / 64;
+    int sk = 1;
+    if (p.N % 64 == 0 && slabs)
+        for (int c = 2; c <= 8 && c <= UVL_CONV_SKMAX; ++c)
+            if (nk % c == 0 && nk / c >= 6 && tiles * c <= 768) sk = c;
+    const char* site = conv_site[layer & 3];
+    if (sk > 1) {
+        p.epi = 1; p.C = slabs; p.splitk = sk; p.part_stride = (size_t)p.M * p.ldc;
+        RUN_GEMM(L, s, p, site);
+        struct RCtx { const float* slabs; int sk; size_t stride; bf16_t* out; size_t n; } rc{slabs, sk, p.part_stride, y, p.part_stride};
+        L.run(s, "conv_fold", 0, 0, [](void* c, hipStream_t st) { auto* x = (RCtx*)c; return launch_slab_relu(x->slabs, x->sk, x->stride, x->out, x->n, st); }, &rc);
+    } else {
+        p.epi = 0; p.C = y; p.act = 2;
+        RUN_GEMM(L, s, p, site);
+    }
+}
+
 // The prompter on tokens that already sit in compact f32 buffers (heads/utils.py:82-99).  Scratch: src / src_ at the start of
 // X, the bf16 MLP operand in Xn, the MLP hidden in Hb -- all idle once the head input has been gathered.
 static int run_prompter(uvl_model* m, const Workspace& w, int B, const float* tem, const float* ctx, const float* vis, const float* txt,
@@ -848,30 +876,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     const bf16_t* cin[4] = {w.G0, w.G1, w.G2, w.G3};
     bf16_t* cout[4] = {w.G1, w.G2, w.G3, w.G4};
     const int in_ld[4] = {g0_ld, 4 * C, 2 * C, C};
-    static const char* const conv_site[4] = {"conv3x3.0", "conv3x3.1", "conv3x3.2", "conv3x3.3"};
     for (int l = 0; l < 4; ++l) {
         const ConvLayerW& cw = m->conv[l];
-        GemmParams p;
-        p.A = cin[l]; p.lda = in_ld[l]; p.W = cw.w; p.ldw = 9 * cw.cin; p.bias = cw.b;
-        p.M = B * S; p.N = cw.cout; p.K = 9 * cw.cin; p.ldc = 4 * cw.cout;
-        p.groups = 4; p.conv_F = m->F; p.cin_g = cw.cin;
-        for (int g = 0; g < 4; ++g) p.a_goff[g] = (l == 0) ? ((g == 0 && m->cfg.cls_tokenize) ? D : 0) : g * cw.cin;
-        // few output tiles and a long K (9*Cin): split K into f32 slabs, folded (+ReLU) by a small kernel
-        const long tiles = (long)((p.M + 63) / 64) * (p.N / 64 > 0 ? p.N / 64 : 1) * 4;
-        const int nk = p.K / 64;
-        int sk = 1;
-        if (p.N % 64 == 0)
-            for (int c = 2; c <= 8 && c <= UVL_CONV_SKMAX; ++c)
-                if (nk % c == 0 && nk / c >= 6 && tiles * c <= 768) sk = c;
-        if (sk > 1) {
-            p.epi = 1; p.C = w.ConvPart; p.splitk = sk; p.part_stride = (size_t)p.M * p.ldc;
-            RUN_GEMM(L, s, p, conv_site[l]);
-            struct RCtx { const float* slabs; int sk; size_t stride; bf16_t* out; size_t n; } rc{w.ConvPart, sk, p.part_stride, cout[l], p.part_stride};
-            L.run(s, "conv_fold", 0, 0, [](void* c, hipStream_t st) { auto* x = (RCtx*)c; return launch_slab_relu(x->slabs, x->sk, x->stride, x->out, x->n, st); }, &rc);
-        } else {
-            p.epi = 0; p.C = cout[l]; p.act = 2;
-            RUN_GEMM(L, s, p, conv_site[l]);
-        }
+        int goff[4];
+        for (int g = 0; g < 4; ++g) goff[g] = (l == 0) ? ((g == 0 && m->cfg.cls_tokenize) ? D : 0) : g * cw.cin;
+        run_conv_layer(L, s, l, cin[l], in_ld[l], goff, cw.w, cw.b, B, m->F, cw.cin, cw.cout, cout[l], w.ConvPart);
     }
     {
         HeadTailParams p;
@@ -1157,6 +1166,26 @@ extern "C" int uvl_linear_splitk(const void* d_x, const void* d_w, const float* 
     p.epi = 1; p.C = d_slabs; p.ldc = N; p.splitk = splitk; p.part_stride = (size_t)M * N;
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
+}
+
+/* ---- conv towers alone (parity test entry; same kernels the frame uses) ---- */
+extern "C" int uvl_fold_conv_bn(const float* d_w, const float* d_b, const float* d_bn_w, const float* d_bn_b, const float* d_bn_mean,
+                                const float* d_bn_var, void* d_w_packed, float* d_bias_folded, int cout, int cin, void* stream) {
+    if (!d_w || !d_b || !d_bn_w || !d_bn_b || !d_bn_mean || !d_bn_var || !d_w_packed || !d_bias_folded || cout <= 0 || cin <= 0)
+        return fail(UVL_EINVAL, "uvl_fold_conv_bn: bad argument");
+    HIPCHK(launch_fold_conv_bn(d_w, d_b, d_bn_w, d_bn_b, d_bn_mean, d_bn_var, (bf16_t*)d_w_packed, d_bias_folded, cout, cin, (hipStream_t)stream));
+    return UVL_OK;
+}
+
+extern "C" int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_ld, const int32_t x_group_offset[4], int cin, int cout,
+                                    const void* d_w_packed, const float* d_bias_folded, void* d_y, float* d_slabs, void* stream) {
+    if (!d_x || !d_w_packed || !d_bias_folded || !d_y || !x_group_offset || batch <= 0 || feat <= 0) return fail(UVL_EINVAL, "uvl_conv_tower_layer: bad argument");
+    if (cin % 64 != 0 || cout % 32 != 0) return fail(UVL_EINVAL, "uvl_conv_tower_layer: need cin %% 64 == 0 and cout %% 32 == 0");
+    Launcher L{nullptr};
+    int goff[4] = {x_group_offset[0], x_group_offset[1], x_group_offset[2], x_group_offset[3]};
+    run_conv_layer(L, (hipStream_t)stream, 0, (const bf16_t*)d_x, x_ld, goff, (const bf16_t*)d_w_packed, d_bias_folded, batch, feat, cin, cout,
+                   (bf16_t*)d_y, d_slabs);
+    return L.err;
 }
 
 extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o, int B, int H, int N, int Npad, int q_prescaled, void* stream) {

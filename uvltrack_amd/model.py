@@ -20,8 +20,34 @@ from .spec import ModelSpec, spec_from_cfg, state_dict_schema
 _BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "coodinate")
 
 
+class _WeightClock:
+    """One counter per model, shared by every container below it: anything that can replace or rewrite parameters through the
+    nn.Module API (load_state_dict / _apply = .to() / .half() / ... on the model OR on any sub-module) ticks it, and the packed
+    bf16 copy inside the HIP library is rebuilt when the tick seen at packing time is stale."""
+
+    def __init__(self):
+        self.ticks = 0
+
+
 class _Node(nn.Module):
     """A parameter container; children are created on demand from dotted state_dict names."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_clock", _WeightClock())
+
+    def _adopt_clock(self, clock):
+        for m in self.modules():
+            if isinstance(m, _Node):
+                object.__setattr__(m, "_clock", clock)
+
+    def _apply(self, fn, *a, **k):
+        self._clock.ticks += 1
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._clock.ticks += 1
+        return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def _attach(self, dotted: str, tensor: torch.Tensor):
         parts = dotted.split(".")
@@ -86,17 +112,33 @@ class UVLTrack(nn.Module):
         self.max_batch = max_batch
         self._engine = None
         self._engine_key = None
-        self._weights_version = 0
+        self._clock = _WeightClock()
+        backbone._adopt_clock(self._clock)
+        box_head._adopt_clock(self._clock)
         self.eval()
 
-    # weights changed -> the packed copy in the HIP library is stale
+    # weights changed -> the packed copy in the HIP library is stale.  The reference reads its parameters live; here every route
+    # through the nn.Module API ticks the shared clock (on the model or on model.backbone / model.box_head / any child), and
+    # in-place writes to a parameter (p.copy_(), p.mul_(), optimiser steps) are caught by the tensors' version counters, which
+    # forward_test sums on every call.  Writes through `.data` bypass both (PyTorch keeps no record of them): call
+    # `mark_weights_dirty()` after such a write.
+    @property
+    def _weights_version(self):
+        return self._clock.ticks
+
+    def mark_weights_dirty(self):
+        self._clock.ticks += 1
+
     def _apply(self, fn, *a, **k):
-        self._weights_version += 1
+        self._clock.ticks += 1
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        self._weights_version += 1
+        self._clock.ticks += 1
         return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _tensor_versions(self):
+        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
 
     def train(self, mode: bool = True):
         if mode:
@@ -108,7 +150,7 @@ class UVLTrack(nn.Module):
 
     def _get_engine(self, device):
         from .engine import HipEngine
-        key = (str(device), self._weights_version)
+        key = (str(device), self._weights_version, self._tensor_versions())
         if self._engine is None or self._engine.device != torch.device(device):
             if self._engine is not None:
                 self._engine.close()
@@ -150,6 +192,8 @@ class UVLTrack(nn.Module):
         weights_version = self._weights_version
 
         def run():
+            # the shared clock is one integer compare per frame; in-place parameter writes between frames (which only the
+            # per-tensor version counters see) are checked by forward_test / a new make_frame_step, not here
             if self._weights_version != weights_version or self._engine is not eng:
                 raise RuntimeError("the model's weights or device changed: build a new frame step")
             return step()

@@ -82,11 +82,20 @@ class WindowUploader:
 
     HEADER = 256
 
-    def __init__(self, max_side: int = 2048, device="cuda"):
-        n = self.HEADER + max_side * max_side * 3
+    def __init__(self, max_side: int = 0, device="cuda"):
+        """Buffers are sized lazily from the first window (max_side = 0) and grow when a later window is larger -- a target that
+        fills a 4K frame needs a bigger window than one in 720p video, and a batch tracker holds one uploader per sequence."""
+        self.device = device
+        self.max_side = 0
+        if max_side:
+            self._resize(max_side)
+
+    def _resize(self, side: int):
+        side = int(side)
+        n = self.HEADER + side * side * 3
         self.stage = torch.empty(n, dtype=torch.uint8).pin_memory()       # flat: every window is one contiguous copy
-        self.dev = torch.empty(n, dtype=torch.uint8, device=device)
-        self.max_side = max_side
+        self.dev = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self.max_side = side
         self._stage_np = self.stage.numpy()                               # views made once: no tensor slicing per frame
         self._meta_np = self._stage_np[:28].view(np.float32)
         self._meta_dev = self.dev[:28].view(torch.float32)
@@ -107,7 +116,10 @@ class WindowUploader:
         y0, y1 = g.y1 + g.y1_pad, g.y1 + g.crop_sz - g.y2_pad
         ww, wh = x1 - x0, y1 - y0
         if ww > self.max_side or wh > self.max_side:
-            raise ValueError("crop window %dx%d exceeds the staging buffer" % (ww, wh))
+            # grow (rare: the first frame, or a target that got much larger); the previous device buffer may still be read by a
+            # queued kernel, so let the stream finish before it is released
+            torch.cuda.current_stream(self.dev.device if self.max_side else None).synchronize()
+            self._resize(max(64, int(1.25 * max(ww, wh)) + 16))
         nbytes = wh * ww * 3
         hdr = self.HEADER
         np.copyto(self._stage_np[hdr:hdr + nbytes].reshape(wh, ww, 3), im[y0:y1, x0:x1])   # host gather into pinned memory
