@@ -7,9 +7,11 @@ tracking/profile_model.py:30-47 (warm-up, then K timed forwards, sync only at bo
         bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of synthetic frames per GPU (inputs resident in HBM, weights
-from the deterministic generator, hipGraph replay of the captured frame).  Each rank owns its own sequences
-(independent per-sequence shards, weights replicated); after every step the per-shard boxes
-are all-gathered over RCCL on a side stream.  Rank 0 prints ONE JSON line.
+from the deterministic generator).  Each rank owns its own sequences (independent per-sequence
+shards, weights replicated); after every step the per-shard boxes are all-gathered over RCCL on the process group's stream.
+A timed BLOCK is exactly `--steps` steps between barrier + synchronize on both sides, maximum over ranks; the line reports the
+MEDIAN of `--blocks` such blocks (default: as many as fit in about one second, at least 3), so a 20-step run of a 0.7 ms frame is
+not a 15 ms sample.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -28,11 +30,12 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.m
 PEAK_HBM_GBS = 8000.0
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps steps (0 = about one second's worth, 3..25)")
     ap.add_argument("--batch", type=int, default=1, help="sequences per GPU advanced one frame per step")
     ap.add_argument("--model", default="B", choices=["B", "L"])
     ap.add_argument("--template-size", type=int, default=256)
@@ -42,21 +45,21 @@ def parse_args():
     ap.add_argument("--reuse-text", action="store_true", help="NOT the headline: frames after the first take the text branch (BERT embedding + "
                     "pre-fusion layers) from the workspace, as the tracker does for a fixed sentence (uvl_inputs.reuse_text); eager launch only")
     ap.add_argument("--launch", default="eager", choices=["eager", "graph"],
-                    help="eager: the frame's ~100-150 kernels are launched each step (one stream for one sequence, two for several) (fastest on ROCm 7.2, where "
-                         "hipGraphLaunch costs more host time per node than a plain launch); graph: hipGraph replay")
-    ap.add_argument("--no-graph", action="store_true", help="alias of --launch eager")
+                    help="eager: the frame's kernels are launched each step (one stream for one sequence, two for several; fastest on ROCm 7.2, "
+                         "where hipGraphLaunch costs more host time per node than a plain launch); graph: hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra `batched` block (UVLTrack-L z256/x384, 8 sequences: the per-GPU load of BASELINE configs[4])")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--profile-json", default=None, help="also write the per-kernel breakdown to this file")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_spec(args):
+def build_spec(model, template_size, search_size):
     from uvltrack_amd.spec import spec_b, spec_l
-    if args.model == "B":
-        return spec_b(args.template_size, args.search_size or 256)
-    return spec_l(args.template_size, args.search_size or 384)
+    if model == "B":
+        return spec_b(template_size, search_size or 256)
+    return spec_l(template_size, search_size or 384)
 
 
 def cpu_baseline(spec, args, flags):
@@ -85,7 +88,172 @@ def cpu_baseline(spec, args, flags):
             limiter.restore_original_limits()
     return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d frames of the same workload (batch 1, fp32 numpy/OpenBLAS oracle, %d BLAS threads of %d host cores)" % (
-                n, threads, os.cpu_count())}
+                n, threads, os.cpu_count()),
+            # the REAL reference (eager PyTorch fp32, imported from /root/reference) cannot travel to the GPU box; measured at survey time:
+            "reference_survey": {"value": 4.8, "unit": "frames/s", "cores": 8,
+                                 "source": "BASELINE.md section 3: reference forward_test, UVLTrack-B z256/x256/T40, 8 vCPU Xeon (Icelake), torch 2.10 MKL/oneDNN, 8 threads"}}
+
+
+class DistEnv:
+    """The few collective operations the timing loop needs; `NoDist` when there is one process."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+        self.world = dist.get_world_size()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        import torch
+        tt = torch.tensor([seconds], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+
+class NoDist:
+    world = 1
+
+    def barrier(self):
+        pass
+
+    def max_over_ranks(self, seconds: float) -> float:
+        return seconds
+
+
+def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmup: int, blocks: int, on_result=None):
+    """THE loop of this benchmark -- also what tests/test_bench_loop_gloo.py drives with a stub step over gloo.
+    step_fn(i) enqueues one frame of this rank's sequences; local_boxes_fn() is the [n_local, 4] tensor it leaves; gatherer
+    (uvltrack_amd.shard.BoxGatherer, or None for one process) all-gathers them, double-buffered so the collective of step i
+    overlaps step i + 1.  on_result(i, boxes) is called on every rank with the gathered boxes of step i once they are complete
+    (one step late, as a consumer of the boxes would).  Returns the list of block times (seconds, maximum over ranks), `blocks`
+    entries (0 = choose from the first block: about one second in total, 3..25)."""
+    counter = [0]
+    delivered = [-1]
+
+    def deliver(i):
+        if gatherer is not None and on_result is not None and i > delivered[0]:
+            on_result(i, gatherer.result(i))
+            delivered[0] = i
+
+    def one(i):
+        step_fn(i)
+        if gatherer is not None:
+            gatherer.submit(i, local_boxes_fn())
+            if i >= 1:
+                deliver(i - 1)
+
+    def finish(last):
+        if gatherer is not None:
+            if last >= 0:
+                deliver(last)
+            gatherer.drain()
+
+    def run(n):
+        first = counter[0]
+        for k in range(n):
+            one(first + k)
+        counter[0] += n
+        finish(counter[0] - 1 if n > 0 else -1)
+
+    run(warmup)
+    sync()
+    times = []
+    want = blocks
+    while True:
+        env.barrier()
+        sync()
+        t0 = time.perf_counter()
+        run(steps)
+        sync()
+        env.barrier()
+        sync()
+        times.append(env.max_over_ranks(time.perf_counter() - t0))
+        if want <= 0:
+            want = int(min(25, max(3, round(1.0 / max(times[0], 1e-6)))))
+        if len(times) >= want:
+            return times
+
+
+def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_text, use_graph, steps, warmup, blocks, seed):
+    """Build an engine for `spec`, run the timed blocks; returns (times, engine, targs, outs, step description)."""
+    from uvltrack_amd import weightgen as wg
+    from uvltrack_amd.engine import HipEngine
+    from uvltrack_amd.shard import BoxGatherer
+    flags = [flag_val] * B
+    eng = HipEngine(spec, dev, max_batch=max(B, 1))
+    eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
+    inp = wg.make_inputs(spec, batch=B, seed=seed + rank, flags=flags)      # every rank advances its own sequences
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    targs = (t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
+    if not use_graph:
+        outs = eng.alloc_outputs(B)
+        step_fn = eng.make_eager_step(*targs, skip_text=skip_text, outs=outs, reuse_text=reuse_text)
+    else:
+        _, outs = eng.capture(*targs, skip_text=skip_text)
+        step_fn = eng.replay
+    # RCCL all-gather of the per-shard boxes (SURVEY.md 8e): rank r owns sequences [r*B, (r+1)*B)
+    gatherer = BoxGatherer(env.world * B, dev) if env.world > 1 else None
+    times = timed_blocks(lambda i: step_fn(), lambda: outs["pred_boxes"].view(B, 4), gatherer, env, torch.cuda.synchronize, steps, warmup, blocks)
+    finite = bool(torch.isfinite(outs["bbox_map"]).all().item()) and bool(torch.isfinite(outs["logits"]).all().item())
+    if not finite:
+        raise SystemExit("bench.py: the forward pass produced non-finite outputs -- timing of a broken path is not reported")
+    return times, eng, targs, outs
+
+
+def kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, single_stream, model):
+    """HIP events around every launch of one profiled frame, on the launching stream -> per (site, kernel) entries; returns the
+    `roofline` block of the kernel instantiation with the largest summed time and the `roofline_attention` block."""
+    if reuse_text:
+        eng.forward(*targs)                       # leaves the text rows the profiled frame reuses
+    eng.forward(*targs, skip_text=skip_text, profile=True, reuse_text=reuse_text)
+    prof = eng.profile_entries()
+    # A HIP event pair around a launch also times the dispatch of that launch.  One-sequence frames are a single stream of
+    # back-to-back kernels, so the bracketing cost per launch is known exactly on average:
+    #   (sum of all event-pair times - duration of the un-instrumented frame) / launches.
+    # It is taken off every launch so that avg_launch_us is comparable with rocprofv3's kernel durations
+    # (profiles/*_bench_kernel_stats.csv); frames with a second stream (batch > 1) report the raw event-pair time.
+    n_launch = sum(e["launches"] for e in prof)
+    event_overhead_ms = max(0.0, (sum(e["ms"] for e in prof) - frame_ms) / max(n_launch, 1)) if single_stream else 0.0
+    by_kernel = {}
+    for e in prof:
+        k = by_kernel.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, sites=[]))
+        k["ms"] += e["ms"]; k["flops"] += e["flops"]; k["bytes"] += e["bytes"]; k["launches"] += e["launches"]
+        k["sites"].append(e["site"])
+
+    def block(name, d):
+        raw_avg_ms = d["ms"] / max(d["launches"], 1)
+        avg_ms = max(raw_avg_ms - event_overhead_ms, 0.25 * raw_avg_ms)
+        tf = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12 if d["flops"] > 0 else 0.0
+        gbs = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+        frac_mfma, frac_hbm = tf / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see
+        # profiles/*_pmc_summary.md); null when no PMC pass of this kernel instantiation on this workload has been committed
+        traffic = None
+        try:
+            pdir = os.path.join(ROOT, "profiles")
+            for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")):
+                tb = json.load(open(os.path.join(pdir, fn))).get("bytes_per_launch", {})
+                if name in tb and B == 1 and model == "B":
+                    traffic = tb[name]
+        except OSError:
+            pass
+        bound = "mfma" if frac_mfma >= frac_hbm else "hbm"
+        return {"bound": bound, "kernel": name, "sites": sorted(set(d["sites"])), "launches_per_frame": d["launches"],
+                "avg_launch_us": avg_ms * 1e3, "avg_launch_us_event_pair": raw_avg_ms * 1e3, "event_overhead_us": event_overhead_ms * 1e3,
+                "flops_per_launch": d["flops"] / max(d["launches"], 1), "bytes_per_launch": d["bytes"] / max(d["launches"], 1),
+                "achieved": tf if bound == "mfma" else gbs, "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(frac_mfma, frac_hbm),
+                "achieved_tflops": tf, "frac_mfma": frac_mfma, "achieved_gbs": gbs, "frac_hbm": frac_hbm, "traffic": traffic}
+
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
+    roofline = block(dom_name, dom)
+    attn = {k: v for k, v in by_kernel.items() if k.startswith("attn") and any(s_ == "attention" for s_ in v["sites"])}
+    roofline_attention = None
+    if attn:
+        an, ad = max(attn.items(), key=lambda kv: kv[1]["ms"])
+        roofline_attention = block(an, ad)
+    return roofline, roofline_attention, by_kernel, prof, n_launch
 
 
 def main():
@@ -107,133 +275,70 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)     # RCCL on ROCm
+    env = DistEnv(dist, dev) if world > 1 else NoDist()
 
-    from uvltrack_amd import weightgen as wg
-    from uvltrack_amd.engine import HipEngine
-
-    spec = build_spec(args)
+    spec = build_spec(args.model, args.template_size, args.search_size)
     B = args.batch
     flag_val = {"BBOX": 0, "NL": 1, "NLBBOX": 2}[args.mode]
-    flags = [flag_val] * B
     skip_text = bool(args.skip_text and args.mode == "BBOX")
     reuse_text = bool(args.reuse_text and not skip_text)
+    use_graph = args.launch == "graph"
 
-    eng = HipEngine(spec, dev, max_batch=max(B, 1))
-    eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
-    # every rank advances its own sequences: different synthetic frames per rank
-    inp = wg.make_inputs(spec, batch=B, seed=1000 + rank, flags=flags)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    targs = (t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
-
-    use_graph = args.launch == "graph" and not args.no_graph
-    if not use_graph:
-        outs = eng.alloc_outputs(B)
-        step_fn = eng.make_eager_step(*targs, skip_text=skip_text, outs=outs, reuse_text=reuse_text)
-    else:
-        _, outs = eng.capture(*targs, skip_text=skip_text)
-        step_fn = eng.replay
-
-    # RCCL all-gather of the per-shard boxes: rank r owns sequences [r*B, (r+1)*B); the gather of step i
-    # overlaps the forward pass of step i+1 (uvltrack_amd/shard.py, covered on CPU by tests/test_shard_gloo.py)
-    from uvltrack_amd.shard import BoxGatherer
-    gatherer = BoxGatherer(world * B, dev) if world > 1 else None
-
-    def step(i):
-        step_fn()
-        if gatherer is not None:
-            gatherer.submit(i, outs["pred_boxes"].view(B, 4))
-
-    def drain():
-        if gatherer is not None:
-            gatherer.drain()
-
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    finite = bool(torch.isfinite(outs["bbox_map"]).all().item()) and bool(torch.isfinite(outs["logits"]).all().item())
-    if not finite:
-        raise SystemExit("bench.py: the forward pass produced non-finite outputs -- timing of a broken path is not reported")
+    times, eng, targs, outs = measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_text, use_graph,
+                                      args.steps, args.warmup, args.blocks, seed=1000)
+    elapsed = float(np.median(times))
 
     if rank == 0:
         frames = world * B * args.steps
         fps = frames / elapsed
-        # ---- roofline of the dominant kernel: HIP events around every launch, on the launching stream ----
-        if reuse_text:
-            eng.forward(*targs)                       # leaves the text rows the profiled frame reuses
-        eng.forward(*targs, skip_text=skip_text, profile=True, reuse_text=reuse_text)
-        prof = eng.profile_entries()
-        # A HIP event pair around a launch also times the dispatch of that launch.  One-sequence frames are a single stream of
-        # back-to-back kernels, so the bracketing cost per launch is known exactly on average:
-        #   (sum of all event-pair times - duration of the un-instrumented frame) / launches.
-        # It is taken off every launch so that avg_launch_us is comparable with rocprofv3's kernel durations
-        # (profiles/*_bench_kernel_stats.csv); frames with a second stream (batch > 1) report the raw event-pair time.
-        n_launch = sum(e["launches"] for e in prof)
-        single_stream = (B == 1) and os.environ.get("UVL_PAIR_TEXT", "1") != "0" and not use_graph
         frame_ms = elapsed / args.steps * 1e3
-        event_overhead_ms = max(0.0, (sum(e["ms"] for e in prof) - frame_ms) / max(n_launch, 1)) if single_stream else 0.0
-        by_kernel = {}
-        for e in prof:
-            k = by_kernel.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, sites=[]))
-            k["ms"] += e["ms"]; k["flops"] += e["flops"]; k["bytes"] += e["bytes"]; k["launches"] += e["launches"]
-            k["sites"].append(e["site"])
-        dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
-        raw_avg_ms = dom["ms"] / max(dom["launches"], 1)
-        avg_ms = max(raw_avg_ms - event_overhead_ms, 0.25 * raw_avg_ms)
-        achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12 if dom["flops"] > 0 else 0.0
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see
-        # profiles/*_pmc_summary.md); null when no PMC pass of this kernel instantiation has been committed
-        traffic = None
-        try:
-            pdir = os.path.join(ROOT, "profiles")
-            for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")):
-                tb = json.load(open(os.path.join(pdir, fn))).get("bytes_per_launch", {})
-                if dom_name in tb and B == 1 and args.model == "B":
-                    traffic = tb[dom_name]
-        except OSError:
-            pass
-        roofline = {"bound": "mfma", "kernel": dom_name, "sites": sorted(set(dom["sites"])), "launches_per_frame": dom["launches"],
-                    "avg_launch_us": avg_ms * 1e3, "avg_launch_us_event_pair": raw_avg_ms * 1e3, "event_overhead_us": event_overhead_ms * 1e3,
-                    "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
-                    "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                    "traffic": traffic}
+        single_stream = (B == 1 or skip_text or reuse_text) and not use_graph
+        roofline, roofline_attention, by_kernel, prof, n_launch = kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, single_stream, args.model)
         flops_frame = spec.flops_per_frame(skip_text=skip_text, reuse_text=reuse_text)
-        weight_bytes = 2.0 * sum(int(np.prod(s)) for n, s in __import__("uvltrack_amd.spec", fromlist=["x"]).state_dict_schema(spec, False).items()
+        from uvltrack_amd.spec import state_dict_schema
+        weight_bytes = 2.0 * sum(int(np.prod(s)) for n, s in state_dict_schema(spec, False).items()
                                  if len(s) >= 2 and "embeddings" not in n and "pos_embed" not in n)
         line = {
             "metric": "tracker FPS (frames/sec) UVLTrack-%s forward_test" % args.model,
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "blocks": len(times), "block_ms": [round(x * 1e3, 3) for x in times], "statistic": "median of the blocks (each: exactly `steps` steps, max over ranks)",
             "config": {"workload": "UVLTrack-%s z%d/x%d/T%d %s%s, %d sequence(s)/GPU, batch shards + RCCL all-gather of boxes" % (
                 args.model, spec.template_size, spec.search_size, spec.text_len, args.mode, " (text branch skipped)" if skip_text else (" (text branch reused from the first frame)" if reuse_text else ""), B),
                 "per_gpu_batch": B, "global_batch": B * world, "tokens_visual": spec.nv, "tokens_joint": spec.nj,
-                "gflop_per_frame": flops_frame / 1e9, "launch": "hipgraph" if use_graph else ("eager-1-stream" if (B == 1 and not skip_text and os.environ.get("UVL_PAIR_TEXT", "1") != "0") or skip_text or reuse_text else "eager-2-streams"), "parallelism": "dp%d" % world},
+                "gflop_per_frame": flops_frame / 1e9, "launches_per_frame": n_launch,
+                "launch": "hipgraph" if use_graph else ("eager-1-stream" if single_stream else "eager-2-streams"), "parallelism": "dp%d" % world},
             "frame_model_tflops": flops_frame * fps / 1e12,
             "frame_mfma_frac": flops_frame * fps / 1e12 / (PEAK_BF16_TFLOPS * world),
             "frame_hbm_frac": (weight_bytes * (args.steps / elapsed)) / 1e9 / PEAK_HBM_GBS,
-            "outputs_finite": finite,
+            "outputs_finite": True,
             "roofline": roofline,
         }
+        if roofline_attention is not None:
+            line["roofline_attention"] = roofline_attention
+    eng.close()
+    del eng, targs, outs
+
+    # ---- the regime where MFMA fractions mean something: the per-GPU load of BASELINE configs[4] (one process only) ----
+    if world == 1 and not args.no_batched and not (args.model == "L" and B == 8):
+        bspec = build_spec("L", 256, 384)
+        bsteps = max(5, min(args.steps, 40))
+        btimes, beng, btargs, bouts = measure(torch, dev, env, rank, bspec, 8, 2, args, False, False, False, bsteps, max(3, min(args.warmup, 8)), 3, seed=2000)
+        bel = float(np.median(btimes))
+        bfps = 8 * bsteps / bel
+        bflops = bspec.flops_per_frame()
+        broof, battn, _, _, bn = kernel_rooflines(beng, btargs, bspec, 8, bel / bsteps * 1e3, False, False, False, "L")
+        line["batched"] = {"workload": "UVLTrack-L z256/x384/T40 NLBBOX, 8 sequences on this GPU (per-GPU load of BASELINE configs[4])",
+                           "value": bfps, "unit": "frames/s", "ms_per_step": bel / bsteps * 1e3, "steps": bsteps, "blocks": len(btimes),
+                           "gflop_per_frame": bflops / 1e9, "frame_model_tflops": bflops * bfps / 1e12,
+                           "frame_mfma_frac": bflops * bfps / 1e12 / PEAK_BF16_TFLOPS, "launches_per_frame": bn,
+                           "roofline": broof, "roofline_attention": battn}
+        beng.close()
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(spec, args, flags)
+            line["cpu_baseline"] = cpu_baseline(spec, args, [flag_val] * B)
         if args.profile_json:
             with open(args.profile_json, "w") as f:
                 json.dump({"by_kernel": by_kernel, "sites": prof, "line": line}, f, indent=1)

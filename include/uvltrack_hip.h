@@ -131,6 +131,11 @@ int uvl_forward_prompt(uvl_model_t* m, int batch, const float* d_template_tokens
                        const uint8_t* d_template_mask, const uint8_t* d_context_mask, float* d_prompt_out,
                        void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Target-cell masks for uvl_forward_prompt / uvl_forward: the tracker's anno2mask (lib/test/tracker/uvltrack.py:183-194).
+ * d_boxes_xywh [batch,4] f32 normalised to [0,1] (device), size = grid side (template_size/16 or search_size/16)
+ * -> d_mask [batch, size*size] u8: 1 where the cell centre lies strictly inside the box, and on the cell of the box centre. */
+int uvl_anno2mask(const float* d_boxes_xywh, int batch, int size, uint8_t* d_mask, void* stream);
+
 /* Per-frame post-processing of the tracker on the device (lib/test/tracker/uvltrack.py:116-125: argmax of
  * cls_score_test * hann window * softmax(cont_score)[0]; box scaled by search_size / resize_factor; map_box_back :167-173;
  * clip_box lib/utils/box_ops.py:117-126 with `margin`).  d_cont_score may be NULL (TRAIN.CONT_WEIGHT == 0).
@@ -211,8 +216,10 @@ int uvl_profile_count(const uvl_model_t* m);
 int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int name_cap,
                       double* ms, double* flops, double* bytes, int* launches);
 
-/* Test hook.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
- * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs. */
+/* Test hooks.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
+ * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs.
+ * keys "pair_text" / "fuse_contrast" (default 1): 0 selects the two-stream form of a one-sequence frame / stand-alone
+ * contrast kernels, so that tests and tools can compare the launch forms (same results). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
 /* Tuning hooks for tools/gemm_bench.py (not part of the product path): force a plain-GEMM tile configuration

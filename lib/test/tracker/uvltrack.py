@@ -76,18 +76,15 @@ class UVLTrack(BaseTracker):
         self._window_dev = torch.from_numpy(self.window.astype(np.float32)).to(self.device)
 
     def anno2mask(self, gt_bboxes, size):
-        """tracker:183-194: cells whose centre lies inside the box, plus the cell of the box centre."""
-        gt_bboxes = gt_bboxes.detach().float().cpu()
-        bboxes = box_xywh_to_xyxy(gt_bboxes) * size
-        cood = torch.arange(size).unsqueeze(0).repeat(gt_bboxes.shape[0], 1) + 0.5
-        x_mask = ((cood > bboxes[:, 0:1]) & (cood < bboxes[:, 2:3])).unsqueeze(1)
-        y_mask = ((cood > bboxes[:, 1:2]) & (cood < bboxes[:, 3:4])).unsqueeze(2)
-        mask = (x_mask & y_mask)
-        cx = ((bboxes[:, 0] + bboxes[:, 2]) / 2).long()
-        cy = ((bboxes[:, 1] + bboxes[:, 3]) / 2).long()
-        bid = torch.arange(cx.shape[0]).to(cx)
-        mask[bid, cy, cx] = True
-        return mask.flatten(1).to(self.device)
+        """Target-cell mask [b, size*size] (bool, on the device) of normalised xywh boxes -- the reference's helper of the same
+        name (tracker:183-194) as one small kernel (uvl_anno2mask): a box that is already on the device stays there."""
+        from uvltrack_amd import _native
+        import ctypes as C
+        boxes = torch.as_tensor(gt_bboxes, dtype=torch.float32).reshape(-1, 4).to(self.device, non_blocking=True).contiguous()
+        mask = torch.empty((boxes.shape[0], size * size), dtype=torch.uint8, device=self.device)
+        _native.check(_native.load().uvl_anno2mask(C.c_void_p(boxes.data_ptr()), boxes.shape[0], int(size), C.c_void_p(mask.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "uvl_anno2mask")
+        return mask.bool()
 
     def map_box_back(self, pred_box: list, resize_factor: float):
         """tracker:167-173."""

@@ -209,3 +209,21 @@ def test_conv_tower_layer(lib, B, F, cin, cout, slabs):
     err = (y.float() - ref).abs()
     assert bool(torch.isfinite(y.float()).all())
     assert bool((err <= 2e-2 * ref.abs() + 2e-2).all()), "conv tower max err %g" % float(err.max())
+
+
+def test_anno2mask_matches_oracle(lib):
+    """uvl_anno2mask against the numpy restatement of the tracker's anno2mask (tracker:183-194), bit-exact, incl. boxes whose
+    centre cell is the only one set and boxes touching the border."""
+    import numpy as np
+    from oracle.tracker_oracle import anno2mask
+    rng = np.random.RandomState(0)
+    for size in (8, 16, 24):
+        xy = rng.uniform(0.0, 0.8, (64, 2))
+        wh = np.minimum(rng.uniform(0.0, 0.6, (64, 2)), 0.999 - xy)
+        wh[:8] = 1e-3                                # degenerate boxes: only the centre cell
+        boxes = np.concatenate([xy, wh], 1).astype(np.float32)
+        d_boxes = torch.from_numpy(boxes).cuda()
+        mask = torch.empty((64, size * size), dtype=torch.uint8, device="cuda")
+        _chk(lib.uvl_anno2mask(_p(d_boxes), 64, size, _p(mask), _stream()), lib)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), anno2mask(boxes, size))

@@ -17,7 +17,7 @@ UVL_NFAM = 5
 # every symbol include/uvltrack_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
     "uvl_last_error", "uvl_version", "uvl_create", "uvl_destroy", "uvl_load_tensor", "uvl_finalize_weights",
-    "uvl_workspace_bytes", "uvl_forward_test", "uvl_forward_prompt", "uvl_forward", "uvl_decode", "uvl_crop_geometry_of", "uvl_sample_target", "uvl_sample_target_window", "uvl_sample_target_staged", "uvl_grounding_resize", "uvl_normalize_u8", "uvl_graph_capture", "uvl_graph_launch", "uvl_graph_release",
+    "uvl_workspace_bytes", "uvl_forward_test", "uvl_forward_prompt", "uvl_forward", "uvl_anno2mask", "uvl_decode", "uvl_crop_geometry_of", "uvl_sample_target", "uvl_sample_target_window", "uvl_sample_target_staged", "uvl_grounding_resize", "uvl_normalize_u8", "uvl_graph_capture", "uvl_graph_launch", "uvl_graph_release",
     "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_debug_set", "uvl_tune_set", "uvl_linear_splitk",
     "uvl_linear", "uvl_attention", "uvl_qkv_project", "uvl_layernorm", "uvl_f32_to_bf16", "uvl_fold_conv_bn", "uvl_conv_tower_layer",
 ]
@@ -105,6 +105,7 @@ def load():
     lib.uvl_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.uvl_qkv_project.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     lib.uvl_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, vp]
+    lib.uvl_anno2mask.argtypes = [vp, i32, i32, vp, vp]
     lib.uvl_fold_conv_bn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.uvl_conv_tower_layer.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, vp, vp, vp, vp, vp]
     lib.uvl_f32_to_bf16.argtypes = [vp, vp, C.c_size_t, vp]

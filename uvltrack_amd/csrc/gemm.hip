@@ -7,71 +7,17 @@
 //   * the 3x3 conv towers of the box head as implicit GEMM over NHWC tokens, grouped by tower
 //                                                          (heads/utils.py:126-131, head:28-50)
 // Both operands are K-contiguous (nn.Linear stores W as [out,in]), so A and B fragments of
-// v_mfma_f32_32x32x16_bf16 are single 16-byte LDS reads.  Tiles are staged HBM -> VGPR -> LDS
-// (issue the next tile's loads before computing the current one, write them after), LDS rows are
-// 128 bytes and XOR-swizzled so ds_read_b128 is conflict-free.  The blockIdx -> tile map keeps all
-// M-tiles of one N-tile on one XCD so a weight panel is fetched into exactly one L2.
+// v_mfma_f32_32x32x16_bf16 are single 16-byte LDS reads.  Tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no
+// VGPR round trip) into an NS-deep ring with counted s_waitcnt vmcnt and a raw s_barrier; LDS rows are 128 bytes and
+// XOR-swizzled (on the per-lane DMA source address and again on the fragment read) so ds_read_b128 is conflict-free.
+// The workgroup -> tile map is XCD-aware (see gemm_glds_body).
 #include <cstdio>
-#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
 namespace uvl {
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_QKV = 2 };
-
-// Shared epilogue: bias, activation / residual accumulate / QKV scatter (see GemmParams).
-template <int TM, int TN, int WM, int WN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int g, int sk = 0) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row_base = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
-        int b0 = 0, rem0 = row_base;
-        if (EPI != EPI_BF16) {
-            b0 = row_base / p.rpb;
-            rem0 = row_base - b0 * p.rpb;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + (lane & 31);
-            const float bias = (p.bias && sk == 0) ? p.bias[(size_t)g * p.N + col] : 0.f;
-            // QKV scatter targets (wave-uniform `which`/h for a 32-column tile since D % 64 == 0)
-            int which = 0, hh = 0, dd = 0;
-            if (EPI == EPI_QKV) {
-                which = col / p.D;
-                const int cc = col - which * p.D;
-                hh = cc >> 6;
-                dd = cc & 63;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int inc = (r & 3) + 8 * (r >> 2);
-                const int row = row_base + inc;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (EPI == EPI_BF16) {
-                    if (p.act == 1) v = gelu_erf(v);
-                    else if (p.act == 2) v = fmaxf(v, 0.f);
-                    reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + (size_t)g * p.N + col] = f2bf(v);
-                } else {
-                    int b = b0, rem = rem0 + inc;
-                    while (rem >= p.rpb) { rem -= p.rpb; ++b; }
-                    if (EPI == EPI_F32) {
-                        if (p.addtab) v += p.addtab[(size_t)rem * p.N + col];
-                        float* dst = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
-                    } else {
-                        const size_t bh = (size_t)b * p.H + hh;
-                        if (which == 0) p.q[(bh * p.Npad + rem) * 64 + dd] = f2bf(v);
-                        else if (which == 1) p.k[(bh * p.Npad + rem) * 64 + dd] = f2bf(v);
-                        else p.vt[(bh * 64 + dd) * p.Npad + rem] = f2bf(v);
-                    }
-                }
-            }
-        }
-    }
-}
 
 // Epilogue of the pipelined kernel, which computes the tile TRANSPOSED (W fragments feed the MFMA row operand, A
 // fragments the column operand): lane l holds output row m = l & 31 and, per register quad q = r >> 2, the four
@@ -201,129 +147,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-    constexpr int BK = 64;
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;          // 16-byte chunks per thread per tile
-    static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "4 waves, 32x32 MFMA tiles");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int g = blockIdx.y;                                // group (conv tower); 0 for plain GEMMs
-
-    // XCD-aware tile map: block b runs on XCD b%8; give each XCD whole N-panels (all their M-tiles).
-    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int nt = (idx / MT) * 8 + xcd, mt = idx % MT;
-    if (nt >= NT) return;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    // kernel arguments are copied to scalars up front: the staging lambdas must not take the address of `p`
-    // (that would push the whole parameter block into scratch)
-    const int goff = !CONV ? 0 : (g == 0 ? p.a_goff[0] : g == 1 ? p.a_goff[1] : g == 2 ? p.a_goff[2] : p.a_goff[3]);
-    const bf16_t* __restrict__ A = p.A + goff;
-    const bf16_t* __restrict__ W = p.W + (size_t)g * p.N * p.ldw;
-    const int lda = p.lda, ldw = p.ldw, M = p.M, convF = p.conv_F, cin_g = p.cin_g;
-    const int ld_chunk = tid & 7, ld_row = tid >> 3;
-
-    // per-thread source rows of the A tile
-    int a_row[A_IT];                                         // plain: clamped global row; conv: b*S base
-    int a_i[A_IT], a_j[A_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        int gm = m0 + ld_row + 32 * it;
-        gm = gm < M ? gm : M - 1;
-        if (CONV) {
-            const int S = convF * convF;
-            const int b = gm / S, pix = gm - b * S;
-            a_row[it] = b * S;
-            a_i[it] = pix / convF;
-            a_j[it] = pix - a_i[it] * convF;
-        } else {
-            a_row[it] = gm;
-            a_i[it] = a_j[it] = 0;
-        }
-    }
-
-    u32x4 ra[A_IT], rb[B_IT];
-    auto load_tile = [&](int kt) __attribute__((always_inline)) {
-        const int k0 = kt * BK;
-        if (CONV) {
-            const int tap = k0 / cin_g, c0 = k0 - tap * cin_g;
-            const int di = tap / 3 - 1, dj = tap % 3 - 1;
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                const int ii = a_i[it] + di, jj = a_j[it] + dj;
-                const bool ok = (unsigned)ii < (unsigned)convF && (unsigned)jj < (unsigned)convF;
-                const int src = a_row[it] + (ok ? ii * convF + jj : 0);
-                const u32x4 v = *reinterpret_cast<const u32x4*>(A + (size_t)src * lda + c0 + ld_chunk * 8);
-                const u32x4 zero = {0u, 0u, 0u, 0u};
-                ra[it] = ok ? v : zero;
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it)
-                ra[it] = *reinterpret_cast<const u32x4*>(A + (size_t)a_row[it] * lda + k0 + ld_chunk * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it)
-            rb[it] = *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + ld_row + 32 * it) * ldw + k0 + ld_chunk * 8);
-    };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
-        char* sA = smem + buf * BUF;
-        char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) *reinterpret_cast<u32x4*>(sA + swz128(ld_row + 32 * it, ld_chunk)) = ra[it];
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) *reinterpret_cast<u32x4*>(sB + swz128(ld_row + 32 * it, ld_chunk)) = rb[it];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = p.K / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char* sA = smem + buf * BUF;
-        const char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[TM], bfr[TN];
-            const int chunk = ks * 2 + (lane >> 5);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(sA + swz128(wm * WM + i * 32 + (lane & 31), chunk));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sB + swz128(wn * WN + j * 32 + (lane & 31), chunk));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, m0, n0, wm, wn, lane, g);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Pipelined variant for the plain (non-conv) GEMMs: tiles go HBM -> LDS directly (global_load_lds,
+// The kernel: tiles go HBM -> LDS directly (global_load_lds,
 // 16 B per lane, no VGPR round trip) into an NS-deep ring, NS-1 tiles in flight per workgroup, counted
 // s_waitcnt vmcnt(N) so loads stay in flight across the (raw) barrier.  The LDS image of a DMA is
 // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address (same 128-byte line, no
@@ -534,7 +359,6 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     // an L2 AND every XCD gets the same number of tiles -- "XCD x owns N panels x, x+8, ..." left half the XCDs with 2 panels and
     // half with 1 when N = 768 (12 panels): 1378-1405 -> 1468-1499 frames/s in the frame (text branch reused, same box).
     p.group_m = MT >= 16 ? 8 : MT;
-    if (g_tune_gemm_gm == -1) { const char* e = getenv("UVL_GEMM_GM"); g_tune_gemm_gm = e ? atoi(e) : -2; }
     if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
     const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * 128;
@@ -550,31 +374,6 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
-}
-
-template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV>
-static hipError_t launch_cfg(const GemmParams& p, int groups, hipStream_t s) {
-    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
-    const int nblk = 8 * ((NT + 7) / 8) * MT;
-    const size_t lds = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<BM, BN, WGM, WGN, EPI, CONV>;
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, (int)CONV);
-    g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(nblk, groups), dim3(256), lds, s, p);
-    return hipGetLastError();
-}
-
-static bool use_v1() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("UVL_GEMM_V1"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
 }
 
 // tuning override for tools/gemm_bench.py: -1 = heuristic, otherwise index into the config table below
@@ -614,7 +413,6 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
 }
 
 static int pick_plain_cfg(const GemmParams& p) {
-    if (g_tune_gemm_cfg == -1) { const char* e = getenv("UVL_GEMM_CFG"); g_tune_gemm_cfg = e ? atoi(e) : -2; }
     if (g_tune_gemm_cfg >= 0) return g_tune_gemm_cfg;
     // measured on MI355X (tools/gemm_bench.py, tools/lib_compare.py, profiles/): co-resident workgroups matter more than
     // ring depth, so the 2-stage ring wins once there are enough tiles; few tiles keep 64x64 for parallelism
@@ -631,22 +429,15 @@ static int pick_plain_cfg(const GemmParams& p) {
     return n128 ? 6 : 9;                            // 128x128, 2 stages
 }
 
-template <int EPI, bool CONV>
-static hipError_t launch_epi(const GemmParams& p, int groups, hipStream_t s) {
-    if (!CONV && groups == 1 && p.N % 64 == 0 && !use_v1()) {
-        int cfg = pick_plain_cfg(p);
-        if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15) && p.N % 128 != 0) cfg = 0;
-        if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
-        return launch_plain_cfg<EPI>(cfg, p, s);
+template <int EPI>
+static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
+    if (p.N % 64 != 0) {                        // N % 32 == 0 (launch_gemm checked): one 32-column tile shape
+        return launch_glds<128, 32, 4, 1, EPI, 3>(p, s);
     }
-    if (p.N % 64 != 0) {
-        if (p.N % 32 == 0) return launch_cfg<128, 32, 4, 1, EPI, CONV>(p, groups, s);
-        return hipErrorInvalidValue;
-    }
-    // tile choice: large tiles only when they still give >= 2 blocks per CU
-    const long tiles128 = (long)((p.M + 127) / 128) * (p.N / 128) * groups;
-    if (p.N % 128 == 0 && tiles128 >= 512) return launch_cfg<128, 128, 2, 2, EPI, CONV>(p, groups, s);
-    return launch_cfg<64, 64, 2, 2, EPI, CONV>(p, groups, s);
+    int cfg = pick_plain_cfg(p);
+    if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15) && p.N % 128 != 0) cfg = 0;
+    if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
+    return launch_plain_cfg<EPI>(cfg, p, s);
 }
 
 // Both problems in one launch when they resolve to the same 64x64 / 3-stage instantiation (the batch-1 configuration);
@@ -673,7 +464,7 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
         return p.conv_F == 0 && (p.groups <= 1) && p.N % 64 == 0 && p.K % 64 == 0 && p.M > 0 && p.splitk >= 1 &&
                (p.splitk == 1 || (p.epi == EPI_F32 && !p.accumulate && (p.K / 64) % p.splitk == 0));
     };
-    const bool pairable = plain(a) && plain(b) && a.epi == b.epi && !use_v1() && pick_plain_cfg(a) == 4 && pick_plain_cfg(b) == 4 &&
+    const bool pairable = plain(a) && plain(b) && a.epi == b.epi && pick_plain_cfg(a) == 4 && pick_plain_cfg(b) == 4 &&
                           (g_tune_gemm_gm < 0) && (a.M + 63) / 64 < 16 && (b.M + 63) / 64 < 16;
     if (!pairable) {
         const hipError_t e = launch_gemm(a, s);
@@ -688,27 +479,26 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
-    if (p.K % 64 != 0 || p.M <= 0 || p.N <= 0 || p.splitk < 1) return hipErrorInvalidValue;
-    if (p.splitk > 1 && (p.epi != EPI_F32 || p.accumulate || p.N % 64 != 0 || (p.K / 64) % p.splitk != 0 || use_v1()))
-        return hipErrorInvalidValue;      // partial slabs: f32 store epilogue of the pipelined kernel only
-    const int groups = p.groups > 0 ? p.groups : 1;
-    if (p.conv_F > 0) {
+    if (p.K % 64 != 0 || p.M <= 0 || p.N <= 0 || p.N % 32 != 0 || p.splitk < 1) return hipErrorInvalidValue;
+    if (p.splitk > 1 && (p.epi != EPI_F32 || p.accumulate || p.N % 64 != 0 || (p.K / 64) % p.splitk != 0))
+        return hipErrorInvalidValue;      // partial slabs: f32 store epilogue only
+    if (p.conv_F > 0) {                   // implicit GEMM over NHWC tokens, towers as groups (optionally split-K into f32 slabs)
         if (p.cin_g % 64 != 0) return hipErrorInvalidValue;
-        if (!use_v1() && p.N % 64 == 0) {          // implicit GEMM on the LDS-DMA pipeline (optionally split-K into f32 slabs)
-            if (p.epi == EPI_BF16 && p.N % 128 == 0 && (long)(p.M / 128) * (p.N / 128) * groups >= 256)
+        if (p.N % 64 == 0) {
+            if (p.epi == EPI_BF16 && p.N % 128 == 0 && (long)(p.M / 128) * (p.N / 128) * (p.groups > 0 ? p.groups : 1) >= 256)
                 return launch_glds<128, 128, 2, 2, EPI_BF16, 2, true>(p, s);   // batched frames: at least one 128x128 tile per CU
             if (p.epi == EPI_BF16) return launch_glds<64, 64, 2, 2, EPI_BF16, 3, true>(p, s);
             if (p.epi == EPI_F32) return launch_glds<64, 64, 2, 2, EPI_F32, 3, true>(p, s);
             return hipErrorInvalidValue;
         }
         if (p.epi != EPI_BF16) return hipErrorInvalidValue;
-        if (!use_v1() && p.N % 32 == 0) return launch_glds<128, 32, 4, 1, EPI_BF16, 3, true>(p, s);   // last tower layer: 32 channels
-        return launch_epi<EPI_BF16, true>(p, groups, s);
+        return launch_glds<128, 32, 4, 1, EPI_BF16, 3, true>(p, s);            // last tower layer: 32 channels
     }
+    if (p.groups > 1) return hipErrorInvalidValue;
     switch (p.epi) {
-        case EPI_BF16: return launch_epi<EPI_BF16, false>(p, groups, s);
-        case EPI_F32: return launch_epi<EPI_F32, false>(p, groups, s);
-        case EPI_QKV: return launch_epi<EPI_QKV, false>(p, groups, s);
+        case EPI_BF16: return launch_epi<EPI_BF16>(p, s);
+        case EPI_F32: return launch_epi<EPI_F32>(p, s);
+        case EPI_QKV: return launch_epi<EPI_QKV>(p, s);
     }
     return hipErrorInvalidValue;
 }

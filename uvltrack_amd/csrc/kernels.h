@@ -158,6 +158,7 @@ struct PrompterParams {
     bf16_t* src_bf16 = nullptr;                                                     // [3B, D] MLP operand
 };
 hipError_t launch_prompter_tokens(const PrompterParams& p, hipStream_t s);
+hipError_t launch_anno2mask(const float* boxes_xywh, int B, int size, uint8_t* mask, hipStream_t s);   // tracker:183-194
 hipError_t launch_prompter_select(const float* src, const float* src0, const int64_t* flag, float* out, int B, int n_per_sample, hipStream_t s);
 
 // Tracker decode (tracker:116-125,167-173; box_ops.clip_box): argmax(cls * hann * softmax(cont)[0]) -> box in image coordinates.
@@ -190,9 +191,6 @@ hipError_t launch_normalize_u8(const uint8_t* src, float* dst, int n_pix, hipStr
 
 // out = relu(sum of split-K slabs) as bf16 (conv towers)
 hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_t* out, size_t n, hipStream_t s);
-
-// touch a weight blob so it is resident in the memory-side cache when the consuming GEMM runs
-hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t s);
 
 // weight packing
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);

@@ -166,4 +166,28 @@ hipError_t launch_prompter_select(const float* src, const float* src0, const int
     return hipGetLastError();
 }
 
+// Target-cell masks of the prompter (tracker anno2mask, lib/test/tracker/uvltrack.py:183-194): cell (i, j) of a size x size grid is
+// set when its centre (j + 0.5, i + 0.5) lies strictly inside the box (x, y, w, h normalised, scaled by size in f32 as the reference
+// does), and the cell that holds the box centre is always set.  One thread per cell; boxes stay on the device (the tracker's
+// updated box comes out of the decode kernel).
+__global__ __launch_bounds__(256) void anno2mask_kernel(const float* __restrict__ boxes, int B, int size, uint8_t* __restrict__ mask) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int S = size * size;
+    if (idx >= B * S) return;
+    const int b = idx / S, c = idx - b * S, i = c / size, j = c - i * size;
+    const float x = boxes[4 * b], y = boxes[4 * b + 1], w = boxes[4 * b + 2], h = boxes[4 * b + 3];
+    const float fs = (float)size;
+    const float x1 = x * fs, y1 = y * fs, x2 = (x + w) * fs, y2 = (y + h) * fs;
+    const float cj = (float)j + 0.5f, ci = (float)i + 0.5f;
+    bool m = cj > x1 && cj < x2 && ci > y1 && ci < y2;
+    const long long cx = (long long)((x1 + x2) / 2.0f), cy = (long long)((y1 + y2) / 2.0f);      // .long(): truncation
+    m = m || (cx == j && cy == i);
+    mask[idx] = m ? 1 : 0;
+}
+hipError_t launch_anno2mask(const float* boxes, int B, int size, uint8_t* mask, hipStream_t s) {
+    const int n = B * size * size;
+    hipLaunchKernelGGL(anno2mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, boxes, B, size, mask);
+    return hipGetLastError();
+}
+
 }  // namespace uvl

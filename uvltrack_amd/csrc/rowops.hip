@@ -179,13 +179,8 @@ __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const L
 
 // Rows (= waves) per workgroup.  With one memory round trip per row, one sequence of UVLTrack-B (553 rows) is 1.5-2.6 % faster in
 // the frame with one row per workgroup (553 workgroups over the 256 CUs instead of 139: 1231-1243 vs 1212-1214 frames/s);
-// from 873 rows on (UVLTrack-L, two or more sequences) 1 and 4 measure the same.  UVL_LN_WPB = 1 | 2 | 4 overrides.
-static int ln_waves_per_block(int M) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("UVL_LN_WPB"); forced = e ? atoi(e) : 0; }
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return M <= 768 ? 1 : 4;
-}
+// from 873 rows on (UVLTrack-L, two or more sequences) 1 and 4 measure the same.
+static int ln_waves_per_block(int M) { return M <= 768 ? 1 : 4; }
 
 template <int NV, bool FULL>
 static void launch_ln_variant(const LnParams& p, int grid, int wpb, hipStream_t s) {
@@ -1027,25 +1022,6 @@ hipError_t launch_decode(const DecodeParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight prefetch: stream a weight blob through the memory-side cache ahead of the GEMM that will DMA it, so the
-// GEMM's tiles come from the Infinity Cache instead of HBM (batch-1 frames touch 274 MB of weights once each).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16) {
-    uint32_t acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
-        const u32x4 v = __builtin_nontemporal_load(p + i);
-        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
-    }
-    asm volatile("" ::"v"(acc));
-}
-hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t s) {
-    const size_t n16 = bytes / 16;
-    if (n16 == 0) return hipSuccess;
-    size_t blocks = (n16 + 2047) / 2048;          // ~8 x 16 B per thread
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const u32x4*)p, n16);
-    return hipGetLastError();
-}
 
 // ------------------------------------------------------------------------------------------------
 // weight packers

@@ -1,8 +1,8 @@
 // C ABI + host-side frame scheduler of the gfx950 UVLTrack forward pass (see include/uvltrack_hip.h).
 //
-// The frame is a fixed DAG of ~150 launches on two HIP streams (the BERT text branch runs beside the
-// visual ViT branch until the first fusion layer: extractor.py:57-65), with no host sync and no
-// allocation; uvl_graph_capture() records the same DAG into a hipGraph for replay.
+// The frame is a fixed sequence of launches -- one stream for a single sequence (the text-branch kernels ride in the visual
+// launches of their kind), two streams for several (the BERT text branch runs beside the visual ViT branch until the first
+// fusion layer: extractor.py:57-65) -- with no host sync and no allocation; uvl_graph_capture() records it for replay.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -85,11 +85,9 @@ struct uvl_model {
     const float *pr_logit_scale = nullptr, *pr_query = nullptr, *pr_b1 = nullptr, *pr_b2 = nullptr;
     bf16_t *pr_w1 = nullptr, *pr_w2 = nullptr;
     // streams / events
-    hipStream_t aux = nullptr, pf = nullptr;     // text-branch stream, weight-prefetch stream
-    std::vector<hipEvent_t> ev_pf;
-    int pair_text = 1;                           // UVL_PAIR_TEXT=0: text branch on its own stream even for one sequence
-    int fuse_contrast = 1;                       // UVL_FUSE_CONTRAST=0: stand-alone contrast kernels
-    int prefetch = 0;                            // UVL_PREFETCH=1: measured -9 % FPS on MI355X (48 extra launches), off by default
+    hipStream_t aux = nullptr;                   // text-branch stream (frames of several sequences)
+    int pair_text = 1;                           // uvl_debug_set("pair_text", 0): text branch on its own stream even for one sequence
+    int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_bert, ev_cont;
     // graph
@@ -132,12 +130,6 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
         delete m;
         return nullptr;
     }
-    hipStreamCreateWithFlags(&m->pf, hipStreamNonBlocking);
-    m->ev_pf.resize(c->depth);
-    for (auto& e : m->ev_pf) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    { const char* e = getenv("UVL_PREFETCH"); if (e) m->prefetch = atoi(e); }
-    { const char* e = getenv("UVL_FUSE_CONTRAST"); if (e) m->fuse_contrast = atoi(e); }
-    { const char* e = getenv("UVL_PAIR_TEXT"); if (e) m->pair_text = atoi(e); }
     m->ev_bert.resize(c->depth);
     m->ev_cont.resize(c->depth);
     for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -156,8 +148,6 @@ extern "C" void uvl_destroy(uvl_model_t* m) {
     for (auto& kv : m->raw) if (kv.second.d) hipFree(kv.second.d);
     for (void* p : m->owned) hipFree(p);
     for (auto& e : m->ev_bert) hipEventDestroy(e);
-    for (auto& e : m->ev_pf) hipEventDestroy(e);
-    if (m->pf) hipStreamDestroy(m->pf);
     for (auto& e : m->ev_cont) hipEventDestroy(e);
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     if (m->ev_join) hipEventDestroy(m->ev_join);
@@ -384,8 +374,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
 // Split-K factor for an `x += A W^T` GEMM that would otherwise leave most CUs idle (batch-1 shapes): each split
 // writes an f32 slab, the consuming LayerNorm / contrast kernel adds the slabs on read (deterministic, no atomics).
 static int choose_splitk(int M, int N, int K) {
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("UVL_SPLITK_MAX"); cap = e ? atoi(e) : UVL_SKMAX; if (cap < 1) cap = 1; if (cap > UVL_SKMAX) cap = UVL_SKMAX; }
+    const int cap = UVL_SKMAX;
     const long tiles = (long)((M + 63) / 64) * (N / 64);
     const int nk = K / 64;
     // measured (tools/gemm_bench.py): with ~100 tiles, K=768 likes 2 splits and K=3072 likes 4; nothing above ~250 tiles
@@ -749,16 +738,6 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             if (!skip) L.cur = PART_V2;
             if (fork && hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
         }
-        if (m->prefetch && parts == PART_ALL && !prof && i + 1 < m->depth) {
-            // while layer i computes, pull layer i+1's weights (14 MB for ViT-B) into the memory-side cache
-            const VitBlockW& nw = m->vit[i + 1];
-            if (hipEventRecord(m->ev_pf[i], s) == hipSuccess && hipStreamWaitEvent(m->pf, m->ev_pf[i], 0) == hipSuccess) {
-                launch_prefetch(nw.wqkv, (size_t)3 * D * D * 2, m->pf);
-                launch_prefetch(nw.wproj, (size_t)D * D * 2, m->pf);
-                launch_prefetch(nw.wfc1, (size_t)Fn * D * 2, m->pf);
-                launch_prefetch(nw.wfc2, (size_t)Fn * D * 2, m->pf);
-            }
-        }
         // ---- ViT block (block.py:29-32) ----
         {
             LnParams p;
@@ -907,7 +886,7 @@ extern "C" int uvl_forward_test_profiled(uvl_model_t* m, const uvl_inputs* in, c
     for (auto& r : prof.recs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.a, r.b);
-        ProfEntry& e = agg[r.name];
+        ProfEntry& e = agg[std::string(r.name) + "|" + r.kernel];      // one entry per (launch site, kernel instantiation)
         e.name = r.name; e.kernel = r.kernel; e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
         int fam = 4;
         if (!strncmp(r.name, "gemm", 4)) fam = 0;
@@ -944,6 +923,8 @@ extern "C" int uvl_tune_set(const char* key, int value) {
 extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!m || !key) return fail(UVL_EINVAL, "null argument");
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
+    if (!strcmp(key, "pair_text")) { m->pair_text = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
 }
 
@@ -1022,6 +1003,12 @@ extern "C" int uvl_forward_prompt(uvl_model_t* m, int batch, const float* d_temp
     if (!d_ws || ws_bytes < w.total || (uintptr_t)d_ws % 256) return fail(UVL_EINVAL, "bad workspace");
     return run_prompter(m, w, B, d_template_tokens, d_search_tokens, d_vis_token, d_txt_token, d_flag, d_template_mask, d_context_mask, 0,
                         d_prompt_out, (hipStream_t)stream);
+}
+
+extern "C" int uvl_anno2mask(const float* d_boxes_xywh, int batch, int size, uint8_t* d_mask, void* stream) {
+    if (!d_boxes_xywh || !d_mask || batch <= 0 || size <= 0) return fail(UVL_EINVAL, "uvl_anno2mask: bad argument");
+    HIPCHK(launch_anno2mask(d_boxes_xywh, batch, size, d_mask, (hipStream_t)stream));
+    return UVL_OK;
 }
 
 // ---- UVLTrack.forward (uvltrack.py:18-24), eval mode: what the tracker's grounding() calls (tracker:45-62) -------------------------
