@@ -1923,6 +1923,335 @@ static hipError_t launch_attn_pp(const AttnParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// attn_swp_kernel: software-pipelined across key tiles INSIDE a wave.  Measured on the variants above (trace probe,
+// profiles/r02_attention_pmc.md): per 64-key tile a wave needs ~512 cycles of the MFMA pipe and ~870 cycles of VALU issue
+// (32 quarter-rate v_exp_f32), and two waves of a SIMD do NOT hide each other's phases -- an 8-MFMA group takes 420-520 cycles
+// beside a partner's exponentials, a tile costs VALU + MFMA.  What does overlap is ONE wave's own instruction stream: a VALU
+// instruction issued between two MFMAs executes while the matrix pipe works.  So the steady-state iteration t of a wave issues
+//     8 MFMAs  O += V^T(t-1) P^T(t-1)        (numerators of the PREVIOUS tile, packed)
+//     8 MFMAs  S(t+1) = K(t+1) Q^T - m        (scores of the NEXT tile, second score block)
+// interleaved one by one with the softmax arithmetic of tile t (exp2 in place, row sums, bf16 packing).  The score blocks and the
+// K / V^T fragment blocks are double-buffered in registers across iterations (K fragments of tile t+2 and V^T fragments of tile t
+// are requested at the end of iteration t, behind the tile barrier), the ring has 4 stages so that the loop unrolls by 4 with
+// compile-time stage offsets and score-block names.  Iterations that cannot run the interleaved form -- first and last tile, a next
+// tile that carries a mask term, a row maximum that grew by more than 2^8 -- run the same work sequentially (exact rescale there).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_swp_kernel(const AttnParams p) {
+    constexpr int NS = 4;
+    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
+    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nqb = (p.N + 127) / 128;
+    int qb, h, b;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, Npad = p.Npad;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
+    const int nt = (N + 63) >> 6;
+    const int q0 = (qb * 4 + wave) * 32;
+    const bool active = q0 < N;                           // wave-uniform
+    const int qrow = q0 + (lane & 31);
+    const int qld = qrow < N ? qrow : N - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
+    if (!p.q_prescaled) {                                 // test entry point: raw q, scaled (and rounded once more) here
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[kk][e] = f2bf(bf2f(qf[kk][e]) * (0.125f * ATTN_LOG2E));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // q is in registers before the first DMA: the loop's vmcnt counts only DMAs
+
+    uint32_t voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave + 4 * (i & 1);
+        const int row = 8 * piece + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        voff[i] = i < 2 ? (uint32_t)(row * 128 + chunk * 16) : (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
+    }
+    auto pin = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    const char* Kb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
+    const char* Vb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
+    const char* Ab = pin(reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem;
+    const uint32_t lds_w = lds0 + wave * 1024;
+    const uint32_t lds_a = lds0 + KADD0 + wave * 256;
+    const uint32_t lane4 = lane * 4;
+    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+        const char* kt = Kb + (size_t)t * 8192;
+        const char* vt = Vb + (size_t)t * 128;
+        const char* at = Ab + (size_t)t * 256;
+        attn_dma16(voff[0], kt, lds_w + ST * STAGE);
+        attn_dma16(voff[1], kt, lds_w + ST * STAGE + 4096);
+        attn_dma16(voff[2], vt, lds_w + ST * STAGE + 8192);
+        attn_dma16(voff[3], vt, lds_w + ST * STAGE + 8192 + 4096);
+        attn_dma4(lane4, at, lds_a + ST * 1024);
+    };
+    const int m31 = lane & 31;
+    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
+    uint32_t kaddr[4], vaddr[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
+
+    f32x16 o[2], sc[2][2];                                 // sc[tile & 1][key block]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = 0.f, l_run = 0.f;
+    bf16x8 frK[8], frV[8];                                 // K fragments of tile t+1, V^T fragments of tile t-1 (at the top of iteration t)
+    union PF { uint32_t u[4]; bf16x8 v; } pf[4];           // packed numerators of tile t-1: fragment (jb, t2) = pf[2 jb + t2]
+
+    auto read_k = [&](auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) frK[4 * jb + kk] = lds_read16(kaddr[kk] + ST * STAGE + jb * 4096);
+    };
+    auto read_v = [&](auto stc) __attribute__((always_inline)) {       // frV[2 f + db], f = 2 jb + t2
+        constexpr int ST = decltype(stc)::value;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) frV[4 * jb + 2 * t2 + db] = lds_read16(vaddr[jb][t2] + ST * STAGE + db * 4096);
+    };
+    auto tail_fix = [&](auto snc, int k1) __attribute__((always_inline)) {
+        constexpr int SN = decltype(snc)::value;
+        const int ln = attn_lane_now();
+        if (k1 + ln >= N) *reinterpret_cast<float*>(smem + KADD0 + SN * 1024 + wave * 256 + ln * 4) = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool isk = i < 2;
+            const int piece = wave + 4 * (i & 1);
+            const int row = 8 * piece + (ln >> 3);
+            char* at = smem + SN * STAGE + (isk ? 0 : 8192) + piece * 1024 + ln * 16;
+            if (isk) {
+                if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const int chunk = (ln & 7) ^ ((row >> 1) & 7);
+                const int kb = k1 + chunk * 8;
+                if (kb + 8 > N) {
+                    u32x4 v = *reinterpret_cast<u32x4*>(at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t wv = v[e];
+                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
+                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
+                        v[e] = wv;
+                    }
+                    *reinterpret_cast<u32x4*>(at) = v;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto mask_flag = [&](auto snc, int tn) __attribute__((always_inline)) {
+        constexpr int SN = decltype(snc)::value;
+        const int ln = attn_lane_now();
+        const float ka = *reinterpret_cast<const float*>(smem + KADD0 + SN * 1024 + wave * 256 + ln * 4);
+        return (bool)__any((tn * 64 + ln < N) ? (ka != 0.f) : true);
+    };
+    // scores of the tile in stage SN into sc[bi]: K fragments in frK; C = base (+ key_add * log2 e on a masked tile, -inf beyond N)
+    auto scores_seq = [&](auto snc, auto bic, bool masked, float base) __attribute__((always_inline)) {
+        constexpr int SN = decltype(snc)::value, BI = decltype(bic)::value;
+        if (masked) {
+            const float* sA = reinterpret_cast<const float*>(smem + KADD0 + SN * 1024 + wave * 256);
+            const int hf = attn_lane_now() >> 5;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int kq = 32 * jb + 16 * (gq >> 1) + 8 * hf + 4 * (gq & 1);
+                    const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sc[BI][jb][4 * gq + e] = fmaf(av[e], ATTN_LOG2E, base);
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[BI][0][r] = base; sc[BI][1][r] = base; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            sc[BI][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[kk], qf[kk], sc[BI][0], 0, 0, 0);
+            sc[BI][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[4 + kk], qf[kk], sc[BI][1], 0, 0, 0);
+        }
+    };
+    auto pv_seq = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frV[2 * f + db], pf[f].v, o[db], 0, 0, 0);
+    };
+
+    // ---- one iteration: softmax of tile t (stage ST), O += V^T P^T of tile t-1, scores of tile t+1 ----
+    auto iter = [&](const int t, auto stc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value;
+        constexpr int CUR = ST & 1, NXT = CUR ^ 1;
+        const bool has_next = t + 1 < nt;
+        // ---- tile t+1 complete in LDS for everyone (requested one iteration ago); the stage of tile t-2 is free: request tile t+2 ----
+        attn_wait_vmcnt<0>();
+        if (t + 1 == nt - 1 && t + 1 >= 2 && (N & 63)) tail_fix(AttnIC<(ST + 1) % NS>{}, (t + 1) * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt && !(p.ablate & 1)) issue(t + 2, AttnIC<(ST + 2) % NS>{});
+        if (active) {
+            // the fragments of this iteration (they live in registers only inside it): V^T(t-1) for the output MFMAs, K(t+1) for the scores
+            if (t >= 1) read_v(AttnIC<(ST + NS - 1) % NS>{});
+            if (has_next) read_k(AttnIC<(ST + 1) % NS>{});
+            const bool masked_next = has_next && mask_flag(AttnIC<(ST + 1) % NS>{}, t + 1);
+            float tmax = attn_max3(sc[CUR][0][0], sc[CUR][1][0], sc[CUR][0][1]);
+#pragma unroll
+            for (int r = 1; r < 15; r += 2) tmax = attn_max3(tmax, sc[CUR][0][r + 1], attn_max3(sc[CUR][1][r], sc[CUR][1][r + 1], sc[CUR][0][r + 2 < 16 ? r + 2 : 15]));
+            tmax = attn_max3(tmax, sc[CUR][1][15], sc[CUR][0][15]);
+            const bool fast = t >= 1 && has_next && !masked_next && !__any(tmax > ATTN_DEFER);
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
+            if (fast) {
+                // ---- interleaved: MFMA slot i, then the exp2 / add (/ pack) of one score pair ----
+                auto slot = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr int I = decltype(ic)::value;
+                    if constexpr (I < 8) {                 // O += V^T(t-1) P^T(t-1): fragment f = I >> 1, d block I & 1
+                        o[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frV[I], pf[I >> 1].v, o[I & 1], 0, 0, 0);
+                    } else {                               // S(t+1): d step (I - 8) >> 1, key block (I - 8) & 1
+                        // the C operand -m is written into the first block only (16 v_mov, in slot 7); the second key block's chain
+                        // opens first and reads it from there
+                        constexpr int kk = (I - 8) >> 1, jb = ((I - 8) & 1) ^ 1;
+                        if constexpr (kk == 0 && jb == 1) sc[NXT][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[4 + kk], qf[kk], sc[NXT][0], 0, 0, 0);
+                        else sc[NXT][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[4 * jb + kk], qf[kk], sc[NXT][jb], 0, 0, 0);
+                    }
+                    if constexpr (I == 7) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[NXT][0][r] = -m_run;
+                    }
+                    constexpr int jbe = I >> 3, r0 = 2 * (I & 7);   // the score pair of this slot
+                    sc[CUR][jbe][r0] = __builtin_amdgcn_exp2f(sc[CUR][jbe][r0]);
+                    sc[CUR][jbe][r0 + 1] = __builtin_amdgcn_exp2f(sc[CUR][jbe][r0 + 1]);
+                    ps[2 * jbe] += sc[CUR][jbe][r0];
+                    ps[2 * jbe + 1] += sc[CUR][jbe][r0 + 1];
+                    if constexpr (I >= 8 && I < 15) {      // packing trails the output MFMAs (slots 0-7 read the previous tile's pf): pairs 2(I-8), 2(I-8)+1
+#pragma unroll
+                        for (int q = 2 * (I - 8); q < 2 * (I - 8) + 2; ++q) {
+                            const int jq = q >> 3, rq = 2 * (q & 7);
+                            pf[2 * jq + (rq >> 3)].u[(rq & 7) >> 1] = pack_bf16x2(sc[CUR][jq][rq], sc[CUR][jq][rq + 1]);
+                        }
+                    }
+                };
+                slot(AttnIC<0>{}); slot(AttnIC<1>{}); slot(AttnIC<2>{}); slot(AttnIC<3>{});
+                slot(AttnIC<4>{}); slot(AttnIC<5>{}); slot(AttnIC<6>{}); slot(AttnIC<7>{});
+                slot(AttnIC<8>{}); slot(AttnIC<9>{}); slot(AttnIC<10>{}); slot(AttnIC<11>{});
+                slot(AttnIC<12>{}); slot(AttnIC<13>{}); slot(AttnIC<14>{}); slot(AttnIC<15>{});
+#pragma unroll
+                for (int q = 14; q < 16; ++q) {            // the last two pairs (exponentiated in slots 14, 15)
+                    const int jq = q >> 3, rq = 2 * (q & 7);
+                    pf[2 * jq + (rq >> 3)].u[(rq & 7) >> 1] = pack_bf16x2(sc[CUR][jq][rq], sc[CUR][jq][rq + 1]);
+                }
+            } else {
+                // ---- sequential form: previous tile's P V first (O complete before a rescale), exact maximum, then the next scores ----
+                if (t >= 1) pv_seq();
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float delta = t == 0 ? (tmax < -1e9f ? 0.f : tmax) : fmaxf(tmax, 0.f);    // first tile: m := row maximum
+                const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[0][r] *= alpha;
+                    o[1][r] *= alpha;
+                    sc[CUR][0][r] = __builtin_amdgcn_exp2f(sc[CUR][0][r] - delta);
+                    sc[CUR][1][r] = __builtin_amdgcn_exp2f(sc[CUR][1][r] - delta);
+                    ps[r & 1] += sc[CUR][0][r];
+                    ps[2 + (r & 1)] += sc[CUR][1][r];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int jq = q >> 3, rq = 2 * (q & 7);
+                    pf[2 * jq + (rq >> 3)].u[(rq & 7) >> 1] = pack_bf16x2(sc[CUR][jq][rq], sc[CUR][jq][rq + 1]);
+                }
+                if (has_next) scores_seq(AttnIC<(ST + 1) % NS>{}, AttnIC<NXT>{}, masked_next, -m_run);
+            }
+            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        }
+    };
+
+    // ---- prologue: tiles 0 and 1 requested and complete, S(0) (raw scores) computed ----
+    issue(0, AttnIC<0>{});
+    if (nt > 1) issue(1, AttnIC<1>{});
+    attn_wait_vmcnt<0>();
+    if (nt == 1 && (N & 63)) tail_fix(AttnIC<0>{}, 0);
+    if (nt == 2 && (N & 63)) tail_fix(AttnIC<1>{}, 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+        read_k(AttnIC<0>{});
+        scores_seq(AttnIC<0>{}, AttnIC<0>{}, mask_flag(AttnIC<0>{}, 0), 0.f);
+    }
+    for (int t0 = 0; t0 < nt; t0 += NS) {
+        iter(t0, AttnIC<0>{});
+        if (t0 + 1 < nt) iter(t0 + 1, AttnIC<1>{});
+        if (t0 + 2 < nt) iter(t0 + 2, AttnIC<2>{});
+        if (t0 + 3 < nt) iter(t0 + 3, AttnIC<3>{});
+    }
+    if (active) {                                          // the last tile's numerators (its stage is still intact)
+        switch ((nt - 1) % NS) {
+            case 0: read_v(AttnIC<0>{}); break;
+            case 1: read_v(AttnIC<1>{}); break;
+            case 2: read_v(AttnIC<2>{}); break;
+            default: read_v(AttnIC<3>{}); break;
+        }
+        pv_seq();
+    }
+
+    if (qrow < N) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = 32 * db + 8 * gq + 4 * half;
+                uint2 w;
+                w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
+                w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
+                *reinterpret_cast<uint2*>(dst + d0) = w;
+            }
+    }
+}
+
+static hipError_t launch_attn_swp(const AttnParams& p_in, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * 16384 + (size_t)4 * 4 * 256;
+    auto kern = attn_swp_kernel;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    g_last_kernel = "attn_swp_kernel";
+    const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
+    AttnParams p = p_in;
+    p.xcd_map = total >= 400 ? 1 : 0;
+    p.ablate = g_tune_attn_abl;
+    hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 template <int NS>
 static hipError_t launch_attn_stream(const AttnParams& p_in, hipStream_t s) {
     constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256;
@@ -2048,6 +2377,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 13: return launch_attn_persist<4, 4>(p, s);
         case 14: return launch_attn_persist<8, 4>(p, s);   // 256 queries per item, one workgroup per CU
         case 15: return launch_attn_persist<8, 6>(p, s);
+        case 18: return launch_attn_swp(p, s);             // one wave's MFMAs interleaved with its own softmax arithmetic across tiles
         case 16: return launch_attn_pp<3>(p, s);           // two 4-wave groups per workgroup in ping-pong (VALU slot / MFMA slot)
     }
     return hipErrorInvalidValue;
