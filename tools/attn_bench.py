@@ -25,11 +25,6 @@ def main():
         i = args.index("--cfgs")
         cfgs = [int(c) for c in args[i + 1].split(",")]
         del args[i:i + 2]
-    abls = [0]
-    if "--abl" in args:       # ablation bits of attn_pipe_kernel (1 = no DMA in the loop, 2 = no compute): timing only, results are garbage
-        i = args.index("--abl")
-        abls = [int(c) for c in args[i + 1].split(",")]
-        del args[i:i + 2]
     if len(args) >= 3:
         shapes = [(int(args[0]), int(args[1]), int(args[2]))]
     for B, H, N in shapes:
@@ -40,9 +35,8 @@ def main():
         add = torch.zeros(B, Npad, device="cuda")
         o = torch.empty(B * N, H * 64, device="cuda", dtype=torch.bfloat16)
         fn = lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, 1, st)
-        for cfg, abl in [(c, a) for c in cfgs for a in abls]:
+        for cfg in cfgs:
             lib.uvl_tune_set(b"attn_cfg", cfg)
-            lib.uvl_tune_set(b"attn_abl", abl)
             for _ in range(5):
                 fn()
             torch.cuda.synchronize()
@@ -58,9 +52,8 @@ def main():
                 best = min(best, a.elapsed_time(b) / it * 1e3)
             us = best
             flops = 4.0 * N * N * H * 64 * B
-            print("attention B=%3d H=%2d N=%4d cfg %2d%s  %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)" % (B, H, N, cfg, (" abl %d" % abl) if abl else "", us, flops / us / 1e6, flops / us / 1e6 / 25), flush=True)
+            print("attention B=%3d H=%2d N=%4d cfg %2d  %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)" % (B, H, N, cfg, us, flops / us / 1e6, flops / us / 1e6 / 25), flush=True)
     lib.uvl_tune_set(b"attn_cfg", -1)
-    lib.uvl_tune_set(b"attn_abl", 0)
 
 
 if __name__ == "__main__":

@@ -644,1614 +644,6 @@ __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// attn_pipe_kernel: attn_stream_kernel's tile with the LDS round trips taken off the critical path.  PMC of the version above
-// (profiles/r02_attention_pmc.md): a wave spends 35 % of its cycles in s_waitcnt -- hipcc places every fragment read directly
-// in front of the MFMA that consumes it, eight exposed LDS latencies per tile.  Here ONE 8-fragment register block is
-// time-shared between the K and the V^T fragments of a tile (K fragments are dead once the score MFMAs have issued, V^T
-// fragments once the output MFMAs have), and every read is issued a phase ahead of its use:
-//     top of tile t : the K fragments of tile t are already in registers (requested during the previous tile's P V phase)
-//     A  8 score MFMAs, C operand = -m (+ the key_add term on a tile that carries a mask)
-//     B  request the 8 V^T fragments of tile t into the same registers
-//     C  exp2 / row sums (speculative, see attn_stream_kernel), 64 VALU instructions that cover B's latency
-//     D  own DMAs of tile t+1 landed (vmcnt), barrier, request tile t+2 by DMA into the stage tile t-1 has left
-//     E  bf16 packing + 8 output MFMAs
-//     F  request the K fragments of tile t+1
-// The barrier sits between C and E: a wave that reaches it has finished P V of tile t-1, so that stage is free, and everyone's
-// share of tile t+1 is in LDS before anyone reads it in F.  LDS-DMA is issued from inline asm with an SGPR base and a 32-bit lane
-// offset (the builtin form makes hipcc rebuild a 64-bit VGPR address per instruction inside the loop).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void attn_dma16(uint32_t voff, const char* sbase, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void attn_dma4(uint32_t voff, const char* sbase, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
-typedef __attribute__((address_space(3))) const char* lds_cptr;
-__device__ __forceinline__ bf16x8 lds_read16(uint32_t addr) { return *reinterpret_cast<__attribute__((address_space(3))) const bf16x8*>((lds_cptr)(uintptr_t)addr); }
-
-template <int OCC>
-__global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(const AttnParams p) {
-    constexpr int NS = 3;
-    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
-    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nqb = (p.N + 127) / 128;
-    int qb, h, b;
-    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = p.N, Npad = p.Npad;
-    const size_t bh = (size_t)b * p.H + h;
-    const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
-    const int nt = (N + 63) >> 6;
-    const int q0 = (qb * 4 + wave) * 32;
-    const bool active = q0 < N && !(p.ablate & 2);        // wave-uniform
-    const int qrow = q0 + (lane & 31);
-    const int qld = qrow < N ? qrow : N - 1;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
-    if (!p.q_prescaled) {                                 // test entry point: raw q, scaled (and rounded once more) here
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[kk][e] = f2bf(bf2f(qf[kk][e]) * (0.125f * ATTN_LOG2E));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // q is in registers before the first DMA: the loop's vmcnt counts only DMAs
-
-    // DMA plan: instruction i of wave w fills piece w + 4 (i & 1) (8 rows) of the K tile (i < 2) or of the V^T tile
-    uint32_t voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave + 4 * (i & 1);
-        const int row = 8 * piece + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        voff[i] = i < 2 ? (uint32_t)(row * 128 + chunk * 16) : (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
-    }
-    auto pin = [](const char* q) __attribute__((always_inline)) {
-        const uint64_t u = reinterpret_cast<uint64_t>(q);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-    };
-    const char* Kb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
-    const char* Vb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
-    const char* Ab = pin(reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride));
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem;      // LDS byte address of the ring (0 unless something static precedes it)
-    const uint32_t lds_w = lds0 + wave * 1024;
-    const uint32_t lds_a = lds0 + KADD0 + wave * 256;
-    const uint32_t lane4 = lane * 4;
-    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        const char* kt = Kb + (size_t)t * 8192;
-        const char* vt = Vb + (size_t)t * 128;
-        const char* at = Ab + (size_t)t * 256;
-        attn_dma16(voff[0], kt, lds_w + ST * STAGE);
-        attn_dma16(voff[1], kt, lds_w + ST * STAGE + 4096);
-        attn_dma16(voff[2], vt, lds_w + ST * STAGE + 8192);
-        attn_dma16(voff[3], vt, lds_w + ST * STAGE + 8192 + 4096);
-        attn_dma4(lane4, at, lds_a + ST * 1024);
-    };
-
-    // lane-constant LDS addresses of the fragments: K chunk 2kk+half of row perm(lane & 31), V^T chunk 4jb+2t+half of row lane & 31
-    const int m31 = lane & 31;
-    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
-    uint32_t kaddr[4], vaddr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
-
-    f32x16 o[2], negm;                                     // negm: -m broadcast, the C operand of a plain tile's score MFMAs
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-    bf16x8 fr[8];                                          // the shared K / V^T fragment block
-
-    auto read_k = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + kk] = K fragment (key block jb, d step kk)
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) fr[4 * jb + kk] = lds_read16(kaddr[kk] + ST * STAGE + jb * 4096);
-    };
-    auto read_v = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + 2 t2 + db] = V^T fragment (d block db, keys 32 jb + 16 t2 ..)
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) fr[4 * jb + 2 * t2 + db] = lds_read16(vaddr[jb][t2] + ST * STAGE + db * 4096);
-    };
-
-    auto tile = [&](const int t, auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        const int k0 = t * 64;
-        f32x16 s[2];
-        float psum = 0.f;
-        if (active) {
-            const float* sA = reinterpret_cast<const float*>(smem + KADD0 + ST * 1024 + wave * 256);
-            const float ka_raw = sA[lane];
-            const bool tail = k0 + 64 > N;                                          // wave-uniform
-            const bool masked = __any((k0 + lane < N) ? (ka_raw != 0.f) : true);    // a mask term, or keys beyond N
-            // C operand of the score MFMAs: (key_add * log2 e, -inf beyond N) - m; all registers equal -m on a plain tile
-            auto c_operand = [&](float base, f32x16 (&c)[2]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {      // registers 4gq..4gq+3 = keys 32jb + 16(gq>>1) + 8 half + 4(gq&1) + 0..3
-                        const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
-                        const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
-                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = fmaf(av[e], ATTN_LOG2E, base);
-                            if (tail) v = (k0 + kq + e < N) ? v : -INFINITY;
-                            c[jb][4 * gq + e] = v;
-                        }
-                    }
-            };
-            auto scores = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kk], qf[kk], kk == 0 ? c0 : s[0], 0, 0, 0);
-                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 + kk], qf[kk], kk == 0 ? c1 : s[1], 0, 0, 0);
-                }
-            };
-            auto exp_sum = [&]() __attribute__((always_inline)) {
-                float ps[4] = {0.f, 0.f, 0.f, 0.f};       // four short add chains instead of one long one
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
-                    s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
-                    ps[r & 1] += s[0][r];
-                    ps[2 + (r & 1)] += s[1][r];
-                }
-                psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            };
-            bool redo = (t == 0);
-            if (!redo) {
-                // ---- A..C, speculative: s - m straight from the MFMA ----
-                if (masked) {
-                    c_operand(-m_run, s);
-                    scores(s[0], s[1]);
-                } else {
-                    scores(negm, negm);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                read_v(stc);
-                __builtin_amdgcn_sched_barrier(0);
-                exp_sum();
-                redo = !__all(psum <= 256.0f);            // also catches inf / NaN
-                if (redo) read_k(stc);                    // the exact path needs the K fragments again (LDS still holds the tile)
-            }
-            if (redo) {
-                // ---- exact tile: scores with C = mask term only, true row max, rescale of l and O ----
-                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (masked) {
-                    c_operand(0.f, s);
-                    scores(s[0], s[1]);
-                } else {
-                    scores(zero16, zero16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                read_v(stc);
-                __builtin_amdgcn_sched_barrier(0);
-                float tmax = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                const float m_new = fmaxf(m_run, tmax);
-                if (t != 0) {                             // first tile: l = 0, O = 0
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    l_run *= alpha;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-                }
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[0][r] -= m_new; s[1][r] -= m_new; negm[r] = -m_new; }
-                exp_sum();
-            }
-            l_run += psum;
-        }
-        // ---- D: tile t+1 is complete in LDS for everyone, the stage of tile t-1 is free ----
-        attn_wait_vmcnt<0>();
-        if (t + 1 == nt - 1 && (N & 63)) {                // tile t+1 is the tail tile: zero its K rows / V^T columns beyond N (own pieces)
-            constexpr int SN = (ST + 1) % NS;
-            const int k1 = (t + 1) * 64;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = wave + 4 * (i & 1);
-                const int row = 8 * piece + (lane >> 3);
-                char* at = smem + SN * STAGE + (i < 2 ? 0 : 8192) + piece * 1024 + lane * 16;
-                if (i < 2) {
-                    if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
-                } else {
-                    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-                    const int kb = k1 + chunk * 8;
-                    if (kb + 8 > N) {
-                        u32x4 v = *reinterpret_cast<u32x4*>(at);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            uint32_t wv = v[e];
-                            if (kb + 2 * e >= N) wv &= 0xffff0000u;
-                            if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
-                            v[e] = wv;
-                        }
-                        *reinterpret_cast<u32x4*>(at) = v;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt && !(p.ablate & 1)) issue(t + 2, AttnIC<(ST + 2) % NS>{});
-        if (!active) return;
-        // ---- E: O^T += V^T P^T ----
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                union { uint32_t u[4]; bf16x8 v; } pf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t2 + 2 * e], s[jb][8 * t2 + 2 * e + 1]);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 * jb + 2 * t2 + db], pf.v, o[db], 0, 0, 0);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- F: K fragments of the next tile ----
-        if (t + 1 < nt) read_k(AttnIC<(ST + 1) % NS>{});
-    };
-
-    // prologue: tiles 0 and 1 requested; tile 0 complete (tail fix-up if it is the only tile) before its K fragments are read
-    issue(0, AttnIC<0>{});
-    if (nt > 1) { issue(1, AttnIC<1>{}); attn_wait_vmcnt<5>(); } else { attn_wait_vmcnt<0>(); }
-    if (nt == 1 && (N & 63)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave + 4 * (i & 1);
-            const int row = 8 * piece + (lane >> 3);
-            char* at = smem + (i < 2 ? 0 : 8192) + piece * 1024 + lane * 16;
-            if (i < 2) {
-                if (row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
-            } else {
-                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-                const int kb = chunk * 8;
-                if (kb + 8 > N) {
-                    u32x4 v = *reinterpret_cast<u32x4*>(at);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t wv = v[e];
-                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
-                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
-                        v[e] = wv;
-                    }
-                    *reinterpret_cast<u32x4*>(at) = v;
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (active) read_k(AttnIC<0>{});
-    for (int t0 = 0; t0 < nt; t0 += NS) {
-        tile(t0, AttnIC<0>{});
-        if (t0 + 1 < nt) tile(t0 + 1, AttnIC<1>{});
-        if (t0 + 2 < nt) tile(t0 + 2, AttnIC<2>{});
-    }
-
-    if (qrow < N) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
-        bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = 32 * db + 8 * gq + 4 * half;
-                uint2 w;
-                w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
-                w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
-                *reinterpret_cast<uint2*>(dst + d0) = w;
-            }
-    }
-}
-
-template <int OCC>
-static hipError_t launch_attn_pipe(const AttnParams& p_in, hipStream_t s) {
-    constexpr size_t lds = (size_t)3 * 16384 + (size_t)3 * 4 * 256;
-    auto kern = attn_pipe_kernel<OCC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    g_last_kernel = OCC == 3 ? "attn_pipe_kernel<3>" : "attn_pipe_kernel<2>";
-    const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
-    AttnParams p = p_in;
-    p.xcd_map = total >= 400 ? 1 : 0;
-    p.ablate = g_tune_attn_abl;
-    hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// attn_persist_kernel<NW, NS>: attn_pipe_kernel's tile inside PERSISTENT workgroups.  Ablation of the one-item-per-workgroup
-// kernels at B = 32, H = 16, N = 681 (profiles/r02_attention_pmc.md): skeleton without DMA or arithmetic (q load, barriers,
-// output stores) 34 us, DMA + barriers alone 53 us, arithmetic alone ~58 us, everything 109 us -- the phases ADD, because
-// every workgroup of a round loads q at the same moment, computes at the same moment and stores at the same moment.  Here a
-// workgroup walks a list of (sample, head, query block) items and its K / V^T tile stream never stops: the DMA cursor runs
-// NS-1 tiles ahead of the arithmetic ACROSS item boundaries, the next item's q fragments are requested during the current
-// item's last tile, and the output stores of an item drain while the next item's first tiles are computed.
-// NW waves x 32 queries share a tile (NW = 4: two workgroups per CU; NW = 8: one, half the L2 -> LDS traffic per query).
-// ------------------------------------------------------------------------------------------------
-template <int NW, int NS>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_persist_kernel(const AttnParams p) {
-    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
-    constexpr int KADD0 = NS * STAGE;                     // [NS][NW waves][64] f32 key_add rows
-    constexpr int QB = 32 * NW;                           // queries per item
-    constexpr int NP = 8 / NW;                            // K pieces (and V^T pieces) per wave and tile: 2 or 1
-    constexpr int VM = 2 * NP + 1;                        // VMEM operations per wave and tile
-    static_assert((NW == 4 || NW == 8) && NS >= 3 && NS <= 6, "geometry");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = p.N, Npad = p.Npad, H = p.H;
-    const int nt = (N + 63) >> 6;                         // >= 2 (the launcher sends shorter sequences elsewhere)
-    const int nqb = (N + QB - 1) / QB;
-    const int total = nqb * H * p.B;
-    // item list of this workgroup: workgroup w runs on XCD w % 8 (speed only); an XCD owns a contiguous run of the head-major
-    // item order and its workgroups take the run's items round-robin, so the items in flight on an XCD are neighbours
-    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wpx = gridDim.x >> 3;
-    const int per = (total + 7) >> 3;
-    const int run0 = xcd * per, run_n = min(per, total - run0);
-    const int n_my = widx < run_n ? (run_n - widx + wpx - 1) / wpx : 0;
-    if (n_my <= 0) return;
-
-    auto pin = [](const char* q) __attribute__((always_inline)) {
-        const uint64_t u = reinterpret_cast<uint64_t>(q);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-    };
-    struct Item { int qb, h, b; };
-    auto decode = [&](int k) __attribute__((always_inline)) {
-        const int L = run0 + widx + k * wpx;
-        Item it;
-        it.qb = L % nqb;
-        const int r = L / nqb;
-        it.h = r % H;
-        it.b = r / H;
-        return it;
-    };
-
-    // DMA plan: wave w fills K pieces w (+ 4) and V^T pieces w (+ 4) of a tile and its own copy of the key_add row
-    uint32_t voff_k[NP], voff_v[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int piece = wave + NW * i;
-        const int row = 8 * piece + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        voff_k[i] = (uint32_t)(row * 128 + chunk * 16);
-        voff_v[i] = (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
-    }
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem;
-    const uint32_t lds_w = lds0 + wave * 1024;
-    const uint32_t lds_a = lds0 + KADD0 + wave * 256;
-    const uint32_t lane4 = lane * 4;
-    // DMA cursor: next tile of the stream to request
-    int dk = 0, dt = 0;
-    const char *dKb, *dVb, *dAb;
-    auto dma_item = [&](int k) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        const size_t bh = (size_t)it.b * H + it.h;
-        dKb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
-        dVb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
-        dAb = pin(reinterpret_cast<const char*>(p.key_add + (size_t)it.b * p.key_add_stride));
-    };
-    auto issue = [&](auto stc) __attribute__((always_inline)) {       // request stream tile (dk, dt) into stage ST, advance the cursor
-        constexpr int ST = decltype(stc)::value;
-        if (dk >= n_my) return;
-        const char* kt = dKb + (size_t)dt * 8192;
-        const char* vt = dVb + (size_t)dt * 128;
-        const char* at = dAb + (size_t)dt * 256;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) attn_dma16(voff_k[i], kt, lds_w + ST * STAGE + i * (NW * 1024));
-#pragma unroll
-        for (int i = 0; i < NP; ++i) attn_dma16(voff_v[i], vt, lds_w + ST * STAGE + 8192 + i * (NW * 1024));
-        attn_dma4(lane4, at, lds_a + ST * (NW * 256));
-        if (++dt == nt) { dt = 0; ++dk; if (dk < n_my) dma_item(dk); }
-    };
-
-    // lane-constant LDS addresses of the fragments: K chunk 2kk+half of row perm(lane & 31), V^T chunk 4jb+2t+half of row lane & 31
-    const int m31 = lane & 31;
-    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
-    uint32_t kaddr[4], vaddr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
-
-    // compute cursor: item ck, tile ct; per-item state
-    int ck = 0, ct = 0;
-    bool active = false;
-    int qrow = 0;
-    size_t obase = 0;                                      // element offset of this lane's output row
-    bf16x8 qf[4], qn[4];
-    const float qs = 0.125f * ATTN_LOG2E;
-    auto load_q = [&](int k, bf16x8 (&dst)[4]) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        const bf16_t* Q = p.q + ((size_t)it.b * H + it.h) * Npad * 64;
-        const int qr = (it.qb * NW + wave) * 32 + (lane & 31);
-        const int qld = qr < N ? qr : N - 1;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
-    };
-    auto begin_item = [&](int k) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        const int q0 = (it.qb * NW + wave) * 32;
-        active = q0 < N && !(p.ablate & 2);
-        qrow = q0 + (lane & 31);
-        obase = ((size_t)it.b * N + (qrow < N ? qrow : 0)) * (size_t)(H * 64) + (size_t)it.h * 64;
-    };
-    auto scale_q = [&](bf16x8 (&q)[4]) __attribute__((always_inline)) {
-        if (!p.q_prescaled) {                             // test entry point: raw q, scaled (and rounded once more) here
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) q[kk][e] = f2bf(bf2f(q[kk][e]) * qs);
-        }
-    };
-
-    f32x16 o[2], negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-    bf16x8 fr[8];                                          // the shared K / V^T fragment block
-#ifdef UVL_ATTN_TRACE
-    // tools/probes/attn_trace.hip: shader-clock stamps of one wave at the phase boundaries, 64 per register (one per lane)
-    int tr_v[3] = {0, 0, 0}, tr_n = 0;
-    const bool tr_on = p.trace && blockIdx.x == (unsigned)p.trace_block && wave == p.trace_wave;
-#define ATTN_WL(dst, val, idx) dst = (lane == (idx)) ? (val) : dst
-#define ATTN_STAMP()                                                                                          \
-    if (tr_on && tr_n < 192) {                                                                               \
-        const int tt_ = __builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());         \
-        const int ix_ = __builtin_amdgcn_readfirstlane(tr_n & 63);                                           \
-        if (tr_n < 64) { ATTN_WL(tr_v[0], tt_, ix_); }                                                       \
-        else if (tr_n < 128) { ATTN_WL(tr_v[1], tt_, ix_); }                                                 \
-        else { ATTN_WL(tr_v[2], tt_, ix_); }                                                                 \
-        ++tr_n;                                                                                              \
-    }
-#else
-#define ATTN_STAMP()
-#endif
-
-    auto read_k = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + kk] = K fragment (key block jb, d step kk)
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) fr[4 * jb + kk] = lds_read16(kaddr[kk] + ST * STAGE + jb * 4096);
-    };
-    auto read_v = [&](auto stc) __attribute__((always_inline)) {       // fr[4 jb + 2 t2 + db] = V^T fragment (d block db, keys 32 jb + 16 t2 ..)
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) fr[4 * jb + 2 * t2 + db] = lds_read16(vaddr[jb][t2] + ST * STAGE + db * 4096);
-    };
-    // zero the K rows / V^T columns beyond N of the tile in stage SN (this wave's own pieces, after its own vmcnt wait)
-    auto tail_fix = [&](auto snc, int k1) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value;
-#pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) {
-            const bool isk = i < NP;
-            const int piece = wave + NW * (i % NP);
-            const int row = 8 * piece + (lane >> 3);
-            char* at = smem + SN * STAGE + (isk ? 0 : 8192) + piece * 1024 + lane * 16;
-            if (isk) {
-                if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
-            } else {
-                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-                const int kb = k1 + chunk * 8;
-                if (kb + 8 > N) {
-                    u32x4 v = *reinterpret_cast<u32x4*>(at);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t wv = v[e];
-                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
-                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
-                        v[e] = wv;
-                    }
-                    *reinterpret_cast<u32x4*>(at) = v;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-
-    auto tile = [&](auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        const int t = ct;
-        const int k0 = t * 64;
-        f32x16 s[2];
-        float psum = 0.f;
-        ATTN_STAMP();                                      // 0: top of tile
-        if (active) {
-            const float* sA = reinterpret_cast<const float*>(smem + KADD0 + ST * (NW * 256) + wave * 256);
-            const float ka_raw = sA[lane];
-            const bool tail = k0 + 64 > N;                                          // wave-uniform
-            const bool masked = __any((k0 + lane < N) ? (ka_raw != 0.f) : true);    // a mask term, or keys beyond N
-            // C operand of the score MFMAs: (key_add * log2 e, -inf beyond N) - m; all registers equal -m on a plain tile
-            auto c_operand = [&](float base, f32x16 (&c)[2]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {      // registers 4gq..4gq+3 = keys 32jb + 16(gq>>1) + 8 half + 4(gq&1) + 0..3
-                        const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
-                        const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
-                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = fmaf(av[e], ATTN_LOG2E, base);
-                            if (tail) v = (k0 + kq + e < N) ? v : -INFINITY;
-                            c[jb][4 * gq + e] = v;
-                        }
-                    }
-            };
-            auto scores = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kk], qf[kk], kk == 0 ? c0 : s[0], 0, 0, 0);
-                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 + kk], qf[kk], kk == 0 ? c1 : s[1], 0, 0, 0);
-                }
-            };
-            auto exp_sum = [&]() __attribute__((always_inline)) {
-                float ps[4] = {0.f, 0.f, 0.f, 0.f};       // four short add chains instead of one long one
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
-                    s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
-                    ps[r & 1] += s[0][r];
-                    ps[2 + (r & 1)] += s[1][r];
-                }
-                psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            };
-            bool redo = (t == 0);
-            if (!redo) {
-                // ---- A..C, speculative: s - m straight from the MFMA ----
-                if (masked) {
-                    c_operand(-m_run, s);
-                    scores(s[0], s[1]);
-                } else {
-                    scores(negm, negm);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                ATTN_STAMP();                             // 1: score MFMAs issued
-                read_v(stc);
-                __builtin_amdgcn_sched_barrier(0);
-                exp_sum();
-                redo = !__all(psum <= 256.0f);            // also catches inf / NaN
-                ATTN_STAMP();                             // 2: exp / sums done
-                if (redo) read_k(stc);                    // the exact path needs the K fragments again (LDS still holds the tile)
-            }
-            if (redo) {
-                // ---- exact tile: scores with C = mask term only, true row max, rescale of l and O ----
-                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (masked) {
-                    c_operand(0.f, s);
-                    scores(s[0], s[1]);
-                } else {
-                    scores(zero16, zero16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                read_v(stc);
-                __builtin_amdgcn_sched_barrier(0);
-                float tmax = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                const float m_new = fmaxf(m_run, tmax);
-                if (t != 0) {                             // first tile: l = 0, O = 0
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    l_run *= alpha;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-                }
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[0][r] -= m_new; s[1][r] -= m_new; negm[r] = -m_new; }
-                exp_sum();
-            }
-            l_run += psum;
-        }
-        // ---- D: the next tile of the stream is complete in LDS for everyone, the stage of the previous one is free ----
-        // (t == 0: the previous item's output stores are in the queue behind the DMAs; stores and loads do not retire in order
-        //  with each other, so no counted wait there)
-        // (the counted form also needs the full complement of younger tiles in the queue: not once the stream's last tile has been
-        //  requested, and not behind the q prefetch below, which is younger than the tiles)
-        ATTN_STAMP();                                      // 3 (1 on an exact tile): before the DMA wait
-        if (NS > 3 && t != 0 && t != nt - 1 && dk < n_my) attn_wait_vmcnt<(NS - 3) * VM>(); else attn_wait_vmcnt<0>();
-        ATTN_STAMP();                                      // 4: DMA landed
-        if (t + 1 == nt - 1 && (N & 63)) tail_fix(AttnIC<(ST + 1) % NS>{}, (t + 1) * 64);
-        __builtin_amdgcn_s_barrier();
-        ATTN_STAMP();                                      // 5: past the barrier
-        if (!(p.ablate & 1)) issue(AttnIC<(ST + NS - 1) % NS>{});
-        if (t == nt - 2 && ck + 1 < n_my) load_q(ck + 1, qn);          // next item's q: a whole tile to land before the next wait
-        ATTN_STAMP();                                      // 6: DMA issued
-        if (active) {
-            // ---- E: O^T += V^T P^T ----
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    union { uint32_t u[4]; bf16x8 v; } pf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t2 + 2 * e], s[jb][8 * t2 + 2 * e + 1]);
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[4 * jb + 2 * t2 + db], pf.v, o[db], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ATTN_STAMP();                                      // 7: output MFMAs issued
-        // ---- end of an item: normalise, store, switch to the next item (its q fragments were requested at the top of this tile) ----
-        const bool last_tile = (t == nt - 1);
-        if (last_tile) {
-            if (active && qrow < N) {
-                const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-                const float inv = 1.0f / l_tot;
-                bf16_t* dst = p.o + obase;
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int d0 = 32 * db + 8 * gq + 4 * half;
-                        uint2 w;
-                        w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
-                        w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
-                        *reinterpret_cast<uint2*>(dst + d0) = w;
-                    }
-            }
-            ++ck;
-            ct = 0;
-            if (ck < n_my) {
-                begin_item(ck);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
-                scale_q(qf);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-                m_run = -INFINITY;
-                l_run = 0.f;
-            } else {
-                active = false;
-            }
-        } else {
-            ct = t + 1;
-        }
-        // ---- F: K fragments of the next tile of the stream ----
-        if (active) read_k(AttnIC<(ST + 1) % NS>{});
-    };
-
-    // prologue: q of the first item, the first NS-1 tiles of the stream requested, tile 0 complete for everyone
-    begin_item(0);
-    load_q(0, qf);
-    scale_q(qf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    dma_item(0);
-    issue(AttnIC<0>{});
-    issue(AttnIC<1>{});
-    if (NS > 3) issue(AttnIC<2 % NS>{});
-    if (NS > 4) issue(AttnIC<3 % NS>{});
-    if (NS > 5) issue(AttnIC<4 % NS>{});
-    if (dk < n_my) attn_wait_vmcnt<(NS - 2) * VM>(); else attn_wait_vmcnt<0>();      // short stream: everything requested already
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (active) read_k(AttnIC<0>{});
-    const int total_tiles = n_my * nt;
-    for (int g = 0; g < total_tiles; g += NS) {
-        tile(AttnIC<0>{});
-        if (g + 1 < total_tiles) tile(AttnIC<1>{});
-        if (g + 2 < total_tiles) tile(AttnIC<2>{});
-        if (NS > 3 && g + 3 < total_tiles) tile(AttnIC<3 % NS>{});
-        if (NS > 4 && g + 4 < total_tiles) tile(AttnIC<4 % NS>{});
-        if (NS > 5 && g + 5 < total_tiles) tile(AttnIC<5 % NS>{});
-    }
-#ifdef UVL_ATTN_TRACE
-    if (tr_on) { p.trace[lane] = tr_v[0]; p.trace[64 + lane] = tr_v[1]; p.trace[128 + lane] = tr_v[2]; p.trace[192] = tr_n; }
-#endif
-#undef ATTN_STAMP
-}
-
-template <int NW, int NS>
-static hipError_t launch_attn_persist(const AttnParams& p_in, hipStream_t s) {
-    constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * NW * 256;
-    auto kern = attn_persist_kernel<NW, NS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    static char name[40];
-    if (!name[0]) snprintf(name, sizeof(name), "attn_persist_kernel<%d,%d>", NW, NS);
-    g_last_kernel = name;
-    const int total = ((p_in.N + 32 * NW - 1) / (32 * NW)) * p_in.H * p_in.B;
-    AttnParams p = p_in;
-    p.ablate = g_tune_attn_abl;
-    const int slots = 256 * (NW == 4 ? 2 : 1);            // resident workgroups on the chip
-    const int grid = total < slots ? 8 * ((total + 7) / 8) : slots;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, p);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// attn_pp_kernel<NS>: two persistent 4-wave groups per workgroup in PING-PONG.  Shader-clock trace of attn_persist_kernel
-// (tools/probes/attn_trace.hip, profiles/r02_attention_pmc.md): per 64-key tile a wave needs ~512 cycles of the MFMA pipe and
-// ~870 cycles of the VALU (32 quarter-rate v_exp_f32 = 512, the adds / packs / addressing the rest), and two co-resident waves
-// in the same phase fight for the same pipe.  Here the 8 waves of a workgroup form two groups (waves 0-3 / 4-7: wave w and
-// w + 4 share a SIMD); each group owns its own item list and K / V^T ring, and the WORKGROUP barrier is the phase clock:
-//
-//        slot 2i   :  group 0  VALU slot of its tile i       |  group 1  MFMA slot of its tile i-1
-//        slot 2i+1 :  group 0  MFMA slot of its tile i       |  group 1  VALU slot of its tile i
-//
-//   VALU slot (tile t): request the V^T fragments of tile t and the K fragments of tile t+1 from LDS, turn the scores S(t)
-//                       (they already hold s - m: the running maximum entered the score MFMA as its C operand) into bf16
-//                       numerators with exp2, row sums, speculation check (redo on S itself: the scores are not overwritten)
-//   MFMA slot (tile t): O += V^T P^T (8 MFMAs), item switch after an item's last tile (normalise, store, next q), S(t+1) =
-//                       K Q^T - m (8 MFMAs), wait for this wave's share of tile t+2, request tile t+NS by DMA
-// so on every SIMD one wave issues exponentials while its partner issues MFMAs.  The tile stream of a group never stops at an
-// item boundary (DMA cursor NS-2 tiles ahead, next item's q requested one tile early, stores drain under the next tiles).
-// A row whose keys are ALL masked with -1e10 is not supported (its sum is 0; cat_mask never masks the search tokens,
-// extractor.py:43-50); rows masked entirely with BERT's -10000 are.
-// ------------------------------------------------------------------------------------------------
-// The lane index as a value hipcc cannot hoist: per-lane addresses and predicates of the RARE paths (tail fix-up, mask term, q request,
-// output rows) are recomputed where they are used instead of living in registers across the whole tile loop (the kernel is at its
-// 256-register budget; a spill reload is a scratch load, and hipcc's wait for it would drain the DMA ring).
-__device__ __forceinline__ float attn_max3(float a, float b, float c) {      // one v_max3_f32 (fmaxf chains get a canonicalising v_max per MFMA output)
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ int attn_lane_now() {
-    int l = (int)(threadIdx.x & 63);
-    asm volatile("" : "+v"(l));
-    return l;
-}
-
-template <int NS>
-__global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
-    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
-    constexpr int QOFF = NS * STAGE + NS * 4 * 256;       // per group: ring, [NS][4 waves][64] f32 key_add rows, [4 waves][32][64] bf16 q rows
-    constexpr int WOFF = QOFF + 4 * 4096;                 // [4 waves][64] f32 landing pad of the L2 warm-up requests
-    constexpr int GLDS = WOFF + 4 * 256;
-    constexpr int VM = 5;                                 // VMEM operations per wave and tile: 2 K pieces, 2 V^T pieces, key_add row
-    static_assert(NS == 3, "ring depth (2 x (NS x 17 KB + 16 KB) of LDS)");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, gw = wave & 3;
-    const int N = p.N, Npad = p.Npad, H = p.H;
-    const int nt = (N + 63) >> 6;                         // >= 2 (the launcher sends shorter sequences elsewhere)
-    const int nqb = (N + 127) / 128;
-    const int total = nqb * H * p.B;
-    // items: an XCD owns a contiguous run of the head-major (sample, head, query block) order (workgroup w runs on XCD w % 8,
-    // speed only); the run's items go round-robin to the 2 x (workgroups per XCD) groups, so items in flight are neighbours
-    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, nworkers = 2 * (gridDim.x >> 3);
-    const int per = (total + 7) >> 3;
-    const int run0 = xcd * per, run_n = min(per, total - run0);
-    const int wk = 2 * widx + grp;
-    const int n_my = wk < run_n ? (run_n - wk + nworkers - 1) / nworkers : 0;
-    const int n_g0 = 2 * widx < run_n ? (run_n - 2 * widx + nworkers - 1) / nworkers : 0;    // group 0 never has fewer items
-    if (n_g0 <= 0) return;
-    const int iters = n_g0 * nt;                          // slot pairs of this workgroup (both groups run the same barriers)
-
-    auto pin = [](const char* q) __attribute__((always_inline)) {
-        const uint64_t u = reinterpret_cast<uint64_t>(q);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-    };
-    struct Item { int qb, h, b; };
-    auto decode = [&](int k) __attribute__((always_inline)) {
-        const int L = run0 + wk + k * nworkers;
-        Item it;
-        it.qb = L % nqb;
-        const int r = L / nqb;
-        it.h = r % H;
-        it.b = r / H;
-        return it;
-    };
-
-    char* gsm = smem + grp * GLDS;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem + grp * GLDS;
-    // DMA plan: wave gw of the group fills K pieces gw, gw+4 and V^T pieces gw, gw+4 of a tile and its own copy of the key_add row
-    uint32_t voff_k[2], voff_v[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int piece = gw + 4 * i;
-        const int row = 8 * piece + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        voff_k[i] = (uint32_t)(row * 128 + chunk * 16);
-        voff_v[i] = (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
-    }
-    const uint32_t lds_w = lds0 + gw * 1024;
-    const uint32_t lds_a = lds0 + NS * STAGE + gw * 256;
-    const uint32_t lane4 = lane * 4;
-    int dk = 0, dt = 0;                                    // DMA cursor: next tile of the group's stream to request
-    const char *dKb = nullptr, *dVb = nullptr, *dAb = nullptr;
-    auto dma_item = [&](int k) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        const size_t bh = (size_t)it.b * H + it.h;
-        dKb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
-        dVb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
-        dAb = pin(reinterpret_cast<const char*>(p.key_add + (size_t)it.b * p.key_add_stride));
-    };
-    // request stream tile (dk, dt) into stage ST in five parts (so that the MFMA slot can put one between its MFMAs: a DMA
-    // instruction holds the wave's issue for ~75 cycles, two MFMAs keep the matrix pipe busy for 64), then advance the cursor
-    auto issue_part = [&](auto stc, auto partc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        constexpr int PART = decltype(partc)::value;
-        if (dk >= n_my || (p.ablate & 1)) return;
-        if (PART == 0) attn_dma16(voff_k[0], dKb + (size_t)dt * 8192, lds_w + ST * STAGE);
-        if (PART == 1) attn_dma16(voff_k[1], dKb + (size_t)dt * 8192, lds_w + ST * STAGE + 4096);
-        if (PART == 2) attn_dma16(voff_v[0], dVb + (size_t)dt * 128, lds_w + ST * STAGE + 8192);
-        if (PART == 3) attn_dma16(voff_v[1], dVb + (size_t)dt * 128, lds_w + ST * STAGE + 8192 + 4096);
-        if (PART == 4) {
-            attn_dma4(lane4, dAb + (size_t)dt * 256, lds_a + ST * 1024);
-            if (++dt == nt) { dt = 0; ++dk; if (dk < n_my) dma_item(dk); }
-        }
-    };
-    auto issue = [&](auto stc) __attribute__((always_inline)) {
-        issue_part(stc, AttnIC<0>{});
-        issue_part(stc, AttnIC<1>{});
-        issue_part(stc, AttnIC<2>{});
-        issue_part(stc, AttnIC<3>{});
-        issue_part(stc, AttnIC<4>{});
-    };
-
-    // lane-constant LDS addresses of the fragments: K chunk 2kk+half of row perm(lane & 31), V^T chunk 4jb+2t+half of row lane & 31
-    const int m31 = lane & 31;
-    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
-    uint32_t kaddr[4], vaddr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
-
-    // compute cursor and per-item state
-    int ck = 0, ct = 0;
-    bool active = false, active_n = false;                 // this wave has queries in the current / the next item
-    int qrow = 0;
-    uint32_t obase = 0;                                    // byte offset of this lane's output row (the output is < 4 GB)
-    bf16x8 qf[4];
-    const float qs = 0.125f * ATTN_LOG2E;
-    auto wave_active = [&](int k) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        return (it.qb * 4 + gw) * 32 < N && !(p.ablate & 2);
-    };
-    // q goes HBM -> LDS by DMA as well (this wave's own 32 rows, swizzled like a K tile) and is read back at the item switch:
-    // an ordinary load inside the loop would make hipcc wait on vmcnt -- and with it on every DMA in flight -- at each use of qf
-    const uint32_t lds_q = lds0 + QOFF + gw * 4096;
-    auto request_q = [&](int k) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        const char* qb_ = pin(reinterpret_cast<const char*>(p.q + ((size_t)it.b * H + it.h) * Npad * 64));
-        const int q0 = (it.qb * 4 + gw) * 32;
-        const int ln = attn_lane_now();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 8 * i + (ln >> 3);
-            const int chunk = (ln & 7) ^ ((row >> 1) & 7);
-            const int qr = q0 + row < N ? q0 + row : N - 1;          // rows beyond N repeat the last one (finite data, results discarded)
-            attn_dma16((uint32_t)(qr * 128 + chunk * 16), qb_, lds_q + i * 1024);
-        }
-    };
-    // Every group of the chip reaches its item boundary at about the same moment, and the first tiles of a new head come from
-    // HBM: with a one-tile DMA lead the slots around the boundary ran 1.5-3.5x long (trace, profiles/r02_attention_pmc.md).  So a
-    // whole item ahead, the K and V^T rows of the next item's head are pulled into L2 by sparse 4-byte DMA requests (one lane per
-    // 128-byte line, 64 lines per instruction) that land on a scratch row nobody reads.
-    auto warm_l2 = [&](int k) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        const size_t bh = (size_t)it.b * H + it.h;
-        const char* kb_ = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
-        const char* vb_ = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
-        const uint32_t bytes = (uint32_t)Npad * 128u;                 // both blocks are Npad * 128 bytes, contiguous
-        const uint32_t ln = (uint32_t)attn_lane_now();
-        for (uint32_t c = (uint32_t)gw * 8192u; c < bytes; c += 4u * 8192u) {
-            const uint32_t off = c + ln * 128u < bytes ? c + ln * 128u : bytes - 128u;
-            attn_dma4(off, kb_, lds0 + WOFF + gw * 256);
-            attn_dma4(off, vb_, lds0 + WOFF + gw * 256);
-        }
-    };
-    auto fetch_q = [&]() __attribute__((always_inline)) {            // after this wave's own vmcnt wait
-        const int ln = attn_lane_now();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = lds_read16(lds_q + swz128(ln & 31, 2 * kk + (ln >> 5)));
-    };
-    auto begin_item = [&](int k) __attribute__((always_inline)) {
-        const Item it = decode(k);
-        qrow = (it.qb * 4 + gw) * 32 + (attn_lane_now() & 31);
-        obase = (((uint32_t)it.b * (uint32_t)N + (uint32_t)(qrow < N ? qrow : 0)) * (uint32_t)(H * 64) + (uint32_t)it.h * 64u) * 2u;
-    };
-    auto scale_q = [&](bf16x8 (&q)[4]) __attribute__((always_inline)) {
-        if (!p.q_prescaled) {                             // test entry point: raw q, scaled (and rounded once more) here
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) q[kk][e] = f2bf(bf2f(q[kk][e]) * qs);
-        }
-    };
-
-    f32x16 o[2], s[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; s[0][r] = 0.f; s[1][r] = 0.f; }
-    float m_run = 0.f, l_run = 0.f;
-    bf16x8 frK[8], frV[8];                                 // K fragments of the next tile, V^T fragments of the current one
-
-    auto read_k = [&](auto stc) __attribute__((always_inline)) {       // frK[4 jb + kk] = K fragment (key block jb, d step kk)
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) frK[4 * jb + kk] = lds_read16(kaddr[kk] + ST * STAGE + jb * 4096);
-    };
-    auto read_v = [&](auto stc) __attribute__((always_inline)) {       // frV[4 jb + 2 t2 + db] = V^T fragment (d block db, keys 32 jb + 16 t2 ..)
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) frV[4 * jb + 2 * t2 + db] = lds_read16(vaddr[jb][t2] + ST * STAGE + db * 4096);
-    };
-    // zero the K rows / V^T columns beyond N of the tile in stage SN (this wave's own pieces, after its own vmcnt wait) and put
-    // -inf on the keys beyond N in this wave's copy of the tile's key_add row (whatever the caller's buffer holds there)
-    auto tail_fix = [&](auto snc, int k1) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value;
-        const int ln = attn_lane_now();
-        if (k1 + ln >= N) *reinterpret_cast<float*>(gsm + NS * STAGE + SN * 1024 + gw * 256 + ln * 4) = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool isk = i < 2;
-            const int piece = gw + 4 * (i & 1);
-            const int row = 8 * piece + (ln >> 3);
-            char* at = gsm + SN * STAGE + (isk ? 0 : 8192) + piece * 1024 + ln * 16;
-            if (isk) {
-                if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
-            } else {
-                const int chunk = (ln & 7) ^ ((row >> 1) & 7);
-                const int kb = k1 + chunk * 8;
-                if (kb + 8 > N) {
-                    u32x4 v = *reinterpret_cast<u32x4*>(at);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t wv = v[e];
-                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
-                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
-                        v[e] = wv;
-                    }
-                    *reinterpret_cast<u32x4*>(at) = v;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    // S(tile tn in stage SN) = K Q^T + C with C[key] = key_add[key] * log2 e + base (the staged row holds -inf beyond N, see
-    // tail_fix); base = -m, or 0 on the first tile of an item.  The C block is built here, in the MFMA slot, where the VALU is otherwise idle: one code path for plain and
-    // masked tiles, no per-tile flag, and no 16-register -m block kept across the VALU slot.
-    auto scores = [&](auto snc, float base) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value;
-        const float* sA = reinterpret_cast<const float*>(gsm + NS * STAGE + SN * 1024 + gw * 256);
-        const int hf = attn_lane_now() >> 5;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {              // registers 4gq..4gq+3 = keys 32jb + 16(gq>>1) + 8 half + 4(gq&1) + 0..3
-                const int kq = 32 * jb + 16 * (gq >> 1) + 8 * hf + 4 * (gq & 1);
-                const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[jb][4 * gq + e] = fmaf(av[e], ATTN_LOG2E, base);
-            }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[kk], qf[kk], s[0], 0, 0, 0);
-            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[4 + kk], qf[kk], s[1], 0, 0, 0);
-        }
-    };
-
-#ifdef UVL_ATTN_TRACE
-    int tr_v[3] = {0, 0, 0}, tr_n = 0;
-    const bool tr_on = p.trace && blockIdx.x == (unsigned)p.trace_block && wave == p.trace_wave;
-#define ATTN_WL(dst, val, idx) dst = (lane == (idx)) ? (val) : dst
-#define ATTN_STAMP()                                                                                          \
-    if (tr_on && tr_n < 192) {                                                                               \
-        const int tt_ = __builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());         \
-        const int ix_ = __builtin_amdgcn_readfirstlane(tr_n & 63);                                           \
-        if (tr_n < 64) { ATTN_WL(tr_v[0], tt_, ix_); }                                                       \
-        else if (tr_n < 128) { ATTN_WL(tr_v[1], tt_, ix_); }                                                 \
-        else { ATTN_WL(tr_v[2], tt_, ix_); }                                                                 \
-        ++tr_n;                                                                                              \
-    }
-#ifdef UVL_ATTN_TRACE_FINE
-#define ATTN_STAMP2() ATTN_STAMP()
-#else
-#define ATTN_STAMP2()
-#endif
-#else
-#define ATTN_STAMP()
-#define ATTN_STAMP2()
-#endif
-
-    // ---- VALU slot of the group's current tile (stage ST) ----
-    auto valu_slot = [&](auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        if (ck >= n_my) return;
-        const int t = ct;
-        const bool has_next = !(t == nt - 1 && ck + 1 >= n_my);
-        const bool act_next = has_next && (t == nt - 1 ? active_n : active);
-        if (active) read_v(stc);
-        if (!active && act_next) read_k(AttnIC<(ST + 1) % NS>{});
-        ATTN_STAMP2();                                     // V1: fragment reads issued
-        if (active) {
-            // s holds score - m (m = 0 on the first tile of an item).  The maximum is only raised when some row of the wave grew by
-            // more than 2^8 ("defer-max", decided BEFORE the exponentials: they are computed in place) -- and always on the first
-            // tile.  Two complete versions of the slot body, chosen by one wave-uniform branch: a conditional patch-up of s and O
-            // inside one body makes hipcc copy both register blocks at the join.
-            float tmax = attn_max3(s[0][0], s[1][0], s[0][1]);
-#pragma unroll
-            for (int r = 1; r < 15; r += 2) tmax = attn_max3(tmax, s[0][r + 1], attn_max3(s[1][r], s[1][r + 1], s[0][r + 2 < 16 ? r + 2 : 15]));
-            tmax = attn_max3(tmax, s[1][15], s[0][15]);
-            // (a wave keeps at most ~8 ds_read_b128 in flight: the K fragments of the next tile are requested here, behind the
-            //  maximum, when the V^T reads above have retired)
-            if (act_next) read_k(AttnIC<(ST + 1) % NS>{});
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};           // row-sum partials in four short chains
-            if (t == 0 || __any(tmax > ATTN_DEFER)) {
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                // first tile: m := row maximum (0 for a row whose keys are all masked with -1e10: its numerators are exactly 0)
-                const float delta = t == 0 ? (tmax < -1e9f ? 0.f : tmax) : fmaxf(tmax, 0.f);
-                const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);         // l = 0, O = 0 on the first tile
-                m_run += delta;
-                l_run *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o[0][r] *= alpha;
-                    o[1][r] *= alpha;
-                    s[0][r] = __builtin_amdgcn_exp2f(s[0][r] - delta);
-                    s[1][r] = __builtin_amdgcn_exp2f(s[1][r] - delta);
-                    ps[r & 1] += s[0][r];
-                    ps[2 + (r & 1)] += s[1][r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
-                    s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
-                    ps[r & 1] += s[0][r];
-                    ps[2 + (r & 1)] += s[1][r];
-                }
-            }
-            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        }
-        ATTN_STAMP2();                                     // V2: numerators done
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this slot has landed: after the barrier the stage of tile t may be refilled
-    };
-
-    // ---- MFMA slot of the group's current tile (stage ST) ----
-    auto mfma_slot = [&](auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        if (ck >= n_my) return;
-        const int t = ct;
-        const bool last = (t == nt - 1);
-        const bool has_next = !(last && ck + 1 >= n_my);
-        // this wave's share of stream tile +2 has landed -- it was requested one tile ago, in the previous MFMA slot -- and so has
-        // everything older: the next item's q rows (requested a whole item ago) and the previous item's output stores (issued at the
-        // END of their slot, so that this wait does not sit right behind them)
-        attn_wait_vmcnt<0>();
-        {
-            const int t2i = t + 2 < nt ? t + 2 : t + 2 - nt;          // is that tile the tail tile of its item?
-            if (t2i == nt - 1 && (N & 63)) tail_fix(AttnIC<(ST + 2) % NS>{}, t2i * 64);
-        }
-        ATTN_STAMP2();                                     // M1: DMA wait done
-        // O^T += V^T P^T, and between the MFMA pairs the request of stream tile +3 into the stage of tile t (free: its K and V^T
-        // fragments are in registers everywhere)
-        auto pv_step = [&](auto jbc, auto t2c) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jbc)::value, t2 = decltype(t2c)::value;
-            if (active) {
-                union { uint32_t u[4]; bf16x8 v; } pf;      // bf16 packing here, where the VALU is idle
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[jb][8 * t2 + 2 * e], s[jb][8 * t2 + 2 * e + 1]);
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frV[4 * jb + 2 * t2 + db], pf.v, o[db], 0, 0, 0);
-            }
-        };
-        pv_step(AttnIC<0>{}, AttnIC<0>{});
-        issue_part(stc, AttnIC<0>{});
-        pv_step(AttnIC<0>{}, AttnIC<1>{});
-        issue_part(stc, AttnIC<1>{});
-        pv_step(AttnIC<1>{}, AttnIC<0>{});
-        issue_part(stc, AttnIC<2>{});
-        pv_step(AttnIC<1>{}, AttnIC<1>{});
-        issue_part(stc, AttnIC<3>{});
-        issue_part(stc, AttnIC<4>{});
-        ATTN_STAMP2();                                     // M2/M3: P V issued, DMA requested
-        const bool store_now = last && active;
-        int tn = t + 1;
-        if (last) {
-            // ---- item switch, part 1: the next item's q (its rows are in LDS), so that its first scores can be issued at once ----
-            ++ck;
-            ct = 0;
-            tn = 0;
-            if (ck < n_my) {
-                active = active_n;
-                fetch_q();
-                scale_q(qf);
-            } else {
-                active = false;
-            }
-        } else {
-            ct = t + 1;
-        }
-        if (has_next && active) scores(AttnIC<(ST + 1) % NS>{}, tn == 0 ? 0.f : -m_run);
-        ATTN_STAMP2();                                     // M4: scores issued
-        if (last) {
-            // ---- item switch, part 2: normalise and store the finished item, reset the accumulators, look one item ahead ----
-            if (store_now && qrow < N) {
-                const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-                const float inv = 1.0f / l_tot;
-                bf16_t* dst = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.o) + obase);
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int d0 = 32 * db + 8 * gq + 4 * (attn_lane_now() >> 5);
-                        uint2 w;
-                        w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
-                        w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
-                        *reinterpret_cast<uint2*>(dst + d0) = w;
-                    }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-            m_run = 0.f;
-            l_run = 0.f;
-            if (ck < n_my) begin_item(ck);                 // output rows of the item that starts now
-            if (ck + 1 < n_my) {
-                request_q(ck + 1);                         // a whole item to land (this wave's q rows in LDS have just been consumed)
-                active_n = wave_active(ck + 1);
-                warm_l2(ck + 1);
-            }
-        }
-    };
-
-    // ---- prologue: q of the first item, the ring filled (NS tiles), tiles 0 and 1 complete, S(0) computed ----
-    if (n_my > 0) {
-        begin_item(0);
-        active = wave_active(0);
-        request_q(0);
-        dma_item(0);
-    }
-    issue(AttnIC<0>{});
-    issue(AttnIC<1>{});
-    issue(AttnIC<2>{});
-    if (NS > 3) issue(AttnIC<3 % NS>{});
-    attn_wait_vmcnt<0>();
-    if (n_my > 0) { fetch_q(); scale_q(qf); }
-    if (n_my > 0 && nt == 2 && (N & 63)) tail_fix(AttnIC<1>{}, 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (n_my > 1) { request_q(1); active_n = wave_active(1); warm_l2(1); }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (n_my > 0 && active) {
-        read_k(AttnIC<0>{});
-        scores(AttnIC<0>{}, 0.f);
-    }
-    // ---- the slots: group 0 opens with its VALU slot, group 1 one slot later ----
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int g = 0; g < iters; g += NS) {
-        valu_slot(AttnIC<0>{});
-        __builtin_amdgcn_s_barrier();
-        ATTN_STAMP();
-        mfma_slot(AttnIC<0>{});
-        __builtin_amdgcn_s_barrier();
-        ATTN_STAMP();
-        if (g + 1 < iters) {
-            valu_slot(AttnIC<1>{});
-            __builtin_amdgcn_s_barrier();
-            ATTN_STAMP();
-            mfma_slot(AttnIC<1>{});
-            __builtin_amdgcn_s_barrier();
-            ATTN_STAMP();
-        }
-        if (g + 2 < iters) {
-            valu_slot(AttnIC<2>{});
-            __builtin_amdgcn_s_barrier();
-            ATTN_STAMP();
-            mfma_slot(AttnIC<2>{});
-            __builtin_amdgcn_s_barrier();
-            ATTN_STAMP();
-        }
-        if (NS > 3 && g + 3 < iters) {
-            valu_slot(AttnIC<3 % NS>{});
-            __builtin_amdgcn_s_barrier();
-            ATTN_STAMP();
-            mfma_slot(AttnIC<3 % NS>{});
-            __builtin_amdgcn_s_barrier();
-            ATTN_STAMP();
-        }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-#ifdef UVL_ATTN_TRACE
-    if (tr_on) { p.trace[lane] = tr_v[0]; p.trace[64 + lane] = tr_v[1]; p.trace[128 + lane] = tr_v[2]; p.trace[192] = tr_n; }
-#endif
-#undef ATTN_STAMP
-#undef ATTN_STAMP2
-}
-
-template <int NS>
-static hipError_t launch_attn_pp(const AttnParams& p_in, hipStream_t s) {
-    constexpr size_t lds = 2 * ((size_t)NS * 16384 + (size_t)NS * 4 * 256 + 4 * 4096 + 4 * 256);
-    auto kern = attn_pp_kernel<NS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    static char name[40];
-    if (!name[0]) snprintf(name, sizeof(name), "attn_pp_kernel<%d>", NS);
-    g_last_kernel = name;
-    const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
-    AttnParams p = p_in;
-    p.ablate = g_tune_attn_abl;
-    const int pairs = (total + 1) / 2;                    // two groups per workgroup
-    const int grid = pairs < 256 ? 8 * ((pairs + 7) / 8) : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// attn_swp_kernel: software-pipelined across key tiles INSIDE a wave.  Measured on the variants above (trace probe,
-// profiles/r02_attention_pmc.md): per 64-key tile a wave needs ~512 cycles of the MFMA pipe and ~870 cycles of VALU issue
-// (32 quarter-rate v_exp_f32), and two waves of a SIMD do NOT hide each other's phases -- an 8-MFMA group takes 420-520 cycles
-// beside a partner's exponentials, a tile costs VALU + MFMA.  What does overlap is ONE wave's own instruction stream: a VALU
-// instruction issued between two MFMAs executes while the matrix pipe works.  So the steady-state iteration t of a wave issues
-//     8 MFMAs  O += V^T(t-1) P^T(t-1)        (numerators of the PREVIOUS tile, packed)
-//     8 MFMAs  S(t+1) = K(t+1) Q^T - m        (scores of the NEXT tile, second score block)
-// interleaved one by one with the softmax arithmetic of tile t (exp2 in place, row sums, bf16 packing).  The score blocks and the
-// K / V^T fragment blocks are double-buffered in registers across iterations (K fragments of tile t+2 and V^T fragments of tile t
-// are requested at the end of iteration t, behind the tile barrier), the ring has 4 stages so that the loop unrolls by 4 with
-// compile-time stage offsets and score-block names.  Iterations that cannot run the interleaved form -- first and last tile, a next
-// tile that carries a mask term, a row maximum that grew by more than 2^8 -- run the same work sequentially (exact rescale there).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_swp_kernel(const AttnParams p) {
-    constexpr int NS = 4;
-    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
-    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nqb = (p.N + 127) / 128;
-    int qb, h, b;
-    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = p.N, Npad = p.Npad;
-    const size_t bh = (size_t)b * p.H + h;
-    const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
-    const int nt = (N + 63) >> 6;
-    const int q0 = (qb * 4 + wave) * 32;
-    const bool active = q0 < N;                           // wave-uniform
-    const int qrow = q0 + (lane & 31);
-    const int qld = qrow < N ? qrow : N - 1;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
-    if (!p.q_prescaled) {                                 // test entry point: raw q, scaled (and rounded once more) here
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[kk][e] = f2bf(bf2f(qf[kk][e]) * (0.125f * ATTN_LOG2E));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // q is in registers before the first DMA: the loop's vmcnt counts only DMAs
-
-    uint32_t voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave + 4 * (i & 1);
-        const int row = 8 * piece + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        voff[i] = i < 2 ? (uint32_t)(row * 128 + chunk * 16) : (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
-    }
-    auto pin = [](const char* q) __attribute__((always_inline)) {
-        const uint64_t u = reinterpret_cast<uint64_t>(q);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-    };
-    const char* Kb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
-    const char* Vb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
-    const char* Ab = pin(reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride));
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem;
-    const uint32_t lds_w = lds0 + wave * 1024;
-    const uint32_t lds_a = lds0 + KADD0 + wave * 256;
-    const uint32_t lane4 = lane * 4;
-    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        const char* kt = Kb + (size_t)t * 8192;
-        const char* vt = Vb + (size_t)t * 128;
-        const char* at = Ab + (size_t)t * 256;
-        attn_dma16(voff[0], kt, lds_w + ST * STAGE);
-        attn_dma16(voff[1], kt, lds_w + ST * STAGE + 4096);
-        attn_dma16(voff[2], vt, lds_w + ST * STAGE + 8192);
-        attn_dma16(voff[3], vt, lds_w + ST * STAGE + 8192 + 4096);
-        attn_dma4(lane4, at, lds_a + ST * 1024);
-    };
-    const int m31 = lane & 31;
-    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
-    uint32_t kaddr[4], vaddr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
-
-    f32x16 o[2], sc[2][2];                                 // sc[tile & 1][key block]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-    float m_run = 0.f, l_run = 0.f;
-    bf16x8 frK[8], frV[8];                                 // K fragments of tile t+1, V^T fragments of tile t-1 (at the top of iteration t)
-    union PF { uint32_t u[4]; bf16x8 v; } pf[4];           // packed numerators of tile t-1: fragment (jb, t2) = pf[2 jb + t2]
-
-    auto read_k = [&](auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) frK[4 * jb + kk] = lds_read16(kaddr[kk] + ST * STAGE + jb * 4096);
-    };
-    auto read_v = [&](auto stc) __attribute__((always_inline)) {       // frV[2 f + db], f = 2 jb + t2
-        constexpr int ST = decltype(stc)::value;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) frV[4 * jb + 2 * t2 + db] = lds_read16(vaddr[jb][t2] + ST * STAGE + db * 4096);
-    };
-    auto tail_fix = [&](auto snc, int k1) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value;
-        const int ln = attn_lane_now();
-        if (k1 + ln >= N) *reinterpret_cast<float*>(smem + KADD0 + SN * 1024 + wave * 256 + ln * 4) = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool isk = i < 2;
-            const int piece = wave + 4 * (i & 1);
-            const int row = 8 * piece + (ln >> 3);
-            char* at = smem + SN * STAGE + (isk ? 0 : 8192) + piece * 1024 + ln * 16;
-            if (isk) {
-                if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
-            } else {
-                const int chunk = (ln & 7) ^ ((row >> 1) & 7);
-                const int kb = k1 + chunk * 8;
-                if (kb + 8 > N) {
-                    u32x4 v = *reinterpret_cast<u32x4*>(at);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t wv = v[e];
-                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
-                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
-                        v[e] = wv;
-                    }
-                    *reinterpret_cast<u32x4*>(at) = v;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    auto mask_flag = [&](auto snc, int tn) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value;
-        const int ln = attn_lane_now();
-        const float ka = *reinterpret_cast<const float*>(smem + KADD0 + SN * 1024 + wave * 256 + ln * 4);
-        return (bool)__any((tn * 64 + ln < N) ? (ka != 0.f) : true);
-    };
-    // scores of the tile in stage SN into sc[bi]: K fragments in frK; C = base (+ key_add * log2 e on a masked tile, -inf beyond N)
-    auto scores_seq = [&](auto snc, auto bic, bool masked, float base) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value, BI = decltype(bic)::value;
-        if (masked) {
-            const float* sA = reinterpret_cast<const float*>(smem + KADD0 + SN * 1024 + wave * 256);
-            const int hf = attn_lane_now() >> 5;
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int kq = 32 * jb + 16 * (gq >> 1) + 8 * hf + 4 * (gq & 1);
-                    const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sc[BI][jb][4 * gq + e] = fmaf(av[e], ATTN_LOG2E, base);
-                }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sc[BI][0][r] = base; sc[BI][1][r] = base; }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            sc[BI][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[kk], qf[kk], sc[BI][0], 0, 0, 0);
-            sc[BI][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[4 + kk], qf[kk], sc[BI][1], 0, 0, 0);
-        }
-    };
-    auto pv_seq = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frV[2 * f + db], pf[f].v, o[db], 0, 0, 0);
-    };
-
-    // ---- one iteration: softmax of tile t (stage ST), O += V^T P^T of tile t-1, scores of tile t+1 ----
-    auto iter = [&](const int t, auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        constexpr int CUR = ST & 1, NXT = CUR ^ 1;
-        const bool has_next = t + 1 < nt;
-        // ---- tile t+1 complete in LDS for everyone (requested one iteration ago); the stage of tile t-2 is free: request tile t+2 ----
-        attn_wait_vmcnt<0>();
-        if (t + 1 == nt - 1 && t + 1 >= 2 && (N & 63)) tail_fix(AttnIC<(ST + 1) % NS>{}, (t + 1) * 64);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt && !(p.ablate & 1)) issue(t + 2, AttnIC<(ST + 2) % NS>{});
-        if (active) {
-            // the fragments of this iteration (they live in registers only inside it): V^T(t-1) for the output MFMAs, K(t+1) for the scores
-            if (t >= 1) read_v(AttnIC<(ST + NS - 1) % NS>{});
-            if (has_next) read_k(AttnIC<(ST + 1) % NS>{});
-            const bool masked_next = has_next && mask_flag(AttnIC<(ST + 1) % NS>{}, t + 1);
-            float tmax = attn_max3(sc[CUR][0][0], sc[CUR][1][0], sc[CUR][0][1]);
-#pragma unroll
-            for (int r = 1; r < 15; r += 2) tmax = attn_max3(tmax, sc[CUR][0][r + 1], attn_max3(sc[CUR][1][r], sc[CUR][1][r + 1], sc[CUR][0][r + 2 < 16 ? r + 2 : 15]));
-            tmax = attn_max3(tmax, sc[CUR][1][15], sc[CUR][0][15]);
-            const bool fast = t >= 1 && has_next && !masked_next && !__any(tmax > ATTN_DEFER);
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};
-            if (fast) {
-                // ---- interleaved: MFMA slot i, then the exp2 / add (/ pack) of one score pair ----
-                auto slot = [&](auto ic) __attribute__((always_inline)) {
-                    constexpr int I = decltype(ic)::value;
-                    if constexpr (I < 8) {                 // O += V^T(t-1) P^T(t-1): fragment f = I >> 1, d block I & 1
-                        o[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frV[I], pf[I >> 1].v, o[I & 1], 0, 0, 0);
-                    } else {                               // S(t+1): d step (I - 8) >> 1, key block (I - 8) & 1
-                        // the C operand -m is written into the first block only (16 v_mov, in slot 7); the second key block's chain
-                        // opens first and reads it from there
-                        constexpr int kk = (I - 8) >> 1, jb = ((I - 8) & 1) ^ 1;
-                        if constexpr (kk == 0 && jb == 1) sc[NXT][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[4 + kk], qf[kk], sc[NXT][0], 0, 0, 0);
-                        else sc[NXT][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[4 * jb + kk], qf[kk], sc[NXT][jb], 0, 0, 0);
-                    }
-                    if constexpr (I == 7) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[NXT][0][r] = -m_run;
-                    }
-                    constexpr int jbe = I >> 3, r0 = 2 * (I & 7);   // the score pair of this slot
-                    sc[CUR][jbe][r0] = __builtin_amdgcn_exp2f(sc[CUR][jbe][r0]);
-                    sc[CUR][jbe][r0 + 1] = __builtin_amdgcn_exp2f(sc[CUR][jbe][r0 + 1]);
-                    ps[2 * jbe] += sc[CUR][jbe][r0];
-                    ps[2 * jbe + 1] += sc[CUR][jbe][r0 + 1];
-                    if constexpr (I >= 8 && I < 15) {      // packing trails the output MFMAs (slots 0-7 read the previous tile's pf): pairs 2(I-8), 2(I-8)+1
-#pragma unroll
-                        for (int q = 2 * (I - 8); q < 2 * (I - 8) + 2; ++q) {
-                            const int jq = q >> 3, rq = 2 * (q & 7);
-                            pf[2 * jq + (rq >> 3)].u[(rq & 7) >> 1] = pack_bf16x2(sc[CUR][jq][rq], sc[CUR][jq][rq + 1]);
-                        }
-                    }
-                };
-                slot(AttnIC<0>{}); slot(AttnIC<1>{}); slot(AttnIC<2>{}); slot(AttnIC<3>{});
-                slot(AttnIC<4>{}); slot(AttnIC<5>{}); slot(AttnIC<6>{}); slot(AttnIC<7>{});
-                slot(AttnIC<8>{}); slot(AttnIC<9>{}); slot(AttnIC<10>{}); slot(AttnIC<11>{});
-                slot(AttnIC<12>{}); slot(AttnIC<13>{}); slot(AttnIC<14>{}); slot(AttnIC<15>{});
-#pragma unroll
-                for (int q = 14; q < 16; ++q) {            // the last two pairs (exponentiated in slots 14, 15)
-                    const int jq = q >> 3, rq = 2 * (q & 7);
-                    pf[2 * jq + (rq >> 3)].u[(rq & 7) >> 1] = pack_bf16x2(sc[CUR][jq][rq], sc[CUR][jq][rq + 1]);
-                }
-            } else {
-                // ---- sequential form: previous tile's P V first (O complete before a rescale), exact maximum, then the next scores ----
-                if (t >= 1) pv_seq();
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                const float delta = t == 0 ? (tmax < -1e9f ? 0.f : tmax) : fmaxf(tmax, 0.f);    // first tile: m := row maximum
-                const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-                m_run += delta;
-                l_run *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o[0][r] *= alpha;
-                    o[1][r] *= alpha;
-                    sc[CUR][0][r] = __builtin_amdgcn_exp2f(sc[CUR][0][r] - delta);
-                    sc[CUR][1][r] = __builtin_amdgcn_exp2f(sc[CUR][1][r] - delta);
-                    ps[r & 1] += sc[CUR][0][r];
-                    ps[2 + (r & 1)] += sc[CUR][1][r];
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int jq = q >> 3, rq = 2 * (q & 7);
-                    pf[2 * jq + (rq >> 3)].u[(rq & 7) >> 1] = pack_bf16x2(sc[CUR][jq][rq], sc[CUR][jq][rq + 1]);
-                }
-                if (has_next) scores_seq(AttnIC<(ST + 1) % NS>{}, AttnIC<NXT>{}, masked_next, -m_run);
-            }
-            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        }
-    };
-
-    // ---- prologue: tiles 0 and 1 requested and complete, S(0) (raw scores) computed ----
-    issue(0, AttnIC<0>{});
-    if (nt > 1) issue(1, AttnIC<1>{});
-    attn_wait_vmcnt<0>();
-    if (nt == 1 && (N & 63)) tail_fix(AttnIC<0>{}, 0);
-    if (nt == 2 && (N & 63)) tail_fix(AttnIC<1>{}, 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (active) {
-        read_k(AttnIC<0>{});
-        scores_seq(AttnIC<0>{}, AttnIC<0>{}, mask_flag(AttnIC<0>{}, 0), 0.f);
-    }
-    for (int t0 = 0; t0 < nt; t0 += NS) {
-        iter(t0, AttnIC<0>{});
-        if (t0 + 1 < nt) iter(t0 + 1, AttnIC<1>{});
-        if (t0 + 2 < nt) iter(t0 + 2, AttnIC<2>{});
-        if (t0 + 3 < nt) iter(t0 + 3, AttnIC<3>{});
-    }
-    if (active) {                                          // the last tile's numerators (its stage is still intact)
-        switch ((nt - 1) % NS) {
-            case 0: read_v(AttnIC<0>{}); break;
-            case 1: read_v(AttnIC<1>{}); break;
-            case 2: read_v(AttnIC<2>{}); break;
-            default: read_v(AttnIC<3>{}); break;
-        }
-        pv_seq();
-    }
-
-    if (qrow < N) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
-        bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = 32 * db + 8 * gq + 4 * half;
-                uint2 w;
-                w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
-                w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
-                *reinterpret_cast<uint2*>(dst + d0) = w;
-            }
-    }
-}
-
-static hipError_t launch_attn_swp(const AttnParams& p_in, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * 16384 + (size_t)4 * 4 * 256;
-    auto kern = attn_swp_kernel;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    g_last_kernel = "attn_swp_kernel";
-    const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
-    AttnParams p = p_in;
-    p.xcd_map = total >= 400 ? 1 : 0;
-    p.ablate = g_tune_attn_abl;
-    hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
-    return hipGetLastError();
-}
-
 template <int NS>
 static hipError_t launch_attn_stream(const AttnParams& p_in, hipStream_t s) {
     constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256;
@@ -2316,7 +708,6 @@ static hipError_t launch_attn_cfg(const AttnParams& p_in, hipStream_t s) {
 }
 
 int g_tune_attn_cfg = -1;      // tools/attn_bench.py override
-int g_tune_attn_abl = 0;       // tools/attn_bench.py: ablation bits of attn_pipe_kernel (1 = no DMA in the loop, 2 = no compute); results are garbage
 
 static int pick_attn_cfg(const AttnParams& p) {
     int cfg = g_tune_attn_cfg;
@@ -2371,14 +762,6 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 7: return launch_attn_cfg<2, 4, 2>(p, s);     // 64 queries x 4 key quarters (8 waves, 133 KB of LDS)
         case 8: return launch_attn_stream<3>(p, s);        // batched: 128 queries per workgroup, speculative tiles
         case 9: return launch_attn_stream<2>(p, s);
-        case 10: return launch_attn_pipe<3>(p, s);         // + fragment reads a phase ahead of their use
-        case 11: return launch_attn_pipe<2>(p, s);         // the same with 2 waves per SIMD (256 registers: nothing spills)
-        case 12: return launch_attn_persist<4, 3>(p, s);   // persistent workgroups, 128 queries per item
-        case 13: return launch_attn_persist<4, 4>(p, s);
-        case 14: return launch_attn_persist<8, 4>(p, s);   // 256 queries per item, one workgroup per CU
-        case 15: return launch_attn_persist<8, 6>(p, s);
-        case 18: return launch_attn_swp(p, s);             // one wave's MFMAs interleaved with its own softmax arithmetic across tiles
-        case 16: return launch_attn_pp<3>(p, s);           // two 4-wave groups per workgroup in ping-pong (VALU slot / MFMA slot)
     }
     return hipErrorInvalidValue;
 }

@@ -8,7 +8,6 @@ namespace uvl {
 
 // name of the kernel instantiation the last launcher picked (for per-kernel profiles)
 extern thread_local const char* g_last_kernel;
-extern int g_tune_attn_abl;
 extern int g_tune_attn_cfg;      // tools/attn_bench.py override of the attention configuration (-1 = heuristic)
 extern int g_tune_gemm_gm;       // override of the grouped tile order (-1 = heuristic, 0 = panel map, g = group of g M-tiles)
 extern int g_tune_gemm_cfg;      // tools/gemm_bench.py override of the plain-GEMM tile configuration (-1 = heuristic)
@@ -45,10 +44,6 @@ struct AttnParams {
     bf16_t* o = nullptr;                                      // [B*N, H*64]
     int B = 0, H = 0, N = 0, Npad = 0;
     int xcd_map = 0;                                          // set by the launcher: query blocks of a head share an XCD (see attn_decode_block)
-    int ablate = 0;                                           // measurement aid (1 = no DMA in the loop, 2 = no arithmetic), 0 in the product
-#ifdef UVL_ATTN_TRACE
-    int* trace = nullptr; int trace_block = 0, trace_wave = 0;   // tools/probes/attn_trace.hip only
-#endif
     int q_prescaled = 0;                                      // 1: q already carries the factor log2(e)/8 (GemmParams.q_scale of the QKV GEMM)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);

@@ -916,7 +916,6 @@ extern "C" int uvl_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_cfg")) { uvl::g_tune_gemm_cfg = value; return UVL_OK; }
     if (!strcmp(key, "gemm_gm")) { uvl::g_tune_gemm_gm = value; return UVL_OK; }
     if (!strcmp(key, "attn_cfg")) { uvl::g_tune_attn_cfg = value; return UVL_OK; }
-    if (!strcmp(key, "attn_abl")) { uvl::g_tune_attn_abl = value; return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown tuning key '%s'", key);
 }
 
