@@ -1,6 +1,7 @@
 // Row-wise (HBM/L2-bound) kernels of the frame: LayerNorm, patch gather, BERT embedding, mask setup,
 // contrastive logits, head prologue/epilogue and the weight packers.  One wave64 per token row,
 // 16-byte vector loads, wave shuffles for the reductions.
+#include <cstdio>
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
@@ -182,9 +183,18 @@ __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const L
 // from 873 rows on (UVLTrack-L, two or more sequences) 1 and 4 measure the same.
 static int ln_waves_per_block(int M) { return M <= 768 ? 1 : 4; }
 
+// name of the instantiation as rocprofv3 prints it (bench.py keys its per-kernel rooflines and the committed PMC traffic on it)
+static const char* ln_name(bool pair, int nv, bool full, bool slabs, bool ct) {
+    static char names[2][5][2][2][2][40];              // interned: the profiler keeps the pointer
+    char* name = names[pair][nv & 7 ? (nv > 4 ? 4 : nv) : 0][full][slabs][ct];
+    if (!name[0]) snprintf(name, 40, "%s<%d,%d,%d,%d>", pair ? "ln_pair_kernel" : "ln_kernel", nv, (int)full, (int)slabs, (int)ct);
+    return name;
+}
+
 template <int NV, bool FULL>
 static void launch_ln_variant(const LnParams& p, int grid, int wpb, hipStream_t s) {
     const bool slabs = p.nsplit > 0, ct = p.ct_x != nullptr;
+    g_last_kernel = ln_name(false, NV, FULL, slabs, ct);
     if (slabs && ct) hipLaunchKernelGGL((ln_kernel<NV, FULL, true, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
     else if (slabs) hipLaunchKernelGGL((ln_kernel<NV, FULL, true, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
     else if (ct) hipLaunchKernelGGL((ln_kernel<NV, FULL, false, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
@@ -206,6 +216,7 @@ hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
 template <int NV, bool FULL>
 static void launch_ln_pair_variant(const LnParams& a, const LnParams& b, int ga, int gb, int wpb, hipStream_t s) {
     const bool slabs = a.nsplit > 0 || b.nsplit > 0, ct = a.ct_x != nullptr;
+    g_last_kernel = ln_name(true, NV, FULL, slabs, ct);
     if (slabs && ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
     else if (slabs) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
     else if (ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
