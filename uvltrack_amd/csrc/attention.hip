@@ -644,334 +644,6 @@ __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// attn_hp_kernel: the streaming tile, software-pipelined INSIDE a wave at half-tile (32-key) granularity.
-// Measured on round-2's variants (profiles/r02_attention_pmc.md): per 64-key tile a wave needs ~512 cycles of the MFMA pipe and
-// ~870 cycles of VALU issue (32 quarter-rate v_exp_f32), and two waves of a SIMD do not hide each other's phases -- what overlaps
-// with a wave's MFMAs is that wave's own following instructions.  So half-step h (key block h & 1 of tile h >> 1) issues
-//     4 MFMAs  O += V^T P^T of half-step h-1        (its numerators were packed at the end of h-1)
-//     4 MFMAs  S of half-step h+1 = K Q^T - m        (into the score block half-step h-1 has left)
-// one by one between the softmax arithmetic of half-step h (16 x exp2 in place, row sums, bf16 packing: 5 VALU per MFMA).  The
-// register blocks are half-tile sized (two 16-register score blocks, two 8-register numerator blocks, K / V^T fragment blocks of 4
-// fragments, double-buffered: the fragments of half-step h+1 are requested at the top of h), which is what lets hipcc allocate it.
-// Half-steps that cannot run interleaved -- first and last, a next tile that carries a mask term, a row maximum that grew by more
-// than 2^8 -- run the same work sequentially with the exact rescale.  One barrier per tile; 4-stage ring, DMA two tiles ahead.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void attn_dma16(uint32_t voff, const char* sbase, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void attn_dma4(uint32_t voff, const char* sbase, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
-typedef __attribute__((address_space(3))) const char* lds_cptr;
-__device__ __forceinline__ bf16x8 lds_read16(uint32_t addr) { return *reinterpret_cast<__attribute__((address_space(3))) const bf16x8*>((lds_cptr)(uintptr_t)addr); }
-__device__ __forceinline__ float attn_max3(float a, float b, float c) {      // one v_max3_f32 (fmaxf chains get a canonicalising v_max per MFMA output)
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-// The lane index as a value hipcc cannot hoist: per-lane addresses of the RARE paths are recomputed where they are used instead of
-// living in registers across the whole tile loop (a spill reload is a scratch load, and hipcc's wait for it would drain the DMA ring).
-__device__ __forceinline__ int attn_lane_now() {
-    int l = (int)(threadIdx.x & 63);
-    asm volatile("" : "+v"(l));
-    return l;
-}
-
-__global__ __launch_bounds__(256, 2) void attn_hp_kernel(const AttnParams p) {
-    constexpr int NS = 4;
-    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
-    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nqb = (p.N + 127) / 128;
-    int qb, h, b;
-    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = p.N, Npad = p.Npad;
-    const size_t bh = (size_t)b * p.H + h;
-    const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
-    const int nt = (N + 63) >> 6;
-    const int q0 = (qb * 4 + wave) * 32;
-    const bool active = q0 < N;                           // wave-uniform
-    const int qrow = q0 + (lane & 31);
-    const int qld = qrow < N ? qrow : N - 1;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
-    if (!p.q_prescaled) {                                 // test entry point: raw q, scaled (and rounded once more) here
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[kk][e] = f2bf(bf2f(qf[kk][e]) * (0.125f * ATTN_LOG2E));
-    }
-    // q is in registers before the first DMA, and hipcc KNOWS it (the empty asm consumes the fragments, so its own vmcnt wait for
-    // these loads sits here): otherwise it waits -- vmcnt(3..0), i.e. for every DMA in flight as well -- in front of each MFMA
-    // that reads qf, in every half-step
-    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    uint32_t voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave + 4 * (i & 1);
-        const int row = 8 * piece + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        voff[i] = i < 2 ? (uint32_t)(row * 128 + chunk * 16) : (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
-    }
-    auto pin = [](const char* q) __attribute__((always_inline)) {
-        const uint64_t u = reinterpret_cast<uint64_t>(q);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-    };
-    const char* Kb = pin(reinterpret_cast<const char*>(p.k + bh * Npad * 64));
-    const char* Vb = pin(reinterpret_cast<const char*>(p.vt + bh * 64 * Npad));
-    const char* Ab = pin(reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride));
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cptr)smem;
-    const uint32_t lds_w = lds0 + wave * 1024;
-    const uint32_t lds_a = lds0 + KADD0 + wave * 256;
-    const uint32_t lane4 = lane * 4;
-    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        const char* kt = Kb + (size_t)t * 8192;
-        const char* vt = Vb + (size_t)t * 128;
-        const char* at = Ab + (size_t)t * 256;
-        attn_dma16(voff[0], kt, lds_w + ST * STAGE);
-        attn_dma16(voff[1], kt, lds_w + ST * STAGE + 4096);
-        attn_dma16(voff[2], vt, lds_w + ST * STAGE + 8192);
-        attn_dma16(voff[3], vt, lds_w + ST * STAGE + 8192 + 4096);
-        attn_dma4(lane4, at, lds_a + ST * 1024);
-    };
-    const int m31 = lane & 31;
-    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
-    uint32_t kaddr[4], vaddr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) kaddr[kk] = lds0 + swz128(kperm, 2 * kk + half);
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) vaddr[jb][t] = lds0 + 8192 + swz128(m31, 4 * jb + 2 * t + half);
-
-    f32x16 o[2], negm, sc[2];                              // sc[key block]: scores, then numerators (in place)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
-    float m_run = 0.f, l_run = 0.f;
-    bf16x8 frK[4], frV[2][4];                              // K fragments: requested at the top of the half-step that uses them (after its four
-                                                           // output MFMAs); V^T fragments: a half-step ahead, indexed by the consumer's parity
-    union PF { uint32_t u[4]; bf16x8 v; } pf[2][2];        // packed numerators of key block jb: pf[jb][t2]
-
-    // K fragments of key block JB of the tile in stage ST into frK[BUF]; V^T fragments (both d blocks of the two 16-key steps)
-    auto read_k = [&](auto stc, auto jbc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value, JB = decltype(jbc)::value;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) frK[kk] = lds_read16(kaddr[kk] + ST * STAGE + JB * 4096);
-    };
-    auto read_v = [&](auto stc, auto jbc, auto bufc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value, JB = decltype(jbc)::value, BUF = decltype(bufc)::value;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) frV[BUF][2 * t2 + db] = lds_read16(vaddr[JB][t2] + ST * STAGE + db * 4096);
-    };
-    auto tail_fix = [&](auto snc, int k1) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value;
-        const int ln = attn_lane_now();
-        if (k1 + ln >= N) *reinterpret_cast<float*>(smem + KADD0 + SN * 1024 + wave * 256 + ln * 4) = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool isk = i < 2;
-            const int piece = wave + 4 * (i & 1);
-            const int row = 8 * piece + (ln >> 3);
-            char* at = smem + SN * STAGE + (isk ? 0 : 8192) + piece * 1024 + ln * 16;
-            if (isk) {
-                if (k1 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
-            } else {
-                const int chunk = (ln & 7) ^ ((row >> 1) & 7);
-                const int kb = k1 + chunk * 8;
-                if (kb + 8 > N) {
-                    u32x4 v = *reinterpret_cast<u32x4*>(at);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t wv = v[e];
-                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
-                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
-                        v[e] = wv;
-                    }
-                    *reinterpret_cast<u32x4*>(at) = v;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    // does key block JB of the tile tn in stage SN carry a mask term (or keys beyond N)?
-    auto mask_flag = [&](auto snc, auto jbc, int tn) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value, JB = decltype(jbc)::value;
-        const int ln = attn_lane_now() & 31;
-        const float ka = *reinterpret_cast<const float*>(smem + KADD0 + SN * 1024 + wave * 256 + (32 * JB + ln) * 4);
-        return (bool)__any((tn * 64 + 32 * JB + ln < N) ? (ka != 0.f) : true);
-    };
-    // sequential scores of key block JB (tile in stage SN, fragments in frK) into sc[JB]: C = base (+ key_add * log2 e, -inf beyond N)
-    auto scores_seq = [&](auto snc, auto jbc, bool masked, float base) __attribute__((always_inline)) {
-        constexpr int SN = decltype(snc)::value, JB = decltype(jbc)::value;
-        if (masked) {
-            const float* sA = reinterpret_cast<const float*>(smem + KADD0 + SN * 1024 + wave * 256);
-            const int hf = attn_lane_now() >> 5;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {              // registers 4gq..4gq+3 = keys 32 JB + 16(gq>>1) + 8 half + 4(gq&1) + 0..3
-                const float4 a4 = *reinterpret_cast<const float4*>(sA + 32 * JB + 16 * (gq >> 1) + 8 * hf + 4 * (gq & 1));
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sc[JB][4 * gq + e] = fmaf(av[e], ATTN_LOG2E, base);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[JB][r] = base;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) sc[JB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[kk], qf[kk], sc[JB], 0, 0, 0);
-    };
-    auto pv_seq = [&](auto jbc, auto bufc) __attribute__((always_inline)) {    // O += V^T P^T of key block JB (numerators in pf[JB], fragments in frV[BUF])
-        constexpr int JB = decltype(jbc)::value, BUF = decltype(bufc)::value;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frV[BUF][2 * t2 + db], pf[JB][t2].v, o[db], 0, 0, 0);
-    };
-
-    // ---- half-step: key block JB of tile t (stage ST).  Consumes frK[JB] (scores of the NEXT half-step) and frV[JB] (numerators of
-    //      the PREVIOUS one); requests the fragments of the next half-step into the other buffers. ----
-    auto half_step = [&](const int t, auto stc, auto jbc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value, JB = decltype(jbc)::value, OB = JB ^ 1;
-        constexpr int SNX = JB == 0 ? ST : (ST + 1) % NS;                  // stage of the next half-step's tile
-        const int hstep = 2 * t + JB;
-        const int tn = JB == 0 ? t : t + 1;                                // tile of the next half-step
-        const bool has_next = tn < nt;
-        if (!active) return;
-        // V^T fragments for the NEXT half-step's output MFMAs (this key block's numerators are produced below); K fragments of the
-        // next half-step's key block for the score MFMAs in slots 4-7 of THIS half-step (their latency hides behind slots 0-3)
-        read_v(stc, jbc, AttnIC<OB>{});
-        if (has_next) read_k(AttnIC<SNX>{}, AttnIC<OB>{});
-        const bool masked_next = has_next && mask_flag(AttnIC<SNX>{}, AttnIC<OB>{}, tn);
-        float tmax = attn_max3(sc[JB][0], sc[JB][1], sc[JB][2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) tmax = attn_max3(tmax, sc[JB][r], sc[JB][r + 1]);
-        tmax = fmaxf(tmax, sc[JB][15]);
-        const bool fast = hstep >= 1 && has_next && !masked_next && !__any(tmax > ATTN_DEFER);
-        float ps0 = 0.f, ps1 = 0.f;
-        if (fast) {
-            // ---- interleaved: MFMA slot i, then exp2 / add of one score pair and its packing ----
-            auto slot = [&](auto ic) __attribute__((always_inline)) {
-                constexpr int I = decltype(ic)::value;
-                if constexpr (I < 4) {                     // O += V^T P^T of the previous half-step (key block OB): 16-key step I >> 1, d block I & 1
-                    o[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frV[JB][I], pf[OB][I >> 1].v, o[I & 1], 0, 0, 0);
-                } else {                                   // scores of the next half-step into the block the previous one has left
-                    constexpr int kk = I - 4;
-                    if constexpr (kk == 0) sc[OB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[kk], qf[kk], negm, 0, 0, 0);
-                    else sc[OB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frK[kk], qf[kk], sc[OB], 0, 0, 0);
-                }
-                constexpr int r0 = 2 * I;
-                sc[JB][r0] = __builtin_amdgcn_exp2f(sc[JB][r0]);
-                sc[JB][r0 + 1] = __builtin_amdgcn_exp2f(sc[JB][r0 + 1]);
-                ps0 += sc[JB][r0];
-                ps1 += sc[JB][r0 + 1];
-                pf[JB][r0 >> 3].u[(r0 & 7) >> 1] = pack_bf16x2(sc[JB][r0], sc[JB][r0 + 1]);
-            };
-            slot(AttnIC<0>{}); slot(AttnIC<1>{}); slot(AttnIC<2>{}); slot(AttnIC<3>{});
-            slot(AttnIC<4>{}); slot(AttnIC<5>{}); slot(AttnIC<6>{}); slot(AttnIC<7>{});
-        } else {
-            // ---- sequential: previous numerators first (O complete before a rescale), exact row maximum, then the next scores ----
-            if (hstep >= 1) pv_seq(AttnIC<OB>{}, jbc);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float delta = hstep == 0 ? (tmax < -1e9f ? 0.f : tmax) : fmaxf(tmax, 0.f);      // first half-step: m := row maximum
-            const float alpha = hstep == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-            m_run += delta;
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o[0][r] *= alpha;
-                o[1][r] *= alpha;
-                negm[r] = -m_run;
-                sc[JB][r] = __builtin_amdgcn_exp2f(sc[JB][r] - delta);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                ps0 += sc[JB][r];
-                ps1 += sc[JB][r + 1];
-                pf[JB][r >> 3].u[(r & 7) >> 1] = pack_bf16x2(sc[JB][r], sc[JB][r + 1]);
-            }
-            if (has_next) scores_seq(AttnIC<SNX>{}, AttnIC<OB>{}, masked_next, -m_run);
-        }
-        l_run += ps0 + ps1;
-    };
-
-    // ---- prologue: tiles 0..2 requested, tiles 0 and 1 complete; S of half-step 0 (raw scores), K fragments of half-step 1 ----
-    issue(0, AttnIC<0>{});
-    if (nt > 1) issue(1, AttnIC<1>{});
-    if (nt > 2) { issue(2, AttnIC<2>{}); attn_wait_vmcnt<5>(); } else { attn_wait_vmcnt<0>(); }
-    if (nt == 1 && (N & 63)) tail_fix(AttnIC<0>{}, 0);
-    if (nt == 2 && (N & 63)) tail_fix(AttnIC<1>{}, 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (nt > 3) issue(3, AttnIC<3>{});
-    if (active) {
-        read_k(AttnIC<0>{}, AttnIC<0>{});
-        scores_seq(AttnIC<0>{}, AttnIC<0>{}, mask_flag(AttnIC<0>{}, AttnIC<0>{}, 0), 0.f);
-    }
-    auto tile = [&](const int t, auto stc) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value;
-        half_step(t, stc, AttnIC<0>{});
-        half_step(t, stc, AttnIC<1>{});
-        // ---- tile t+2 complete in LDS for everyone (requested two tiles ago); the stage of tile t is free: request tile t+4 ----
-        attn_wait_vmcnt<5>();
-        if (t + 3 >= nt) attn_wait_vmcnt<0>();            // nothing younger in the queue any more
-        if (t + 2 == nt - 1 && (N & 63)) tail_fix(AttnIC<(ST + 2) % NS>{}, (t + 2) * 64);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 4 < nt) issue(t + 4, stc);
-    };
-    for (int t0 = 0; t0 < nt; t0 += NS) {
-        tile(t0, AttnIC<0>{});
-        if (t0 + 1 < nt) tile(t0 + 1, AttnIC<1>{});
-        if (t0 + 2 < nt) tile(t0 + 2, AttnIC<2>{});
-        if (t0 + 3 < nt) tile(t0 + 3, AttnIC<3>{});
-    }
-    if (active) pv_seq(AttnIC<1>{}, AttnIC<0>{});          // numerators of the last half-step (key block 1; its V^T fragments went to frV[0])
-
-    if (qrow < N) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
-        bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = 32 * db + 8 * gq + 4 * half;
-                uint2 w;
-                w.x = pack_bf16x2(o[db][4 * gq + 0] * inv, o[db][4 * gq + 1] * inv);
-                w.y = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
-                *reinterpret_cast<uint2*>(dst + d0) = w;
-            }
-    }
-}
-
-static hipError_t launch_attn_hp(const AttnParams& p_in, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * 16384 + (size_t)4 * 4 * 256;
-    auto kern = attn_hp_kernel;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    g_last_kernel = "attn_hp_kernel";
-    const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
-    AttnParams p = p_in;
-    p.xcd_map = total >= 400 ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
-    return hipGetLastError();
-}
-
 template <int NS>
 static hipError_t launch_attn_stream(const AttnParams& p_in, hipStream_t s) {
     constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256;
@@ -1090,7 +762,6 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 7: return launch_attn_cfg<2, 4, 2>(p, s);     // 64 queries x 4 key quarters (8 waves, 133 KB of LDS)
         case 8: return launch_attn_stream<3>(p, s);        // batched: 128 queries per workgroup, speculative tiles
         case 9: return launch_attn_stream<2>(p, s);
-        case 10: return launch_attn_hp(p, s);              // half-tile software pipeline inside each wave
     }
     return hipErrorInvalidValue;
 }
