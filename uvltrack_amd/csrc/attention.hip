@@ -533,10 +533,12 @@ __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p)
         bool redo = masked || t == 0;
         if (!redo) {
             // ---- speculative tile: s - m straight from the MFMA, exp2, row-sum partials ----
+            // the two key blocks' chains alternate: a lone wave with one accumulator chain in flight runs the matrix pipe at well
+            // under half rate (tools/probes/exp_mfma_probe.hip)
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int jb = 0; jb < 2; ++jb) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
                     s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? negm : s[jb], 0, 0, 0);
                 }
@@ -554,9 +556,9 @@ __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p)
         if (redo) {
             // ---- exact tile: scores with C = 0, mask term, true row max, rescale ----
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int jb = 0; jb < 2; ++jb) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
                     s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? zero16 : s[jb], 0, 0, 0);
                 }
