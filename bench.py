@@ -48,7 +48,6 @@ def parse_args(argv=None):
                     help="eager: the frame's kernels are launched each step (one stream for one sequence, two for several; fastest on ROCm 7.2, "
                          "where hipGraphLaunch costs more host time per node than a plain launch); graph: hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ln-fold", action="store_true", help="A/B aid: keep the LayerNorm kernels in frames of many sequences (uvl_debug_set ln_fold 0)")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra `batched` block (UVLTrack-L z256/x384, 8 sequences: the per-GPU load of BASELINE configs[4])")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -184,8 +183,6 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     flags = [flag_val] * B
     eng = HipEngine(spec, dev, max_batch=max(B, 1))
     eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
-    if getattr(args, "no_ln_fold", False):
-        eng.lib.uvl_debug_set(eng.handle, b"ln_fold", 0)
     inp = wg.make_inputs(spec, batch=B, seed=seed + rank, flags=flags)      # every rank advances its own sequences
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     targs = (t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))

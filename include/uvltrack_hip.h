@@ -219,8 +219,7 @@ int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int
 /* Test hooks.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
  * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs.
  * keys "pair_text" / "fuse_contrast" (default 1): 0 selects the two-stream form of a one-sequence frame / stand-alone
- * contrast kernels, so that tests and tools can compare the launch forms (same results); "ln_fold" = 0 keeps the LayerNorm
- * kernels in frames of many sequences (see uvl_linear_ln below; results differ by bf16 rounding only). */
+ * contrast kernels, so that tests and tools can compare the launch forms (same results). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
 /* Tuning hooks for tools/gemm_bench.py (not part of the product path): force a plain-GEMM tile configuration
@@ -274,33 +273,6 @@ int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_ld, const i
  * d_x [M,D] f32 -> d_y_bf16 [M,D] bf16 (may be NULL) and d_y_f32 [M,D] f32 (may be NULL, may alias d_x). */
 int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
                   void* d_y_bf16, float* d_y_f32, int M, int D, void* stream);
-
-/* ---- LayerNorm folded into the GEMMs on either side of it --------------------------------------------------------------
- * Frames of many sequences (>= 4096 token rows) run the ViT blocks without LayerNorm kernels.  For  y = Linear(norm(x))
- * (block.py:30-31 with Attention.qkv block.py:49 / Mlp.fc1 backbones/utils.py:58):
- *     norm(x) W^T + b = rstd * (x W'^T - mean * colsum(W')) + b',   W' = W * gamma (per input column),  b' = b + W beta
- * so the GEMM runs on the UN-normalised rows (rounded to bf16) and its epilogue applies mean / rstd of each row.  The GEMM that
- * produces x (x += a W^T + b: Attention.proj, Mlp.fc2) leaves that rounded copy and the row statistics as it writes x.
- * Statistics layout: d_stats [M][D/64][2] f32 = per 64-column chunk (sum, sum of squared deviations from the chunk mean); the
- * consumer combines the chunks in order (Chan et al.), so results do not depend on tile configuration or launch order.
- * uvl_fold_ln_linear: d_w [N,K] f32, d_b [N] or NULL, d_gamma / d_beta [K] -> d_w_folded bf16 [N,K], d_bias_folded [N], d_colsum [N]
- *   (column sums of the ROUNDED folded weights).
- * uvl_row_stats: d_x [M,D] f32 -> d_x_bf16 [M,D] and d_stats (D % 256 == 0, D <= 1024): what a LayerNorm launch does in such a
- *   frame where the row set changes (layer 0, first fusion layer).
- * uvl_linear_ln: y = act(norm(x) W^T + b) as bf16 [M,N] from d_x_bf16 / d_stats and the folded operands (K = D).
- * uvl_qkv_project_ln: the same with uvl_qkv_project's scatter epilogue.
- * uvl_linear_residual: d_x [M,N] f32 += d_a [M,K] d_w[N,K]^T + d_bias (+ d_rowadd0[n] for rows t < rowadd_split of each sequence
- *   of rows_per_seq rows, d_rowadd1[n] for the others: modal_embed of the next fusion layer, mae_vit.py:196; NULL = none), and
- *   d_x_bf16 / d_stats of the updated rows.  N % 128 == 0; M large enough for 64-column wave tiles (M >= 4096 at N = 768). */
-int uvl_fold_ln_linear(const float* d_w, const float* d_b, const float* d_gamma, const float* d_beta, void* d_w_folded,
-                       float* d_bias_folded, float* d_colsum, int N, int K, void* stream);
-int uvl_row_stats(const float* d_x, void* d_x_bf16, float* d_stats, int M, int D, void* stream);
-int uvl_linear_ln(const void* d_x_bf16, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum,
-                  float eps, void* d_y, int M, int N, int K, int act, void* stream);
-int uvl_qkv_project_ln(const void* d_x_bf16, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum,
-                       float eps, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream);
-int uvl_linear_residual(const void* d_a, const void* d_w, const float* d_bias, float* d_x, void* d_x_bf16, float* d_stats,
-                        const float* d_rowadd0, const float* d_rowadd1, int rows_per_seq, int rowadd_split, int M, int N, int K, void* stream);
 
 /* f32 -> bf16 (round to nearest even) helper for tests. */
 int uvl_f32_to_bf16(const float* d_in, void* d_out, size_t n, void* stream);

@@ -227,139 +227,3 @@ def test_anno2mask_matches_oracle(lib):
         _chk(lib.uvl_anno2mask(_p(d_boxes), 64, size, _p(mask), _stream()), lib)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), anno2mask(boxes, size))
-
-
-# ---- LayerNorm folded into the neighbouring GEMMs (frames of many sequences; include/uvltrack_hip.h "LayerNorm folded ...") ----
-def _ln_fold_operands(lib, N, K, seed):
-    w = _rand((N, K), seed, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]
-    b = _rand((N,), seed + 1, 0.5)
-    gamma = 1.0 + _rand((K,), seed + 2, 0.2)
-    beta = _rand((K,), seed + 3, 0.3)
-    wf = torch.empty(N, K, dtype=torch.bfloat16, device="cuda")
-    bf = torch.empty(N, device="cuda")
-    cs = torch.empty(N, device="cuda")
-    _chk(lib.uvl_fold_ln_linear(_p(w), _p(b), _p(gamma), _p(beta), _p(wf), _p(bf), _p(cs), N, K, _stream()), lib)
-    torch.cuda.synchronize()
-    # the fold itself, against its definition
-    assert torch.equal(wf, (w * gamma[None, :]).bfloat16())
-    assert float((bf - (b + w @ beta)).abs().max()) < 1e-4
-    assert float((cs - wf.float().sum(1)).abs().max()) < 1e-3
-    return w, b, gamma, beta, wf, bf, cs
-
-
-def _residual_rows(M, D, seed):
-    """f32 residual rows the way a ViT stream looks: a per-row offset (non-zero mean), a few large channels."""
-    x = _rand((M, D), seed) * (0.5 + torch.rand(M, 1, generator=torch.Generator().manual_seed(seed)).cuda() * 2.0)
-    x = x + _rand((M, 1), seed + 1, 0.7)
-    x[:, 5] *= 20.0
-    x[:, D - 3] += 9.0
-    return x.contiguous()
-
-
-@pytest.mark.parametrize("M,D", [(4424, 768), (873, 1024), (40, 256), (1, 512)])
-def test_row_stats(lib, M, D):
-    x = _residual_rows(M, D, 11)
-    xb = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
-    st = torch.full((M, D // 64, 2), float("nan"), device="cuda")
-    _chk(lib.uvl_row_stats(_p(x), _p(xb), _p(st), M, D, _stream()), lib)
-    torch.cuda.synchronize()
-    assert torch.equal(xb, x.bfloat16())
-    ch = x.view(M, D // 64, 64).double()
-    assert float((st[..., 0].double() - ch.sum(-1)).abs().max()) < 1e-3
-    m2 = ((ch - ch.mean(-1, keepdim=True)) ** 2).sum(-1)
-    assert bool(((st[..., 1].double() - m2).abs() <= 1e-4 * m2 + 1e-4).all())
-
-
-@pytest.mark.parametrize("M,N,K,act", [(4424, 3072, 768, 1), (4424, 768, 768, 0), (553, 3072, 768, 1), (5448, 4096, 1024, 1), (40, 256, 256, 0), (8192, 2304, 768, 0)])
-def test_linear_ln_matches_layernorm_then_linear(lib, M, N, K, act):
-    w, b, gamma, beta, wf, bf, cs = _ln_fold_operands(lib, N, K, 21)
-    x = _residual_rows(M, K, 31)
-    xb = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
-    st = torch.empty(M, K // 64, 2, device="cuda")
-    _chk(lib.uvl_row_stats(_p(x), _p(xb), _p(st), M, K, _stream()), lib)
-    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_linear_ln(_p(xb), _p(st), _p(wf), _p(bf), _p(cs), 1e-6, _p(y), M, N, K, act, _stream()), lib)
-    torch.cuda.synchronize()
-    ref = torch.nn.functional.layer_norm(x, (K,), gamma, beta, 1e-6) @ w.t() + b
-    if act:
-        ref = torch.nn.functional.gelu(ref)
-    # the unfused path for comparison: LayerNorm kernel -> bf16 -> plain GEMM on bf16(w)
-    xn = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_layernorm(_p(x), _p(gamma), _p(beta), 1e-6, _p(xn), None, M, K, _stream()), lib)
-    y0 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_linear(_p(xn), _p(w.bfloat16()), _p(b), _p(y0), M, N, K, act, 0, 0, _stream()), lib)
-    torch.cuda.synchronize()
-    err = (y.float() - ref).abs()
-    err0 = (y0.float() - ref).abs()
-    tol = 1e-2 * ref.abs() + 3e-2
-    assert bool((err <= tol).all()), "max err %g (unfused %g)" % (float(err.max()), float(err0.max()))
-    # folding must not cost accuracy: rms error within 1.5x of the LayerNorm-kernel path
-    assert float(err.pow(2).mean().sqrt()) <= 1.5 * float(err0.pow(2).mean().sqrt()) + 1e-4, (float(err.pow(2).mean().sqrt()), float(err0.pow(2).mean().sqrt()))
-
-
-@pytest.mark.parametrize("B,N,D", [(8, 553, 768), (8, 873, 1024), (2, 321, 768)])
-def test_qkv_project_ln(lib, B, N, D):
-    H, Npad, M = D // 64, (N + 63) // 64 * 64, B * N
-    w, b, gamma, beta, wf, bf, cs = _ln_fold_operands(lib, 3 * D, D, 41)
-    x = _residual_rows(M, D, 51)
-    xb = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
-    st = torch.empty(M, D // 64, 2, device="cuda")
-    _chk(lib.uvl_row_stats(_p(x), _p(xb), _p(st), M, D, _stream()), lib)
-    q = torch.zeros(B, H, Npad, 64, dtype=torch.bfloat16, device="cuda")
-    k = torch.zeros_like(q)
-    vt = torch.zeros(B, H, 64, Npad, dtype=torch.bfloat16, device="cuda")
-    qs = 0.18033688011112042
-    _chk(lib.uvl_qkv_project_ln(_p(xb), _p(st), _p(wf), _p(bf), _p(cs), 1e-6, _p(q), _p(k), _p(vt), B, N, Npad, D, qs, _stream()), lib)
-    torch.cuda.synchronize()
-    ref = (torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-6) @ w.t() + b).view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
-    for got, want in ((q[:, :, :N].float(), ref[0] * qs), (k[:, :, :N].float(), ref[1]), (vt[:, :, :, :N].float().transpose(2, 3), ref[2])):
-        err = (got - want).abs()
-        assert bool((err <= 1e-2 * want.abs() + 3e-2).all()), float(err.max())
-
-
-@pytest.mark.parametrize("M,N,K,rows,split", [(4424, 768, 768, 553, 513), (4424, 768, 3072, 553, 0), (6984, 1024, 1024, 873, 833), (7304, 1024, 4096, 913, 873)])
-def test_linear_residual_leaves_rows_and_stats(lib, M, N, K, rows, split):
-    a = _rand((M, K), 61).bfloat16()
-    w = (_rand((N, K), 62, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
-    b = _rand((N,), 63, 0.5)
-    x0 = _residual_rows(M, N, 64)
-    r0, r1 = _rand((N,), 65, 0.3), _rand((N,), 66, 0.3)
-    x = x0.clone()
-    xb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-    st = torch.full((M, N // 64, 2), float("nan"), device="cuda")
-    use_add = split > 0
-    _chk(lib.uvl_linear_residual(_p(a), _p(w), _p(b), _p(x), _p(xb), _p(st), _p(r0) if use_add else None, _p(r1) if use_add else None,
-                                 rows, split, M, N, K, _stream()), lib)
-    torch.cuda.synchronize()
-    ref = x0 + a.float() @ w.float().t() + b
-    if use_add:
-        t = torch.arange(M, device="cuda") % rows
-        ref = ref + torch.where((t < split)[:, None], r0[None, :], r1[None, :])
-    err = (x - ref).abs()
-    assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), float(err.max())
-    # the rounded copy and the statistics describe exactly the rows that were written
-    assert torch.equal(xb, x.bfloat16())
-    ch = x.view(M, N // 64, 64).double()
-    assert float((st[..., 0].double() - ch.sum(-1)).abs().max()) < 2e-3
-    m2 = ((ch - ch.mean(-1, keepdim=True)) ** 2).sum(-1)
-    assert bool(((st[..., 1].double() - m2).abs() <= 1e-4 * m2 + 1e-3).all())
-    # ... and feed the consumer: proj -> (norm2 folded) fc1 chain against torch
-    Nf = 4 * N if N == 768 else 2048
-    w2, b2, gamma, beta, wf, bf, cs = _ln_fold_operands(lib, Nf, N, 71)
-    y = torch.empty(M, Nf, dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_linear_ln(_p(xb), _p(st), _p(wf), _p(bf), _p(cs), 1e-6, _p(y), M, Nf, N, 1, _stream()), lib)
-    torch.cuda.synchronize()
-    ref2 = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (N,), gamma, beta, 1e-6) @ w2.t() + b2)
-    err2 = (y.float() - ref2).abs()
-    assert bool((err2 <= 1e-2 * ref2.abs() + 3e-2).all()), float(err2.max())
-
-
-def test_linear_residual_rejects_small_m(lib):
-    M, N, K = 553, 768, 768
-    a = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
-    w = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda")
-    x = torch.zeros(M, N, device="cuda")
-    xb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-    st = torch.zeros(M, N // 64, 2, device="cuda")
-    rc = lib.uvl_linear_residual(_p(a), _p(w), None, _p(x), _p(xb), _p(st), None, None, M, 0, M, N, K, _stream())
-    assert rc < 0 and b"64-column" in lib.uvl_last_error()

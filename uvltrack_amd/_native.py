@@ -20,7 +20,6 @@ EXPORTS = [
     "uvl_workspace_bytes", "uvl_forward_test", "uvl_forward_prompt", "uvl_forward", "uvl_anno2mask", "uvl_decode", "uvl_crop_geometry_of", "uvl_sample_target", "uvl_sample_target_window", "uvl_sample_target_staged", "uvl_grounding_resize", "uvl_normalize_u8", "uvl_graph_capture", "uvl_graph_launch", "uvl_graph_release",
     "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_debug_set", "uvl_tune_set", "uvl_linear_splitk",
     "uvl_linear", "uvl_attention", "uvl_qkv_project", "uvl_layernorm", "uvl_f32_to_bf16", "uvl_fold_conv_bn", "uvl_conv_tower_layer",
-    "uvl_fold_ln_linear", "uvl_row_stats", "uvl_linear_ln", "uvl_qkv_project_ln", "uvl_linear_residual",
 ]
 
 
@@ -109,11 +108,6 @@ def load():
     lib.uvl_anno2mask.argtypes = [vp, i32, i32, vp, vp]
     lib.uvl_fold_conv_bn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.uvl_conv_tower_layer.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, vp, vp, vp, vp, vp]
-    lib.uvl_fold_ln_linear.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
-    lib.uvl_row_stats.argtypes = [vp, vp, vp, i32, i32, vp]
-    lib.uvl_linear_ln.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, vp]
-    lib.uvl_qkv_project_ln.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
-    lib.uvl_linear_residual.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.uvl_f32_to_bf16.argtypes = [vp, vp, C.c_size_t, vp]
     _lib = lib
     return lib

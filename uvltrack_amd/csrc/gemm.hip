@@ -40,19 +40,9 @@ __device__ __forceinline__ void gemm_bias_preload(const GemmParams& p, int colw,
         for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(bp + j * 32 + 8 * q + 4 * (lane >> 5));
 }
 
-// LayerNorm folded into this GEMM (GemmParams.ln_stats): per-lane mean / rstd of the lane's TM rows and the column sums of the
-// folded weights; the epilogue turns the product of the UN-normalised rows into the product of the normalised ones.
-template <int TM, int TN>
-struct LnFold {
-    bool on;
-    const char* sst;          // LDS image of the tile rows' partials, [BM][K/64] float2
-    float mu[TM], rs[TM];
-    f32x4 cs[TN][4];
-};
-
 template <int TM, int TN, int WM, int WN, int EPI, int NW>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
-                                                  int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4], LnFold<TM, TN>& lf) {
+                                                  int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4]) {
     const bool has_bias = p.bias && sk == 0;
     constexpr int ES = (EPI == EPI_F32) ? 4 : 2;               // output element size
     constexpr int RS = WN * ES + 16;                            // padded LDS row stride
@@ -61,33 +51,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
     const int colw = n0 + wn * WN;                              // first column of this wave's sub-tile
     const bool vpart = EPI == EPI_QKV && colw >= 2 * p.D;       // wave-uniform: D % 64 == 0 and WN divides 64
     const float qs = (EPI == EPI_QKV && colw < p.D) ? p.q_scale : 1.0f;   // q columns carry the attention's log2(e)/8 (wave-uniform)
-    __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring (and every DMA has landed)
-    if constexpr (EPI != EPI_F32) {
-        if (lf.on) {
-            // mean / rstd of the lane's rows from the producer's per-64-column partials (in LDS since the start of the kernel),
-            // chunks combined in order (Chan et al.)
-            const int np = p.K >> 6;
-            const float inv_k = 1.0f / (float)p.K;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int rl = wm * WM + i * 32 + (lane & 31);
-                const float4* sp = reinterpret_cast<const float4*>(lf.sst + (size_t)rl * (np * 8));
-                const int sw = np == 16 ? (rl & 7) : 0;          // chunk h of this row sits at position h ^ sw (see the DMA above)
-                // two passes over the LDS image (re-read, not held: the epilogue is where this kernel's register peak is)
-                float sum = 0.f;
-                for (int h = 0; 2 * h < np; ++h) { const float4 a = sp[h ^ sw]; sum += a.x + a.z; }
-                const float mu = sum * inv_k;
-                float m2 = 0.f;
-                for (int h = 0; 2 * h < np; ++h) {
-                    const float4 a = sp[h ^ sw];
-                    const float d0 = a.x * (1.0f / 64.0f) - mu, d1 = a.z * (1.0f / 64.0f) - mu;
-                    m2 += (a.y + 64.0f * d0 * d0) + (a.w + 64.0f * d1 * d1);
-                }
-                lf.mu[i] = mu;
-                lf.rs[i] = 1.0f / sqrtf(m2 * inv_k + p.ln_eps);
-            }
-        }
-    }
+    __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
     char* cw = smem + wave * (32 * RS);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -102,11 +66,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                         const int col = colw + j * 32 + 8 * q + 4 * (lane >> 5);
                         const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float a = acc[i][j][4 * q + e];
-                            const float y = lf.on ? (a - lf.mu[i] * lf.cs[j][q][e]) * lf.rs[i] + bv[j][q][e] : a + (has_bias ? bv[j][q][e] : 0.f);
-                            p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(y);
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][4 * q + e] + (has_bias ? bv[j][q][e] : 0.f));
                     }
             }
             continue;
@@ -117,8 +78,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
             for (int q = 0; q < 4; ++q) {
                 const int cl = j * 32 + 8 * q + 4 * (lane >> 5);
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (EPI != EPI_F32 && lf.on) v = (v - lf.mu[i] * lf.cs[j][q]) * lf.rs[i] + bv[j][q];
-                else if (has_bias) v += bv[j][q];
+                if (has_bias) v += bv[j][q];
                 if (EPI == EPI_QKV) v *= qs;
                 if (EPI == EPI_F32) {
                     *reinterpret_cast<f32x4*>(cw + (lane & 31) * RS + cl * 4) = v;
@@ -135,62 +95,32 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 }
             }
         if constexpr (EPI == EPI_F32) {
-            // the table / residual operands of four row groups are requested together (one wait), then added in the same order; four at a
-            // time, not all eight: the operand registers decide whether two workgroups of the 128x128 tile fit on a CU
-            constexpr int NIT = 32 / RPI, NCH = NIT < 4 ? NIT : 4;
+            // the table / residual operands of all row groups are requested together (one wait), then added in the same order
+            constexpr int NIT = 32 / RPI;
+            f32x4 v[NIT], tv[NIT], ov[NIT];
+            float* dst[NIT];
+            bool inb[NIT];
             const int c16 = lane % LPR, col = colw + c16 * (16 / ES);
 #pragma unroll
-            for (int i0 = 0; i0 < NIT; i0 += NCH) {
-                f32x4 v[NCH], tv[NCH], ov[NCH], ra[NCH];
-                float* dst[NCH];
-                bool inb[NCH];
+            for (int it = 0; it < NIT; ++it) {
+                const int r = it * RPI + lane / LPR;
+                const int row = m0 + wm * WM + i * 32 + r;
+                inb[it] = row < p.M;
+                const int rc = inb[it] ? row : p.M - 1;
+                const int b = rc / p.rpb, rem = rc - b * p.rpb;
+                v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
+                dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
+                if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
+            }
+            if (p.accumulate) {
 #pragma unroll
-                for (int it = 0; it < NCH; ++it) {
-                    const int r = (i0 + it) * RPI + lane / LPR;
-                    const int row = m0 + wm * WM + i * 32 + r;
-                    inb[it] = row < p.M;
-                    const int rc = inb[it] ? row : p.M - 1;
-                    const int b = rc / p.rpb, rem = rc - b * p.rpb;
-                    v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
-                    dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
-                    if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
-                    if (p.rowadd0) ra[it] = *reinterpret_cast<const f32x4*>((rem < p.rowadd_split ? p.rowadd0 : p.rowadd1) + col);
-                }
-                if (p.accumulate) {
+                for (int it = 0; it < NIT; ++it) ov[it] = *reinterpret_cast<const f32x4*>(dst[it]);
+            }
 #pragma unroll
-                    for (int it = 0; it < NCH; ++it) ov[it] = *reinterpret_cast<const f32x4*>(dst[it]);
-                }
-#pragma unroll
-                for (int it = 0; it < NCH; ++it) {
-                    if (p.addtab) v[it] += tv[it];
-                    if (p.accumulate) v[it] += ov[it];
-                    if (p.rowadd0) v[it] += ra[it];
-                    if (inb[it]) *reinterpret_cast<f32x4*>(dst[it]) = v[it];
-                }
-                if constexpr (WN == 64) {
-                    // producer of a LayerNorm-folded GEMM: the 16 lanes of a row hold this wave's 64 columns of it -- rounded copy of
-                    // the updated row + (sum, M2 about the chunk mean) of the f32 values, one partial per 64-column chunk (fixed
-                    // layout, so the consumer's combination order does not depend on the tile configuration)
-                    if (p.xb) {
-#pragma unroll
-                        for (int it = 0; it < NCH; ++it) {
-                            const int row = m0 + wm * WM + i * 32 + (i0 + it) * RPI + lane / LPR;
-                            float cs = v[it][0] + v[it][1] + v[it][2] + v[it][3];
-#pragma unroll
-                            for (int o = 1; o < 16; o <<= 1) cs += __shfl_xor(cs, o);
-                            const float cm = cs * (1.0f / 64.0f);
-                            const f32x4 d = v[it] - cm;
-                            float m2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-#pragma unroll
-                            for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
-                            if (inb[it]) {
-                                if (c16 == 0) p.stats_out[(size_t)row * (p.N >> 6) + (colw >> 6)] = make_float2(cs, m2);
-                                const uint2 o2 = {pack_bf16x2(v[it][0], v[it][1]), pack_bf16x2(v[it][2], v[it][3])};
-                                *reinterpret_cast<uint2*>(p.xb + (size_t)row * p.N + col) = o2;
-                            }
-                        }
-                    }
-                }
+            for (int it = 0; it < NIT; ++it) {
+                if (p.addtab) v[it] += tv[it];
+                if (p.accumulate) v[it] += ov[it];
+                if (inb[it]) *reinterpret_cast<f32x4*>(dst[it]) = v[it];
             }
             continue;
         }
@@ -230,7 +160,7 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 
 // NTW: the weight tiles are requested non-temporal (aux = 2).  For the text-branch riders of a one-sequence frame (M = 40 rows: every
 // weight byte is read once, by one CU) -- see the note at gemm_glds_pair_kernel.
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, bool LNF = false>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk, const int g, char* smem) {
     constexpr int BK = 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -358,43 +288,11 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // LayerNorm folded into this GEMM.  The epilogue needs mean / rstd of the tile's rows (from the producer's per-64-column partials,
-    // 8 bytes x K/64 per row) and the column sums of the folded weights.  Neither may be a load the tile waits for: with two
-    // workgroups per CU streaming tiles through the same memory pipeline, a dependent load costs its QUEUED latency (measured: each of
-    // the two round trips added 15-20 us to a 60-130 us launch).  So the partials of the BM rows -- one contiguous block -- go to LDS
-    // by DMA ahead of the first tile (4 instructions per wave, no registers) and are read in the epilogue, and the column sums are
-    // requested here like the bias and used only in the epilogue.
-    LnFold<TM, TN> lf;
-    lf.on = LNF;                                              // compile-time: the column sums cost 32 registers
-    lf.sst = smem + NS * STAGE;
-    if constexpr (LNF) {
-        const float* cp = p.ln_cs + n0 + wn * WN;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lf.cs[j][q] = *reinterpret_cast<const f32x4*>(cp + j * 32 + 8 * q + 4 * (lane >> 5));
-        const int rowb = (p.K >> 6) * 8;                          // bytes of partials per row
-        const int pieces = BM * rowb / 1024;                      // 1-KB DMA pieces (BM * K/64 is a multiple of 128)
-        for (int k = wave; k < pieces; k += NW) {
-            const int o = k * 1024 + lane * 16;
-            const int r = o / rowb;
-            int row = m0 + r;
-            row = row < p.M ? row : p.M - 1;
-            // 128-byte rows (K = 1024): the epilogue's lanes read one 16-byte chunk of 32 consecutive rows -- all in the same four banks
-            // unless the chunk order rotates with the row (measured: 17-30 us of a 60-130 us launch); shorter rows rotate by themselves
-            const int within = o - r * rowb;
-            const int src = rowb == 128 ? (within ^ ((r & 7) << 4)) : within;
-            const char* gp = reinterpret_cast<const char*>(p.ln_stats) + (size_t)row * rowb + src;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(smem + NS * STAGE + k * 1024), 16, 0, 0);
-        }
-    }
-
     const int nk = kspan / BK;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) issue(t);
-    auto kstep = [&](int kt) __attribute__((always_inline)) {
+    for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight
         const int ahead = nk - 1 - kt;
         if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
@@ -420,17 +318,15 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue_lds
         }
-    };
-    kstep(0);
-    for (int kt = 1; kt < nk; ++kt) kstep(kt);
+    }
     static_assert(32 * (WN * 4 + 16) * NW <= NS * STAGE, "epilogue staging fits in the ring");
-    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v, lf);
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, bool LNF = false>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, LNF>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
+    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
 }
 
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
@@ -454,7 +350,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false, bool LNF = false>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false>
 static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
@@ -465,19 +361,16 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     p.group_m = MT >= 16 ? 8 : MT;
     if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
     const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
-    // + the LDS image of the rows' LayerNorm partials when the fold is on (BM rows x K/64 x 8 bytes, K <= 1024)
-    const size_t lds_max = (size_t)NS * (BM + BN) * 128 + (size_t)BM * 128;
-    const size_t lds = (size_t)NS * (BM + BN) * 128 + (LNF ? (size_t)BM * (p.K >> 6) * 8 : 0);
-    if (LNF != (p.ln_stats != nullptr)) return hipErrorInvalidValue;
-    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, LNF>;
+    const size_t lds = (size_t)NS * (BM + BN) * 128;
+    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_max <= 160 * 1024 ? lds_max : (size_t)NS * (BM + BN) * 128));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : (LNF ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,ln>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>"), BM, BN, WGM, WGN, EPI, NS, (int)CONV);
+    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
@@ -495,17 +388,6 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
             case 9: return launch_glds<128, 64, 2, 2, EPI, 2, false, true>(p, s);
             case 10: return launch_glds<64, 128, 2, 2, EPI, 2, false, true>(p, s);
             default: break;
-        }
-    }
-    if constexpr (EPI != EPI_F32) {
-        if (p.ln_stats) {                  // LayerNorm folded in: the instantiations frames of many sequences (and the tests) resolve to
-            switch (cfg) {
-                case 4: return launch_glds<64, 64, 2, 2, EPI, 3, false, false, true>(p, s);
-                case 6: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, true>(p, s);
-                case 9: return launch_glds<128, 64, 2, 2, EPI, 2, false, false, true>(p, s);
-                case 10: return launch_glds<64, 128, 2, 2, EPI, 2, false, false, true>(p, s);
-                default: return hipErrorInvalidValue;
-            }
         }
     }
     switch (cfg) {
@@ -547,35 +429,14 @@ static int pick_plain_cfg(const GemmParams& p) {
     return n128 ? 6 : 9;                            // 128x128, 2 stages
 }
 
-static int resolve_plain_cfg(const GemmParams& p) {
-    int cfg = pick_plain_cfg(p);
-    if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15) && p.N % 128 != 0) cfg = 0;
-    if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
-    return cfg;
-}
-// configurations whose wave tiles are 64 columns wide (the producer epilogue's statistics chunk)
-static bool cfg_wn64(int cfg) { return cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 14 || cfg == 15; }
-
-bool gemm_producer_ok(const GemmParams& p) {
-    return p.conv_F == 0 && p.groups <= 1 && p.N % 64 == 0 && p.K % 64 == 0 && p.splitk == 1 && p.epi == EPI_F32 && !p.w_stream && cfg_wn64(resolve_plain_cfg(p));
-}
-
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
     if (p.N % 64 != 0) {                        // N % 32 == 0 (launch_gemm checked): one 32-column tile shape
-        if (p.xb || p.ln_stats) return hipErrorInvalidValue;
         return launch_glds<128, 32, 4, 1, EPI, 3>(p, s);
     }
-    const int cfg = resolve_plain_cfg(p);
-    if (p.xb && !gemm_producer_ok(p)) return hipErrorInvalidValue;
-    if (p.ln_stats) {                  // a configuration that is instantiated with the fold (see launch_plain_cfg)
-        int c = cfg;
-        if (c == 0 || c == 5 || c == 7) c = 4;
-        else if (c == 2 || c == 11 || c == 13 || c == 14 || c == 15) c = 6;
-        else if (c == 1 || c == 8 || c == 12) c = 9;
-        else if (c == 3) c = 10;
-        return launch_plain_cfg<EPI>(c, p, s);
-    }
+    int cfg = pick_plain_cfg(p);
+    if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15) && p.N % 128 != 0) cfg = 0;
+    if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
 
@@ -600,7 +461,7 @@ static hipError_t launch_pair_epi(const GemmParams& a_in, const GemmParams& b_in
 
 hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
     auto plain = [](const GemmParams& p) {
-        return p.conv_F == 0 && (p.groups <= 1) && p.N % 64 == 0 && p.K % 64 == 0 && p.M > 0 && p.splitk >= 1 && !p.xb && !p.ln_stats &&
+        return p.conv_F == 0 && (p.groups <= 1) && p.N % 64 == 0 && p.K % 64 == 0 && p.M > 0 && p.splitk >= 1 &&
                (p.splitk == 1 || (p.epi == EPI_F32 && !p.accumulate && (p.K / 64) % p.splitk == 0));
     };
     const bool pairable = plain(a) && plain(b) && a.epi == b.epi && pick_plain_cfg(a) == 4 && pick_plain_cfg(b) == 4 &&
@@ -622,7 +483,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.splitk > 1 && (p.epi != EPI_F32 || p.accumulate || p.N % 64 != 0 || (p.K / 64) % p.splitk != 0))
         return hipErrorInvalidValue;      // partial slabs: f32 store epilogue only
     if (p.conv_F > 0) {                   // implicit GEMM over NHWC tokens, towers as groups (optionally split-K into f32 slabs)
-        if (p.cin_g % 64 != 0 || p.xb || p.ln_stats) return hipErrorInvalidValue;
+        if (p.cin_g % 64 != 0) return hipErrorInvalidValue;
         if (p.N % 64 == 0) {
             if (p.epi == EPI_BF16 && p.N % 128 == 0 && (long)(p.M / 128) * (p.N / 128) * (p.groups > 0 ? p.groups : 1) >= 256)
                 return launch_glds<128, 128, 2, 2, EPI_BF16, 2, true>(p, s);   // batched frames: at least one 128x128 tile per CU
@@ -634,8 +495,6 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
         return launch_glds<128, 32, 4, 1, EPI_BF16, 3, true>(p, s);            // last tower layer: 32 channels
     }
     if (p.groups > 1) return hipErrorInvalidValue;
-    if (p.ln_stats && (p.epi == EPI_F32 || p.splitk != 1 || !p.ln_cs || !p.bias || p.K > 1024)) return hipErrorInvalidValue;
-    if (p.xb && (!p.stats_out || p.epi != EPI_F32 || p.splitk != 1)) return hipErrorInvalidValue;
     switch (p.epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(p, s);
         case EPI_F32: return launch_epi<EPI_F32>(p, s);

@@ -33,21 +33,7 @@ struct GemmParams {
                                                  // Infinity Cache (text branch): non-temporal weight-tile loads where instantiated
     int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
-    // ---- LayerNorm folded into the GEMMs on either side of it (frames of many sequences, see uvl_api.hip::run_forward) ----
-    // Consumer (norm -> Linear; EPI_BF16 / EPI_QKV, no split-K): A holds the UN-normalised rows in bf16, W = bf16(gamma * W),
-    // bias = b + W beta, and the epilogue applies   y = rstd_m * (acc - mean_m * ln_cs[n]) + bias[n]
-    // with mean / rstd of row m combined from the per-64-column partials the producer left in ln_stats.
-    const float2* ln_stats = nullptr;            // [M][K/64] (sum, M2 about the chunk mean) of the f32 row the bf16 A row was rounded from
-    const float* ln_cs = nullptr;                // [N] column sums of the folded bf16 weights
-    float ln_eps = 0.f;
-    // Producer (x += A W^T + b; EPI_F32, accumulate, no split-K, 64-column wave tiles): also leaves the bf16 copy of the updated
-    // rows and their partial statistics for the consumer, and can add the next layer's per-row-type vector (modal embedding)
-    bf16_t* xb = nullptr;                        // [M, N] compact
-    float2* stats_out = nullptr;                 // [M][N/64]
-    const float *rowadd0 = nullptr, *rowadd1 = nullptr; int rowadd_split = 0;   // + rowadd0[n] for t < split, rowadd1[n] otherwise
 };
-// true if launch_gemm would run p (a producer, see above) on a configuration whose wave tiles are 64 columns wide
-bool gemm_producer_ok(const GemmParams& p);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // two independent plain GEMMs; one launch when both resolve to the batch-1 instantiation, else two launches (same results)
 hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_t s);
@@ -80,8 +66,6 @@ struct LnParams {
     float* y_copy = nullptr;                     // optional second f32 output, compact [M,D] (text snapshot)
     float* x_snap = nullptr;                     // optional copy of the row AFTER the slab fold and BEFORE pre_add (= the previous
                                                  // layer's output), same row map as x
-    float2* stats_out = nullptr;                 // not null: NO normalisation -- y_bf16 receives the rounded row itself and stats_out
-                                                 // [M][D/64] its per-64-column (sum, M2); the consuming GEMM normalises (GemmParams.ln_stats)
     // Optional second job of the launch: the contrastive logits of the PREVIOUS layer (extractor.py:85-93) from the snapshot the
     // previous LayerNorm left in ct_x -- the wave that normalises search row s of sample b also writes logits[b, slot, s].
     // No extra launch, no cross-stream event ('cls' text token only; 'mean' keeps the stand-alone contrast kernel).
@@ -127,8 +111,6 @@ struct ContrastParams {
     float* logits = nullptr; int slot = 0, n_cont = 0;
     const float* part = nullptr; int nsplit = 0, part_rows = 0; size_t part_stride = 0;   // pending split-K slabs
     const float* txt_snap = nullptr;             // [B,T,D] text rows of this layer (pre-fusion layers) or null = read x
-    const float *sub0 = nullptr, *sub1 = nullptr; // not null: x already carries the NEXT layer's modal embedding (added by the fc2 epilogue
-                                                 // of an ln_fold frame); rows < nv have sub0 [D] taken off again as they are read, text rows sub1
 };
 hipError_t launch_contrast(const ContrastParams& p, hipStream_t s);
 
@@ -210,10 +192,6 @@ hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_
 // conv [Co,Ci,3,3] f32 + BN(eval) -> bf16 [Co][tap][Ci] and folded bias f32 [Co]
 hipError_t launch_fold_conv_bn(const float* w, const float* b, const float* bn_w, const float* bn_b, const float* bn_mean,
                                const float* bn_var, bf16_t* w_out, float* b_out, int Co, int Ci, hipStream_t s);
-// LayerNorm folded into the Linear that follows it (block.py:30-31 -> attn.qkv / mlp.fc1): w_out = bf16(gamma[k] * w[n,k]),
-// b_out[n] = b[n] + sum_k w[n,k] beta[k], cs_out[n] = sum_k float(w_out[n,k])      (GemmParams.ln_stats consumer)
-hipError_t launch_fold_ln_linear(const float* w, const float* b, const float* gamma, const float* beta, bf16_t* w_out, float* b_out,
-                                 float* cs_out, int N, int K, hipStream_t s);
 hipError_t launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s);
 
 }  // namespace uvl

@@ -103,30 +103,6 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
         if ((padd || nsp > 0 || xin != xr) && ok[i]) *reinterpret_cast<float4*>(xr + c) = v[i];
         sum += v[i].x + v[i].y + v[i].z + v[i].w;
     }
-    if (p.stats_out) {
-        // no normalisation here: the GEMM that reads y_bf16 normalises in its epilogue (GemmParams.ln_stats).  Lanes 16g..16g+15 hold
-        // the 64 columns [256 i + 64 g, +64): their (sum, M2 about their own mean) is one partial, combined by the consumer.
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (lane + 64 * i) * 4;
-            float cs = v[i].x + v[i].y + v[i].z + v[i].w;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) cs += __shfl_xor(cs, o);
-            const float cm = cs * (1.0f / 64.0f);
-            const float dx = v[i].x - cm, dy = v[i].y - cm, dz = v[i].z - cm, dw = v[i].w - cm;
-            float m2 = dx * dx + dy * dy + dz * dz + dw * dw;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
-            if (ok[i]) {
-                if ((lane & 15) == 0) p.stats_out[(size_t)m * (p.D >> 6) + (c >> 6)] = make_float2(cs, m2);
-                uint2 w;
-                w.x = pack_bf16x2(v[i].x, v[i].y);
-                w.y = pack_bf16x2(v[i].z, v[i].w);
-                *reinterpret_cast<uint2*>(p.y_bf16 + (size_t)m * p.D + c) = w;
-            }
-        }
-        return;
-    }
     const float mean = wave_sum(sum) / (float)p.D;
     float sq = 0.f;
 #pragma unroll
@@ -227,7 +203,6 @@ static void launch_ln_variant(const LnParams& p, int grid, int wpb, hipStream_t 
 
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
     if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0 || p.nsplit > LN_MAX_SLABS) return hipErrorInvalidValue;
-    if (p.stats_out && (p.D % 256 != 0 || !p.y_bf16 || p.ct_x)) return hipErrorInvalidValue;   // whole 64-column chunks per 16 lanes
     const int wpb = ln_waves_per_block(p.M);
     const int grid = (p.M + wpb - 1) / wpb;
     if (p.D == 768) launch_ln_variant<3, true>(p, grid, wpb, s);
@@ -536,17 +511,9 @@ __global__ __launch_bounds__(256) void contrast_kernel(const ContrastParams p) {
     const int fl = (int)p.flag[b];
     float* txt = sh;
     float* vis = sh + D;
-    auto ld = [&](int row, int c) __attribute__((always_inline)) {
-        float4 a = rv.load(row, c);
-        if (p.sub0) {
-            const float4 m = *reinterpret_cast<const float4*>((row < p.nv ? p.sub0 : p.sub1) + c);
-            a.x -= m.x; a.y -= m.y; a.z -= m.z; a.w -= m.w;
-        }
-        return a;
-    };
     // stage the two tokens (generate_txt_token, extractor.py:79-83: 'cls' = first text row, 'mean' = masked mean)
     for (int c = threadIdx.x * 4; c < D; c += 1024) {
-        *reinterpret_cast<float4*>(vis + c) = ld(0, c);
+        *reinterpret_cast<float4*>(vis + c) = rv.load(0, c);
         if (!p.skip_text) {
             float4 tk;
             if (p.txt_snap) {                  // pre-fusion layer: text rows of THIS layer, snapshotted by the BERT LayerNorm
@@ -566,14 +533,14 @@ __global__ __launch_bounds__(256) void contrast_kernel(const ContrastParams p) {
                     tk.x /= cnt; tk.y /= cnt; tk.z /= cnt; tk.w /= cnt;
                 }
             } else if (!p.mean_mode) {
-                tk = ld(p.nv, c);
+                tk = rv.load(p.nv, c);
             } else {
                 tk = make_float4(0.f, 0.f, 0.f, 0.f);
                 float cnt = 0.f;
                 const uint8_t* tm = p.text_mask + (size_t)b * p.T;
                 for (int t = 0; t < p.T; ++t)
                     if (tm[t]) {
-                        const float4 a = ld(p.nv + t, c);
+                        const float4 a = rv.load(p.nv + t, c);
                         tk.x += a.x; tk.y += a.y; tk.z += a.z; tk.w += a.w;
                         cnt += 1.f;
                     }
@@ -587,7 +554,7 @@ __global__ __launch_bounds__(256) void contrast_kernel(const ContrastParams p) {
     if (s >= p.nx) return;
     float xx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
-        const float4 a = ld(1 + p.nz + s, c);
+        const float4 a = rv.load(1 + p.nz + s, c);
         const float4 v = *reinterpret_cast<const float4*>(vis + c);
         xx += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         xv += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
@@ -1127,33 +1094,6 @@ hipError_t launch_fold_conv_bn(const float* w, const float* b, const float* bn_w
     size_t blocks = ((size_t)Co * 9 * Ci + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(fold_conv_bn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, b, bn_w, bn_b, bn_mean, bn_var, w_out, b_out, Co, Ci);
-    return hipGetLastError();
-}
-
-// LayerNorm -> Linear folded (see kernels.h): one wave per output feature n.
-__global__ __launch_bounds__(256) void fold_ln_linear_kernel(const float* __restrict__ w, const float* __restrict__ b,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             bf16_t* __restrict__ w_out, float* __restrict__ b_out, float* __restrict__ cs_out,
-                                                             int N, int K) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const float* wr = w + (size_t)n * K;
-    float sb = 0.f, sc = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        const float wv = wr[k];
-        const bf16_t q = f2bf(wv * gamma[k]);
-        w_out[(size_t)n * K + k] = q;
-        sb += wv * beta[k];
-        sc += bf2f(q);
-    }
-    sb = wave_sum(sb);
-    sc = wave_sum(sc);
-    if (lane == 0) { b_out[n] = (b ? b[n] : 0.f) + sb; cs_out[n] = sc; }
-}
-hipError_t launch_fold_ln_linear(const float* w, const float* b, const float* gamma, const float* beta, bf16_t* w_out, float* b_out,
-                                 float* cs_out, int N, int K, hipStream_t s) {
-    hipLaunchKernelGGL(fold_ln_linear_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, w, b, gamma, beta, w_out, b_out, cs_out, N, K);
     return hipGetLastError();
 }
 

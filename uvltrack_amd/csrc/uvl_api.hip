@@ -44,9 +44,6 @@ struct RawTensor {
 struct VitBlockW {
     const float *ln1g, *ln1b, *ln2g, *ln2b, *bqkv, *bproj, *bfc1, *bfc2;
     bf16_t *wqkv, *wproj, *wfc1, *wfc2;
-    // norm1 folded into attn.qkv and norm2 into mlp.fc1 (launch_fold_ln_linear): frames of many sequences run without LayerNorm kernels
-    bf16_t *wqkv_ln, *wfc1_ln;
-    float *bqkv_ln, *csqkv, *bfc1_ln, *csfc1;
 };
 struct BertLayerW {
     const float *bao, *bi, *bo, *ln1g, *ln1b, *ln2g, *ln2b;
@@ -91,7 +88,6 @@ struct uvl_model {
     hipStream_t aux = nullptr;                   // text-branch stream (frames of several sequences)
     int pair_text = 1;                           // uvl_debug_set("pair_text", 0): text branch on its own stream even for one sequence
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
-    int ln_fold = 1;                             // uvl_debug_set("ln_fold", 0): LayerNorm kernels at every batch size
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_bert, ev_cont;
     // graph
@@ -272,16 +268,6 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
         w.wproj = P.bf16(b + "attn.proj.weight", D * D); w.bproj = P.f32(b + "attn.proj.bias", D);
         w.wfc1 = P.bf16(b + "mlp.fc1.weight", Fn * D); w.bfc1 = P.f32(b + "mlp.fc1.bias", Fn);
         w.wfc2 = P.bf16(b + "mlp.fc2.weight", D * Fn); w.bfc2 = P.f32(b + "mlp.fc2.bias", D);
-        w.wqkv_ln = P.alloc<bf16_t>(3 * D * D); w.bqkv_ln = P.alloc<float>(3 * D); w.csqkv = P.alloc<float>(3 * D);
-        w.wfc1_ln = P.alloc<bf16_t>(Fn * D); w.bfc1_ln = P.alloc<float>(Fn); w.csfc1 = P.alloc<float>(Fn);
-        {
-            const float* wq = P.f32(b + "attn.qkv.weight", 3 * D * D);
-            const float* wf = P.f32(b + "mlp.fc1.weight", Fn * D);
-            if (wq && wf && w.ln1g && w.ln1b && w.ln2g && w.ln2b && w.bqkv && w.bfc1 && w.wqkv_ln && w.bqkv_ln && w.csqkv && w.wfc1_ln && w.bfc1_ln && w.csfc1) {
-                launch_fold_ln_linear(wq, w.bqkv, w.ln1g, w.ln1b, w.wqkv_ln, w.bqkv_ln, w.csqkv, (int)(3 * D), (int)D, s);
-                launch_fold_ln_linear(wf, w.bfc1, w.ln2g, w.ln2b, w.wfc1_ln, w.bfc1_ln, w.csfc1, (int)Fn, (int)D, s);
-            }
-        }
         m->vit.push_back(w);
     }
     const std::string e = "backbone.bert.embeddings.";
@@ -403,7 +389,6 @@ struct Workspace {
     float* X; bf16_t *Xn, *Q, *K, *Vt, *O, *Hb, *P;
     bf16_t *Tn, *Tq, *Tk, *Tvt, *To, *Th;
     float *key_add, *bert_add, *cont, *bbox, *Part, *PartT, *TxtSnap, *ConvPart, *XSnap;
-    float2* Stats;
     bf16_t *G0, *G1, *G2, *G3, *G4;
     size_t total;
 };
@@ -432,7 +417,6 @@ static Workspace carve(const uvl_model* m, int B, char* base) {
     w.PartT = (float*)take((size_t)UVL_SKMAX * B * T * D * 4);
     w.TxtSnap = (float*)take((size_t)(m->nf > 0 ? m->nf : 1) * B * T * D * 4);
     w.XSnap = (float*)take(B * nj * D * 4);
-    w.Stats = (float2*)take(B * nj * (D / 64) * 8);
     w.ConvPart = (float*)take((size_t)UVL_CONV_SKMAX * B * S * 4 * C * 4);
     w.cont = (float*)take(B * S * 3 * 4);
     w.bbox = (float*)take(B * S * 4 * 4);
@@ -652,13 +636,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     auto consume = [](LnParams& p, Pending& pd) { p.part = pd.part; p.nsplit = pd.nsplit; p.part_rows = pd.rows; p.part_stride = pd.stride; pd = Pending(); };
     auto is_cont_layer = [&](int i) { bool c = false; for (int k = 0; k < m->cfg.n_cont; ++k) c |= (m->cfg.cont_layers[k] == i); return c; };
     auto residual_gemm = [&](hipStream_t st, const char* what, const bf16_t* A, int lda, const bf16_t* Wt, const float* bias, int Mr, int K,
-                             int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false, bool produce = false,
-                             bool add_modal = false) {
+                             int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false) {
         GemmParams p;
         p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
-        if (produce) { p.xb = w.Xn; p.stats_out = w.Stats; }          // the next GEMM normalises (ln_fold frames; never split)
-        if (add_modal) { p.rowadd0 = m->modal; p.rowadd1 = m->modal + D; p.rowadd_split = nv; }
-        const int sk = (allow_split && !produce) ? choose_splitk(Mr, D, K) : 1;
+        const int sk = allow_split ? choose_splitk(Mr, D, K) : 1;
         if (sk > 1) {             // slabs [sk][Mr, D], folded in by the next LayerNorm / contrast kernel
             p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D;
             pd.part = slab; pd.nsplit = sk; pd.rows = rpb; pd.stride = p.part_stride;
@@ -746,19 +727,6 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     int head_ct_slot = -1;                       // >= 0: head_prep also writes the last layer's logits into this slot
     int fused_ct = -1, fused_slot = 0;           // contrast layer whose logits the next layer's LayerNorm-2 will write
     Pending pend_v;                              // split-K slabs not yet folded into the residual stream (visual/joint rows)
-    // Frames of many sequences run the ViT blocks WITHOUT LayerNorm kernels (they are HBM passes over the residual stream there):
-    // the residual GEMMs (proj, fc2) also leave a bf16 copy of the updated rows and per-64-column statistics, and the GEMMs that
-    // follow a norm (qkv, fc1) run on that copy with gamma / beta folded into their weights and apply mean / rstd in the epilogue.
-    // A LayerNorm launch remains where the row set changes: layer 0 (after the patch embedding) and the first fusion layer; there
-    // it only rounds the rows and computes the statistics.  The text branch (post-LN, 40 rows per sequence) keeps its LayerNorms.
-    bool lnfree = false;
-    if (m->ln_fold && !paired && (long)B * nv >= 4096 && D % 256 == 0) {
-        GemmParams t;
-        t.M = B * nv; t.N = D; t.K = D; t.epi = 1; t.accumulate = 1;
-        GemmParams u = t;
-        u.K = Fn;
-        lnfree = choose_splitk(t.M, D, D) == 1 && choose_splitk(t.M, D, Fn) == 1 && gemm_producer_ok(t) && gemm_producer_ok(u);
-    }
     for (int i = 0; i < m->depth; ++i) {
         const bool joint = i >= m->nf;
         const int N = (joint && !skip) ? nj : nv;
@@ -771,9 +739,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             if (fork && hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
         }
         // ---- ViT block (block.py:29-32) ----
-        bool modal_in_x = false;                  // ln_fold frames: this layer's fc2 already added the next layer's modal embedding
-        const bool seam = i == 0 || i == m->nf;   // ln_fold frames: rows and statistics come from a LayerNorm launch, not from fc2
-        if (!lnfree || seam) {
+        {
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
             consume(p, pend_v);
@@ -781,14 +747,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             if (reuse && i == m->nf) { p.x_alt = w.TxtSnap + (size_t)(m->nf - 1) * B * T * D; p.x_alt_rows = T; }   // text rows kept from the last full frame
             p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
             if (fused_ct >= 0) p.x_snap = w.XSnap;   // this fold completes layer `fused_ct`: keep its output for the logits
-            if (lnfree) p.stats_out = w.Stats;
             run_ln(s, p, (double)M * D * 6, false);
         }
         {
             GemmParams p;
             p.A = w.Xn; p.lda = D; p.W = vw.wqkv; p.ldw = D; p.bias = vw.bqkv; p.M = M; p.N = 3 * D; p.K = D;
             p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D; p.q_scale = UVL_QSCALE;
-            if (lnfree) { p.W = vw.wqkv_ln; p.bias = vw.bqkv_ln; p.ln_cs = vw.csqkv; p.ln_stats = w.Stats; p.ln_eps = 1e-6f; }
             run_gemm(s, p, "gemm.qkv", false);
         }
         {
@@ -796,8 +760,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad; p.q_prescaled = 1;
             run_attn(s, p, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, false);
         }
-        residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true, false, lnfree);
-        if (!lnfree) {
+        residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true);
+        {
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
             consume(p, pend_v);
@@ -819,22 +783,15 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             GemmParams p;
             p.A = w.Xn; p.lda = D; p.W = vw.wfc1; p.ldw = D; p.bias = vw.bfc1; p.M = M; p.N = Fn; p.K = D;
             p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
-            if (lnfree) { p.W = vw.wfc1_ln; p.bias = vw.bfc1_ln; p.ln_cs = vw.csfc1; p.ln_stats = w.Stats; p.ln_eps = 1e-6f; }
             run_gemm(s, p, "gemm.fc1", false);
         }
-        {
-            // ln_fold frames: fc2 hands the next layer its rows; the permanent modal-embedding add of a fusion layer that has no
-            // LayerNorm launch of its own (every fusion layer after the first) moves into this epilogue
-            const bool feeds = lnfree && !last && i + 1 != m->nf;
-            modal_in_x = feeds && i + 1 > m->nf;
-            residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last, false, feeds, modal_in_x);
-        }
+        residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last);
         if (i <= last_bert && !paired) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
         if (is_cont_layer(i)) {
             if (out->d_logits && last && joint && i == m->depth - 1 && m->fuse_contrast && m->debug_stop_layer < 0) {
                 head_ct_slot = cont_slot;        // last layer: X is final, head_prep walks the same search rows anyway
-            } else if (out->d_logits && !last && !m->cfg.txt_token_mean && m->fuse_contrast && !lnfree) {
+            } else if (out->d_logits && !last && !m->cfg.txt_token_mean && m->fuse_contrast) {
                 // 'cls' text token and a following layer: the next LayerNorm-1 leaves this layer's output in XSnap and the
                 // next LayerNorm-2 computes the logits from it (no launch of its own)
                 fused_ct = i;
@@ -853,7 +810,6 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 p.text_mask = in->d_text_mask; p.flag = in->d_flag; p.logit_scale = m->logit_scale_bb;
                 p.mean_mode = m->cfg.txt_token_mean; p.skip_text = skip; p.logits = out->d_logits; p.slot = cont_slot; p.n_cont = m->cfg.n_cont;
                 p.part = pend_v.part; p.nsplit = pend_v.nsplit; p.part_rows = pend_v.rows; p.part_stride = pend_v.stride;   // read-only view
-                if (modal_in_x) { p.sub0 = m->modal; p.sub1 = m->modal + D; }
                 L.run(s, "contrast", 0, 0, tramp<ContrastParams, launch_contrast>, &p);
             }
             ++cont_slot;
@@ -968,7 +924,6 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
-    if (!strcmp(key, "ln_fold")) { m->ln_fold = value ? 1 : 0; return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
 }
 
@@ -1242,60 +1197,6 @@ extern "C" int uvl_layernorm(const float* d_x, const float* d_gamma, const float
     LnParams p;
     p.x = d_x; p.M = M; p.D = D; p.gamma = d_gamma; p.beta = d_beta; p.eps = eps; p.y_bf16 = (bf16_t*)d_y_bf16; p.y_f32 = d_y_f32;
     HIPCHK(launch_layernorm(p, (hipStream_t)stream));
-    return UVL_OK;
-}
-
-/* ---- LayerNorm folded into the neighbouring GEMMs (parity test entries; the kernels of the many-sequence frames) ---- */
-extern "C" int uvl_fold_ln_linear(const float* d_w, const float* d_b, const float* d_gamma, const float* d_beta, void* d_w_folded,
-                                  float* d_bias_folded, float* d_colsum, int N, int K, void* stream) {
-    if (!d_w || !d_gamma || !d_beta || !d_w_folded || !d_bias_folded || !d_colsum || N <= 0 || K <= 0) return fail(UVL_EINVAL, "uvl_fold_ln_linear: bad argument");
-    HIPCHK(launch_fold_ln_linear(d_w, d_b, d_gamma, d_beta, (bf16_t*)d_w_folded, d_bias_folded, d_colsum, N, K, (hipStream_t)stream));
-    return UVL_OK;
-}
-
-extern "C" int uvl_row_stats(const float* d_x, void* d_x_bf16, float* d_stats, int M, int D, void* stream) {
-    if (!d_x || !d_x_bf16 || !d_stats || M <= 0 || D % 256 != 0 || D > 1024) return fail(UVL_EINVAL, "uvl_row_stats: need D %% 256 == 0, D <= 1024");
-    LnParams p;
-    p.x = d_x; p.M = M; p.D = D; p.gamma = d_x; p.beta = d_x;       // not used by the statistics mode (read, never applied)
-    p.y_bf16 = (bf16_t*)d_x_bf16; p.stats_out = (float2*)d_stats;
-    HIPCHK(launch_layernorm(p, (hipStream_t)stream));
-    return UVL_OK;
-}
-
-extern "C" int uvl_linear_ln(const void* d_x_bf16, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum,
-                             float eps, void* d_y, int M, int N, int K, int act, void* stream) {
-    if (!d_x_bf16 || !d_stats || !d_w_folded || !d_bias_folded || !d_colsum || !d_y || M <= 0 || N % 64 != 0 || K % 128 != 0 || K > 1024)
-        return fail(UVL_EINVAL, "uvl_linear_ln: need N %% 64 == 0, K %% 128 == 0, K <= 1024");
-    GemmParams p;
-    p.A = (const bf16_t*)d_x_bf16; p.lda = K; p.W = (const bf16_t*)d_w_folded; p.ldw = K; p.bias = d_bias_folded; p.M = M; p.N = N; p.K = K;
-    p.epi = 0; p.C = d_y; p.ldc = N; p.act = act; p.ln_stats = (const float2*)d_stats; p.ln_cs = d_colsum; p.ln_eps = eps;
-    HIPCHK(launch_gemm(p, (hipStream_t)stream));
-    return UVL_OK;
-}
-
-extern "C" int uvl_qkv_project_ln(const void* d_x_bf16, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum,
-                                  float eps, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream) {
-    if (!d_x_bf16 || !d_stats || !d_w_folded || !d_bias_folded || !d_colsum || !d_q || !d_k || !d_vt || D % 128 != 0 || D > 1024)
-        return fail(UVL_EINVAL, "uvl_qkv_project_ln: bad argument");
-    GemmParams p;
-    p.A = (const bf16_t*)d_x_bf16; p.lda = D; p.W = (const bf16_t*)d_w_folded; p.ldw = D; p.bias = d_bias_folded; p.M = B * N; p.N = 3 * D; p.K = D;
-    p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale;
-    p.ln_stats = (const float2*)d_stats; p.ln_cs = d_colsum; p.ln_eps = eps;
-    HIPCHK(launch_gemm(p, (hipStream_t)stream));
-    return UVL_OK;
-}
-
-extern "C" int uvl_linear_residual(const void* d_a, const void* d_w, const float* d_bias, float* d_x, void* d_x_bf16, float* d_stats,
-                                   const float* d_rowadd0, const float* d_rowadd1, int rows_per_seq, int rowadd_split, int M, int N, int K, void* stream) {
-    if (!d_a || !d_w || !d_x || !d_x_bf16 || !d_stats || M <= 0 || N % 128 != 0 || K % 64 != 0 || rows_per_seq <= 0)
-        return fail(UVL_EINVAL, "uvl_linear_residual: need N %% 128 == 0 and K %% 64 == 0");
-    GemmParams p;
-    p.A = (const bf16_t*)d_a; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
-    p.epi = 1; p.C = d_x; p.ldc = N; p.accumulate = 1; p.rpb = rows_per_seq; p.obs = rows_per_seq; p.oro = 0;
-    p.xb = (bf16_t*)d_x_bf16; p.stats_out = (float2*)d_stats;
-    if (d_rowadd0) { p.rowadd0 = d_rowadd0; p.rowadd1 = d_rowadd1 ? d_rowadd1 : d_rowadd0; p.rowadd_split = rowadd_split; }
-    if (!gemm_producer_ok(p)) return fail(UVL_EINVAL, "uvl_linear_residual: M = %d resolves to a tile configuration without 64-column wave tiles (need M >= 1024)", M);
-    HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
 
