@@ -233,8 +233,10 @@ def kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, singl
         try:
             pdir = os.path.join(ROOT, "profiles")
             for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")):
-                tb = json.load(open(os.path.join(pdir, fn))).get("bytes_per_launch", {})
-                if name in tb and B == 1 and model == "B":
+                doc = json.load(open(os.path.join(pdir, fn)))
+                wl = doc.get("workload", {"model": "B", "batch": 1})
+                tb = doc.get("bytes_per_launch", {})
+                if name in tb and wl.get("batch") == B and wl.get("model") == model:
                     traffic = tb[name]
         except OSError:
             pass

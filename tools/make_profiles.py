@@ -1,6 +1,6 @@
 """Condense the rocprofv3 outputs a gpurun call left under gpurun_out/<tag>/ into the small, committed files of
 profiles/: the --stats CSV, a per-kernel PMC summary (MFMA busy, HBM bytes) and the traffic table bench.py reads.
-Usage: python tools/make_profiles.py <gpurun_out/tag> <round-prefix, e.g. r01>"""
+Usage: python tools/make_profiles.py <gpurun_out/tag> <round-prefix, e.g. r01> [model batch "workload text"]   (default: B 1)"""
 import collections
 import csv
 import json
@@ -32,7 +32,7 @@ def agg(path):
     return d, {k: len(v) for k, v in n.items()}
 
 
-def main(src, tag):
+def main(src, tag, model="B", batch=1, wl="bench.py default workload: UVLTrack-B z256/x256/T40, batch 1"):
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     st = os.path.join(src, "stats", "bench_kernel_stats.csv")
@@ -41,7 +41,7 @@ def main(src, tag):
         shutil.copy(st, os.path.join(out, tag + "_bench_kernel_stats.csv"))
         for r in csv.DictReader(open(st)):
             stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
-    lines = ["# %s -- rocprofv3 PMC summary per kernel (bench.py default workload: UVLTrack-B z256/x256/T40, batch 1)" % tag, "",
+    lines = ["# %s -- rocprofv3 PMC summary per kernel (%s)" % (tag, wl), "",
              "Separate `--pmc` passes (MFMA / FETCH_SIZE / WRITE_SIZE), each with `--kernel-trace` only.  `avg us` is from the",
              "un-instrumented `--kernel-trace --stats` run (PMC passes serialise and slow the kernels).  HBM bytes per launch =",
              "2 x FETCH_SIZE + WRITE_SIZE (KB): MI355X_MICROARCH.md says FETCH_SIZE reports half of a wide coalesced stream.",
@@ -65,6 +65,7 @@ def main(src, tag):
         lines.append("| `%s` | %d | %.2f | %.1f | %.0f | %.1f | %.0f | %.0f | %.2f |" % (k, calls, avg_us, pct, busy, util, fe, wr, hbm / 1e6))
     open(os.path.join(out, tag + "_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py` (%s)" % tag,
+               "workload": {"model": model, "batch": int(batch), "text": wl},
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", "bytes_per_launch": traffic},
               open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
     for fn in os.listdir(src):
@@ -83,4 +84,4 @@ def main(src, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:6])
