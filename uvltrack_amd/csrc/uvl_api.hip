@@ -373,8 +373,11 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
 
 // Split-K factor for an `x += A W^T` GEMM that would otherwise leave most CUs idle (batch-1 shapes): each split
 // writes an f32 slab, the consuming LayerNorm / contrast kernel adds the slabs on read (deterministic, no atomics).
+static int g_tune_sk[2] = {-1, -1};          // uvl_tune_set("sk_k1" / "sk_k4"): split-K of the residual GEMMs with K = D / K = 4 D (-1 = heuristic)
 static int choose_splitk(int M, int N, int K) {
     const int cap = UVL_SKMAX;
+    const int forced = g_tune_sk[K > N ? 1 : 0];
+    if (forced > 0 && (K / 64) % forced == 0 && forced <= cap) return forced;
     const long tiles = (long)((M + 63) / 64) * (N / 64);
     const int nk = K / 64;
     // measured (tools/gemm_bench.py): with ~100 tiles, K=768 likes 2 splits and K=3072 likes 4; nothing above ~250 tiles
@@ -916,6 +919,8 @@ extern "C" int uvl_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_cfg")) { uvl::g_tune_gemm_cfg = value; return UVL_OK; }
     if (!strcmp(key, "gemm_gm")) { uvl::g_tune_gemm_gm = value; return UVL_OK; }
     if (!strcmp(key, "attn_cfg")) { uvl::g_tune_attn_cfg = value; return UVL_OK; }
+    if (!strcmp(key, "sk_k1")) { g_tune_sk[0] = value; return UVL_OK; }
+    if (!strcmp(key, "sk_k4")) { g_tune_sk[1] = value; return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown tuning key '%s'", key);
 }
 
