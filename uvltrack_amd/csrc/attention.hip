@@ -666,6 +666,427 @@ static hipError_t launch_attn_stream(const AttnParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// attn_w64_kernel<NS>: 64 queries per wave (two 32-query blocks), four waves = 256 queries per workgroup, one wave per SIMD
+// with the whole register file (the guide's one-wave-per-SIMD shape).  Same LDS image, DMA ring and MFMA operand trick as
+// attn_stream_kernel; what changes is the work per wave between two barriers and who schedules it:
+//   * every K / V^T fragment read from LDS feeds two MFMAs (one per query block): half the LDS reads, DMA issues and barriers
+//     per MFMA
+//   * pass 1 uses NO running maximum at all: p = exp2(s) straight from the score MFMA (q carries log2(e)/8).  In bf16 / f32 the
+//     absolute scale of P is irrelevant (relative precision), so this is exact softmax arithmetic as long as exp2 neither
+//     overflows nor flushes a whole row: checked ONCE per item after the last tile (2^-100 < row sum < 2^100, NaN fails); a
+//     workgroup that fails redoes its item in pass 2, the textbook online softmax with true row maxima (compiler-scheduled).
+//     Masked keys need no special case in pass 1 (exp2(-1.4e10) = 0); a row whose keys are ALL masked has row sum 0 -> pass 2
+//   * the pass-1 tile is one straight-line block in five phases pinned with sched_barrier: score MFMAs of block 0 | score MFMAs
+//     of block 1 beside the exponentials / row sums / bf16 packing of block 0 (four exponentials per MFMA) and the V^T fragment
+//     reads | P V MFMAs of block 0 beside the exponentials of block 1 | P V MFMAs of block 1 beside the next tile's DMA issue.
+//     hipcc's own order is all MFMAs, then all exponentials (measured 537 TFLOP/s against the stream kernel's 654 at B = 32,
+//     H = 16, N = 681)
+//   * pass 1 issues a DMA round in EVERY tile (tile index clamped: the last NS-1 rounds re-read the final tile into stages
+//     nobody reads again), so the counted vmcnt wait and the whole tile are branch-free
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float attn_vadd(float a, float b) {   // one v_add_f32, never SLP-packed into v_pk_add_f32 (guide: anti-lever beside MFMAs)
+    float d;
+    asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#define ATTN_SB() __builtin_amdgcn_sched_barrier(0)
+// the lane index, recomputed where it is used: lane-constant addresses of RARE paths (tail fix-up, mask term) are otherwise hoisted
+// out of the tile loop and held (or spilled) across it
+__device__ __forceinline__ int attn_opaque_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
+    constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
+    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
+    constexpr int FLAG0 = KADD0 + NS * 4 * 256;           // 4 x int: "this wave wants the exact pass"
+    constexpr int VM = 5;                                 // VMEM operations per wave and tile: 2 K + 2 V^T pieces + the key_add row
+    static_assert(NS >= 3 && NS <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
+    int qb, h, b;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, Npad = p.Npad;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
+    const char* Kb = reinterpret_cast<const char*>(p.k + bh * Npad * 64);
+    const char* Vb = reinterpret_cast<const char*>(p.vt + bh * 64 * Npad);
+    const char* Ab = reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride);
+    const int nt = (N + 63) >> 6;
+    const int q0 = (qb * 4 + wave) * 64;
+    const bool active = q0 < N;                           // wave-uniform
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int qrow = q0 + 32 * x + (lane & 31);
+        const int qld = qrow < N ? qrow : N - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[x][kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
+        if (!p.q_prescaled) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[x][kk][e] = f2bf(bf2f(qf[x][kk][e]) * (0.125f * ATTN_LOG2E));
+        }
+    }
+
+    uint32_t voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave + 4 * (i & 1);
+        const int row = 8 * piece + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        voff[i] = i < 2 ? (uint32_t)(row * 128 + chunk * 16) : (uint32_t)row * (uint32_t)(Npad * 2) + (uint32_t)(chunk * 16);
+    }
+    auto pin = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+#define ATTN_GLDS(src, dst, bytes) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                                                    (__attribute__((address_space(3))) void*)(dst), bytes, 0, 0)
+    // one of the five DMA instructions of a round (i = 0, 1: K pieces, 2, 3: V^T pieces, 4: this wave's key_add row)
+    auto issue1 = [&](int t, auto stc, auto ic) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stc)::value, I = decltype(ic)::value;
+        char* st = smem + ST * STAGE;
+        if (I < 2) ATTN_GLDS(pin(Kb + (size_t)t * 8192) + voff[I], st + (wave + 4 * I) * 1024, 16);
+        else if (I < 4) ATTN_GLDS(pin(Vb + (size_t)t * 128) + voff[I], st + 8192 + (wave + 4 * (I - 2)) * 1024, 16);
+        else ATTN_GLDS(pin(Ab + (size_t)t * 256) + lane * 4, smem + KADD0 + (ST * 4 + wave) * 256, 4);
+    };
+    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
+        issue1(t, stc, AttnIC<0>{}); issue1(t, stc, AttnIC<1>{}); issue1(t, stc, AttnIC<2>{}); issue1(t, stc, AttnIC<3>{}); issue1(t, stc, AttnIC<4>{});
+    };
+    // tail tile: zero K rows / V^T columns beyond N in LDS (own pieces, after the own DMA wait, before the barrier)
+    auto tail_fix = [&](char* sK, int k0) __attribute__((always_inline)) {
+        const int lane = attn_opaque_lane();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 4 * (i & 1);
+            const int row = 8 * piece + (lane >> 3);
+            char* at = sK + (i < 2 ? 0 : 8192) + piece * 1024 + lane * 16;
+            if (i < 2) {
+                if (k0 + row >= N) *reinterpret_cast<u32x4*>(at) = u32x4{0u, 0u, 0u, 0u};
+            } else {
+                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                const int kb = k0 + chunk * 8;
+                if (kb + 8 > N) {
+                    u32x4 v = *reinterpret_cast<u32x4*>(at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t wv = v[e];
+                        if (kb + 2 * e >= N) wv &= 0xffff0000u;
+                        if (kb + 2 * e + 1 >= N) wv &= 0x0000ffffu;
+                        v[e] = wv;
+                    }
+                    *reinterpret_cast<u32x4*>(at) = v;
+                }
+            }
+        }
+    };
+
+    const int m31 = lane & 31;
+    const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
+    int koff[4], voff2[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = swz128(kperm, 2 * kk + half);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) voff2[jb][t] = swz128(m31, 4 * jb + 2 * t + half);
+
+    f32x16 o[2][2];
+    float l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[x][0][r] = 0.f; o[x][1][r] = 0.f; }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // =============================== pass 1: p = exp2(s), no maximum ===============================
+    {
+        float ps[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        auto tile = [&](const int t, auto stc) __attribute__((always_inline)) {
+            constexpr int ST = decltype(stc)::value;
+            char* sK = smem + ST * STAGE;
+            char* sV = sK + 8192;
+            float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
+            attn_wait_vmcnt<VM*(NS - 2)>();                 // a round is issued in every tile: rounds t+1 .. t+NS-2 stay in flight
+            const int k0 = t * 64;
+            if (t == nt - 1 && (N & 63)) tail_fix(sK, k0);
+            float ka = 0.f;
+            if (active) ka = sA[lane];                        // own DMA, own wait: no barrier needed for this row
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int tn = t + NS - 1;                              // the stage of round tn was last read in tile t-1
+            tn = tn < nt ? tn : nt - 1;
+            if (!active) { issue(tn, AttnIC<(ST + NS - 1) % NS>{}); return; }
+
+            ka = (k0 + lane < N) ? ka * ATTN_LOG2E : -INFINITY;                     // log2 domain; keys beyond N never count
+            const bool masked = __any(ka != 0.f);
+            bf16x8 kf[4][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) kf[kk][jb] = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
+            f32x16 s0[2], s1[2];
+            bf16x8 vf[2][2][2];
+            union PF { uint32_t u[4]; bf16x8 v; };
+            PF pf0[2][2], pf1[2][2];
+            ATTN_SB();
+            // ---- phase 2: scores of block 0 ----
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+                    s0[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[0][kk], kk == 0 ? zero16 : s0[jb], 0, 0, 0);
+            ATTN_SB();
+            // the mask term of this tile (log2 domain, -inf beyond N), added in the score registers' key order; re-read from the
+            // staged row for each block (32 live registers across phase 3 otherwise)
+            auto add_mask = [&](f32x16 (&sx)[2]) __attribute__((always_inline)) {
+                const int half = attn_opaque_lane() >> 5;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {          // registers 4gq..4gq+3 = keys 16(gq>>1) + 8 half + 4(gq&1) + 0..3
+                        const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
+                        const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sx[jb][4 * gq + e] += (k0 + kq + e < N) ? a[e] * ATTN_LOG2E : -INFINITY;
+                    }
+            };
+            if (masked) add_mask(s0);                         // wave-uniform
+            ATTN_SB();
+            // ---- phase 3: scores of block 1 | exponentials, row sums, packing of block 0, V^T fragment reads ----
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = i >> 1, jb = i & 1;
+                s1[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[1][kk], kk == 0 ? zero16 : s1[jb], 0, 0, 0);
+                const int ej = i >> 2, r0 = 4 * (i & 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s0[ej][r0 + e] = __builtin_amdgcn_exp2f(s0[ej][r0 + e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ps[0][e] = attn_vadd(ps[0][e], s0[ej][r0 + e]);
+                pf0[ej][(i & 3) >> 1].u[2 * (i & 1) + 0] = pack_bf16x2(s0[ej][r0 + 0], s0[ej][r0 + 1]);
+                pf0[ej][(i & 3) >> 1].u[2 * (i & 1) + 1] = pack_bf16x2(s0[ej][r0 + 2], s0[ej][r0 + 3]);
+                if (i >= 4) {                                 // V^T fragments in the order P V consumes them
+                    const int j0 = 2 * (i - 4), vjb = j0 >> 2, vt2 = (j0 >> 1) & 1;
+                    vf[0][vjb][vt2] = *reinterpret_cast<const bf16x8*>(sV + 0 * 4096 + voff2[vjb][vt2]);
+                    vf[1][vjb][vt2] = *reinterpret_cast<const bf16x8*>(sV + 1 * 4096 + voff2[vjb][vt2]);
+                }
+                ATTN_SB();
+            }
+            if (masked) add_mask(s1);
+            ATTN_SB();
+            // ---- phase 4: P V of block 0 | exponentials, row sums, packing of block 1 ----
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf0[jb][t2].v, o[0][db], 0, 0, 0);
+                const int ej = j >> 2, r0 = 4 * (j & 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s1[ej][r0 + e] = __builtin_amdgcn_exp2f(s1[ej][r0 + e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ps[1][e] = attn_vadd(ps[1][e], s1[ej][r0 + e]);
+                pf1[ej][(j & 3) >> 1].u[2 * (j & 1) + 0] = pack_bf16x2(s1[ej][r0 + 0], s1[ej][r0 + 1]);
+                pf1[ej][(j & 3) >> 1].u[2 * (j & 1) + 1] = pack_bf16x2(s1[ej][r0 + 2], s1[ej][r0 + 3]);
+                ATTN_SB();
+            }
+            // ---- phase 5: P V of block 1 | the next round's DMA issue ----
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf1[jb][t2].v, o[1][db], 0, 0, 0);
+                if (j == 1) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<0>{});
+                if (j == 2) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<1>{});
+                if (j == 3) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<2>{});
+                if (j == 4) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<3>{});
+                if (j == 5) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<4>{});
+                ATTN_SB();
+            }
+        };
+
+        issue(0, AttnIC<0>{});
+        issue(1 < nt ? 1 : nt - 1, AttnIC<1>{});
+        if (NS == 4) issue(2 < nt ? 2 : nt - 1, AttnIC<2 % NS>{});
+        for (int t0 = 0; t0 < nt; t0 += NS) {
+            tile(t0, AttnIC<0>{});
+            if (t0 + 1 < nt) tile(t0 + 1, AttnIC<1>{});
+            if (t0 + 2 < nt) tile(t0 + 2, AttnIC<2>{});
+            if (NS >= 4 && t0 + 3 < nt) tile(t0 + 3, AttnIC<3 % NS>{});
+        }
+        attn_wait_vmcnt<0>();                               // the clamped rounds of the last tiles
+#pragma unroll
+        for (int x = 0; x < 2; ++x) l_run[x] = (ps[x][0] + ps[x][1]) + (ps[x][2] + ps[x][3]);
+    }
+
+    // one check per item: did exp2 overflow, or flush a whole row?  Workgroup-wide decision (pass 2 needs every wave for its DMA
+    // ring and barriers)
+    bool bad = false;
+    if (active) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
+            bad = bad || !(l_tot < 1.2676506e30f && l_tot > 7.888609e-31f);      // 2^100, 2^-100; NaN fails both
+        }
+        bad = __any(bad);
+    }
+    {
+        int* flags = reinterpret_cast<int*>(smem + FLAG0);
+        if (lane == 0) flags[wave] = bad ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int any_bad = flags[0] | flags[1] | flags[2] | flags[3];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bad = __builtin_amdgcn_readfirstlane(any_bad) != 0;
+    }
+
+    // =============================== pass 2 (rare): online softmax with true row maxima ===============================
+    if (bad) {
+        __builtin_amdgcn_s_barrier();                       // every wave has read the flags; the ring may be refilled
+        float m_run[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            l_run[x] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[x][0][r] = 0.f; o[x][1][r] = 0.f; }
+        }
+        auto tile2 = [&](const int t, auto stc) __attribute__((always_inline)) {
+            constexpr int ST = decltype(stc)::value;
+            char* sK = smem + ST * STAGE;
+            char* sV = sK + 8192;
+            float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
+            if (t + NS - 2 < nt) attn_wait_vmcnt<VM*(NS - 2)>();    // rounds t+1 .. t+NS-2 may stay in flight
+            else if (NS >= 4 && t + 1 < nt) attn_wait_vmcnt<VM>();
+            else attn_wait_vmcnt<0>();
+            const int k0 = t * 64;
+            if (t == nt - 1 && (N & 63)) tail_fix(sK, k0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + NS - 1 < nt) issue(t + NS - 1, AttnIC<(ST + NS - 1) % NS>{});
+            if (!active) return;
+            f32x16 s[2][2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
+                        s[x][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[x][kk], kk == 0 ? zero16 : s[x][jb], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
+                    const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ad = (k0 + kq + e < N) ? a[e] * ATTN_LOG2E : -INFINITY;
+                        s[0][jb][4 * gq + e] += ad;
+                        s[1][jb][4 * gq + e] += ad;
+                    }
+                }
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[x][0][r], s[x][1][r]));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[x], tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[x] - m_new);      // first tile: exp2(-inf) = 0
+                m_run[x] = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[x][0][r] *= alpha; o[x][1][r] *= alpha; }
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[x][0][r] = __builtin_amdgcn_exp2f(s[x][0][r] - m_new);
+                    s[x][1][r] = __builtin_amdgcn_exp2f(s[x][1][r] - m_new);
+                    ps[r & 1] += s[x][0][r];
+                    ps[2 + (r & 1)] += s[x][1][r];
+                }
+                l_run[x] = l_run[x] * alpha + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        union { uint32_t u[4]; bf16x8 v; } pf;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s[x][jb][8 * t2 + 2 * e], s[x][jb][8 * t2 + 2 * e + 1]);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const bf16x8 vfr = *reinterpret_cast<const bf16x8*>(sV + db * 4096 + voff2[jb][t2]);
+                            o[x][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, pf.v, o[x][db], 0, 0, 0);
+                        }
+                    }
+        };
+        issue(0, AttnIC<0>{});
+        if (1 < nt) issue(1, AttnIC<1>{});
+        if (NS == 4 && 2 < nt) issue(2, AttnIC<2 % NS>{});
+        for (int t0 = 0; t0 < nt; t0 += NS) {
+            tile2(t0, AttnIC<0>{});
+            if (t0 + 1 < nt) tile2(t0 + 1, AttnIC<1>{});
+            if (t0 + 2 < nt) tile2(t0 + 2, AttnIC<2>{});
+            if (NS >= 4 && t0 + 3 < nt) tile2(t0 + 3, AttnIC<3 % NS>{});
+        }
+    }
+#undef ATTN_GLDS
+
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int qrow = q0 + 32 * x + (lane & 31);
+        if (qrow < N) {
+            const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
+            const float inv = 1.0f / l_tot;
+            bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int d0 = 32 * db + 8 * gq + 4 * half;
+                    uint2 w;
+                    w.x = pack_bf16x2(o[x][db][4 * gq + 0] * inv, o[x][db][4 * gq + 1] * inv);
+                    w.y = pack_bf16x2(o[x][db][4 * gq + 2] * inv, o[x][db][4 * gq + 3] * inv);
+                    *reinterpret_cast<uint2*>(dst + d0) = w;
+                }
+        }
+    }
+}
+
+template <int NS>
+static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
+    constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256 + 16;
+    auto kern = attn_w64_kernel<NS>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[40];
+    if (!name[0]) snprintf(name, sizeof(name), "attn_w64_kernel<%d>", NS);
+    g_last_kernel = name;
+    const int total = ((((p_in.N + 63) / 64) + 3) / 4) * p_in.H * p_in.B;
+    AttnParams p = p_in;
+    p.xcd_map = total >= 400 ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 template <int QW, int KS, int NS>
 static hipError_t launch_attn_pair_cfg(const AttnParams& a, const AttnParams& b, hipStream_t s) {
     constexpr size_t ring = (size_t)NS * KS * (8192 + 8192 + 256 + 16);
@@ -764,6 +1185,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 7: return launch_attn_cfg<2, 4, 2>(p, s);     // 64 queries x 4 key quarters (8 waves, 133 KB of LDS)
         case 8: return launch_attn_stream<3>(p, s);        // batched: 128 queries per workgroup, speculative tiles
         case 9: return launch_attn_stream<2>(p, s);
+        case 10: return launch_attn_w64<3>(p, s);          // 64 queries per wave, one wave per SIMD
+        case 11: return launch_attn_w64<4>(p, s);
     }
     return hipErrorInvalidValue;
 }
