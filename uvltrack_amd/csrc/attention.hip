@@ -700,6 +700,17 @@ __device__ __forceinline__ int attn_opaque_lane() {
     return l;
 }
 
+#ifdef ATTN_TRACE
+// development build only (tools/attn_trace.py): shader-clock stamps of wave 0 of workgroup 0, summed per phase over the tiles
+__device__ unsigned long long g_attn_trace[16 + 8 * 32];
+#define ATTN_STAMP(i) do { ATTN_SB(); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                           tr_acc[i] += now_ - tr_last; \
+                           if (blockIdx.x == 0 && threadIdx.x == 0 && tr_tile < 32) reinterpret_cast<unsigned int*>(smem + 160 * 1024 - 1024)[tr_tile * 8 + (i)] = (unsigned int)(now_ - tr_last); \
+                           tr_last = now_; ATTN_SB(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+
 template <int NS>
 __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
@@ -711,6 +722,11 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
     int qb, h, b;
     if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+#ifdef ATTN_TRACE
+    unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long tr_start = tr_last;
+    int tr_slot0 = 0, tr_tile = 0;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -754,14 +770,15 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 #define ATTN_GLDS(src, dst, bytes) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                                                     (__attribute__((address_space(3))) void*)(dst), bytes, 0, 0)
     // one of the five DMA instructions of a round (i = 0, 1: K pieces, 2, 3: V^T pieces, 4: this wave's key_add row)
-    auto issue1 = [&](int t, auto stc, auto ic) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stc)::value, I = decltype(ic)::value;
+    auto issue1 = [&](int t, int stage, auto ic) __attribute__((always_inline)) {
+        constexpr int I = decltype(ic)::value;
+        const int ST = stage;
         char* st = smem + ST * STAGE;
         if (I < 2) ATTN_GLDS(pin(Kb + (size_t)t * 8192) + voff[I], st + (wave + 4 * I) * 1024, 16);
         else if (I < 4) ATTN_GLDS(pin(Vb + (size_t)t * 128) + voff[I], st + 8192 + (wave + 4 * (I - 2)) * 1024, 16);
         else ATTN_GLDS(pin(Ab + (size_t)t * 256) + lane * 4, smem + KADD0 + (ST * 4 + wave) * 256, 4);
     };
-    auto issue = [&](int t, auto stc) __attribute__((always_inline)) {
+    auto issue = [&](int t, int stc) __attribute__((always_inline)) {
         issue1(t, stc, AttnIC<0>{}); issue1(t, stc, AttnIC<1>{}); issue1(t, stc, AttnIC<2>{}); issue1(t, stc, AttnIC<3>{}); issue1(t, stc, AttnIC<4>{});
     };
     // tail tile: zero K rows / V^T columns beyond N in LDS (own pieces, after the own DMA wait, before the barrier)
@@ -813,29 +830,36 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     // =============================== pass 1: p = exp2(s), no maximum ===============================
     {
         float ps[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        auto tile = [&](const int t, auto stc) __attribute__((always_inline)) {
-            constexpr int ST = decltype(stc)::value;
+        auto tile = [&](const int t, const int ST) __attribute__((always_inline)) {
+            const int STN = ST == 0 ? NS - 1 : ST - 1;      // the stage of the round issued in this tile
             char* sK = smem + ST * STAGE;
             char* sV = sK + 8192;
             float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
-            attn_wait_vmcnt<VM*(NS - 2)>();                 // a round is issued in every tile: rounds t+1 .. t+NS-2 stay in flight
+#ifdef ATTN_TRACE_CAL
+            if (tr_slot0) ATTN_STAMP(6); else
+#endif
+            ATTN_STAMP(0);                                  // [0] = between tiles (loop control)
+            if (t + NS - 2 < nt) attn_wait_vmcnt<VM*(NS - 2)>();    // rounds t+1 .. t+NS-2 may stay in flight
+            else if (NS >= 4 && t + 1 < nt) attn_wait_vmcnt<VM>();
+            else attn_wait_vmcnt<0>();
             const int k0 = t * 64;
-            if (t == nt - 1 && (N & 63)) tail_fix(sK, k0);
-            float ka = 0.f;
-            if (active) ka = sA[lane];                        // own DMA, own wait: no barrier needed for this row
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t == nt - 1 && (N & 63)) {
+                tail_fix(sK, k0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
-            int tn = t + NS - 1;                              // the stage of round tn was last read in tile t-1
-            tn = tn < nt ? tn : nt - 1;
-            if (!active) { issue(tn, AttnIC<(ST + NS - 1) % NS>{}); return; }
+            ATTN_STAMP(1);                                  // [1] = DMA wait + barrier
+            const int tn = t + NS - 1;                        // the stage of round tn was last read in tile t-1
+            const bool do_issue = tn < nt;
+            if (!active) { if (do_issue) issue(tn, STN); return; }
 
-            ka = (k0 + lane < N) ? ka * ATTN_LOG2E : -INFINITY;                     // log2 domain; keys beyond N never count
-            const bool masked = __any(ka != 0.f);
             bf16x8 kf[4][2];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) kf[kk][jb] = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
+            float ka = sA[lane];                              // this wave's own copy of the tile's key_add row: its latency rides on the K reads
+            ka = (k0 + lane < N) ? ka * ATTN_LOG2E : -INFINITY;                     // log2 domain; keys beyond N never count
             f32x16 s0[2], s1[2];
             bf16x8 vf[2][2][2];
             union PF { uint32_t u[4]; bf16x8 v; };
@@ -847,7 +871,8 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb)
                     s0[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[0][kk], kk == 0 ? zero16 : s0[jb], 0, 0, 0);
-            ATTN_SB();
+            const bool masked = __any(ka != 0.f);
+            ATTN_STAMP(2);                                  // [2] = K fragment reads + phase 2
             // the mask term of this tile (log2 domain, -inf beyond N), added in the score registers' key order; re-read from the
             // staged row for each block (32 live registers across phase 3 otherwise)
             auto add_mask = [&](f32x16 (&sx)[2]) __attribute__((always_inline)) {
@@ -884,6 +909,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
                 }
                 ATTN_SB();
             }
+            ATTN_STAMP(3);                                  // [3] = (mask) + phase 3
             if (masked) add_mask(s1);
             ATTN_SB();
             // ---- phase 4: P V of block 0 | exponentials, row sums, packing of block 1 ----
@@ -900,30 +926,57 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
                 pf1[ej][(j & 3) >> 1].u[2 * (j & 1) + 1] = pack_bf16x2(s1[ej][r0 + 2], s1[ej][r0 + 3]);
                 ATTN_SB();
             }
-            // ---- phase 5: P V of block 1 | the next round's DMA issue ----
+            ATTN_STAMP(4);                                  // [4] = (mask) + phase 4
+            // ---- phase 5: P V of block 1 | the next round's DMA issue (two bodies behind one wave-uniform branch) ----
+            if (do_issue) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
-                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf1[jb][t2].v, o[1][db], 0, 0, 0);
-                if (j == 1) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<0>{});
-                if (j == 2) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<1>{});
-                if (j == 3) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<2>{});
-                if (j == 4) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<3>{});
-                if (j == 5) issue1(tn, AttnIC<(ST + NS - 1) % NS>{}, AttnIC<4>{});
-                ATTN_SB();
+                for (int j = 0; j < 8; ++j) {
+                    const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                    o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf1[jb][t2].v, o[1][db], 0, 0, 0);
+                    if (j == 1) issue1(tn, STN, AttnIC<0>{});
+                    if (j == 2) issue1(tn, STN, AttnIC<1>{});
+                    if (j == 3) issue1(tn, STN, AttnIC<2>{});
+                    if (j == 4) issue1(tn, STN, AttnIC<3>{});
+                    if (j == 5) issue1(tn, STN, AttnIC<4>{});
+                    ATTN_SB();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                    o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf1[jb][t2].v, o[1][db], 0, 0, 0);
+                }
             }
+            ATTN_STAMP(5);                                  // [5] = phase 5
+#ifdef ATTN_TRACE
+            ++tr_tile;
+#endif
         };
 
-        issue(0, AttnIC<0>{});
-        issue(1 < nt ? 1 : nt - 1, AttnIC<1>{});
-        if (NS == 4) issue(2 < nt ? 2 : nt - 1, AttnIC<2 % NS>{});
-        for (int t0 = 0; t0 < nt; t0 += NS) {
-            tile(t0, AttnIC<0>{});
-            if (t0 + 1 < nt) tile(t0 + 1, AttnIC<1>{});
-            if (t0 + 2 < nt) tile(t0 + 2, AttnIC<2>{});
-            if (NS >= 4 && t0 + 3 < nt) tile(t0 + 3, AttnIC<3 % NS>{});
+        ATTN_STAMP(6);                                      // [6] = prologue (q loads, addresses)
+        issue(0, 0);
+        if (1 < nt) issue(1, 1);
+        if (NS == 4 && 2 < nt) issue(2, 2);
+        // NOT unrolled by the ring depth: three copies of the tile (34 KB of code) cost ~600 cycles per tile at the jump into the
+        // next copy (instruction fetch); the stage is a run-time LDS offset instead (a handful of address adds per tile)
+        int stage = 0;
+#ifdef ATTN_TRACE_CAL
+        for (int t = 0; t < nt; t += 2) {                   // calibration: the second tile of a pair is reached without a taken branch
+            tile(t, stage);
+            stage = stage + 1 == NS ? 0 : stage + 1;
+            if (t + 1 < nt) {
+                tr_slot0 = 6;
+                tile(t + 1, stage);
+                tr_slot0 = 0;
+                stage = stage + 1 == NS ? 0 : stage + 1;
+            }
         }
-        attn_wait_vmcnt<0>();                               // the clamped rounds of the last tiles
+#else
+        for (int t = 0; t < nt; ++t) {
+            tile(t, stage);
+            stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+#endif
 #pragma unroll
         for (int x = 0; x < 2; ++x) l_run[x] = (ps[x][0] + ps[x][1]) + (ps[x][2] + ps[x][3]);
     }
@@ -959,8 +1012,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[x][0][r] = 0.f; o[x][1][r] = 0.f; }
         }
-        auto tile2 = [&](const int t, auto stc) __attribute__((always_inline)) {
-            constexpr int ST = decltype(stc)::value;
+        auto tile2 = [&](const int t, const int ST) __attribute__((always_inline)) {
             char* sK = smem + ST * STAGE;
             char* sV = sK + 8192;
             float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
@@ -971,7 +1023,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
             if (t == nt - 1 && (N & 63)) tail_fix(sK, k0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (t + NS - 1 < nt) issue(t + NS - 1, AttnIC<(ST + NS - 1) % NS>{});
+            if (t + NS - 1 < nt) issue(t + NS - 1, (ST + NS - 1) % NS);
             if (!active) return;
             f32x16 s[2][2];
 #pragma unroll
@@ -1034,18 +1086,13 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
                         }
                     }
         };
-        issue(0, AttnIC<0>{});
-        if (1 < nt) issue(1, AttnIC<1>{});
-        if (NS == 4 && 2 < nt) issue(2, AttnIC<2 % NS>{});
-        for (int t0 = 0; t0 < nt; t0 += NS) {
-            tile2(t0, AttnIC<0>{});
-            if (t0 + 1 < nt) tile2(t0 + 1, AttnIC<1>{});
-            if (t0 + 2 < nt) tile2(t0 + 2, AttnIC<2>{});
-            if (NS >= 4 && t0 + 3 < nt) tile2(t0 + 3, AttnIC<3 % NS>{});
-        }
+        issue(0, 0);
+        if (1 < nt) issue(1, 1);
+        if (NS == 4 && 2 < nt) issue(2, 2);
+        for (int t = 0; t < nt; ++t) tile2(t, t % NS);
     }
 #undef ATTN_GLDS
-
+    ATTN_STAMP(0);
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int qrow = q0 + 32 * x + (lane & 31);
@@ -1053,23 +1100,42 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
             const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
             const float inv = 1.0f / l_tot;
             bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
+            // 16-byte stores (guide T21): the two half-waves hold columns 8g..8g+3 / 8g+4..8g+7 of the same row; one
+            // v_permlane32_swap per dword turns a pair of column groups into 16 contiguous bytes per lane
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int d0 = 32 * db + 8 * gq + 4 * half;
-                    uint2 w;
-                    w.x = pack_bf16x2(o[x][db][4 * gq + 0] * inv, o[x][db][4 * gq + 1] * inv);
-                    w.y = pack_bf16x2(o[x][db][4 * gq + 2] * inv, o[x][db][4 * gq + 3] * inv);
-                    *reinterpret_cast<uint2*>(dst + d0) = w;
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint32_t a0 = pack_bf16x2(o[x][db][8 * gp + 0] * inv, o[x][db][8 * gp + 1] * inv);
+                    uint32_t a1 = pack_bf16x2(o[x][db][8 * gp + 2] * inv, o[x][db][8 * gp + 3] * inv);
+                    uint32_t b0 = pack_bf16x2(o[x][db][8 * gp + 4] * inv, o[x][db][8 * gp + 5] * inv);
+                    uint32_t b1 = pack_bf16x2(o[x][db][8 * gp + 6] * inv, o[x][db][8 * gp + 7] * inv);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    const u32x4 w = {(uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]};
+                    *reinterpret_cast<u32x4*>(dst + 32 * db + 16 * gp + 8 * half) = w;
                 }
         }
     }
+#ifdef ATTN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(7);                                          // [7] = epilogue (normalise + stores)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 8; ++i) g_attn_trace[i] = tr_acc[i];
+        g_attn_trace[8] = tr_last - tr_start;
+        g_attn_trace[9] = (unsigned long long)nt;
+        for (int i = 0; i < 8 * 32; ++i) g_attn_trace[16 + i] = reinterpret_cast<unsigned int*>(smem + 160 * 1024 - 1024)[i];
+    }
+#endif
 }
 
 template <int NS>
 static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
+#ifdef ATTN_TRACE
+    constexpr size_t lds = 160 * 1024;
+#else
     constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256 + 16;
+#endif
     auto kern = attn_w64_kernel<NS>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -1130,6 +1196,9 @@ static hipError_t launch_attn_cfg(const AttnParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef ATTN_TRACE
+extern "C" int uvl_debug_attn_trace(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), (16 + 8 * 32) * sizeof(unsigned long long)); }
+#endif
 int g_tune_attn_cfg = -1;      // tools/attn_bench.py override
 
 static int pick_attn_cfg(const AttnParams& p) {
