@@ -703,9 +703,10 @@ __device__ __forceinline__ int attn_opaque_lane() {
 #ifdef ATTN_TRACE
 // development build only (tools/attn_trace.py): shader-clock stamps of wave 0 of workgroup 0, summed per phase over the tiles
 __device__ unsigned long long g_attn_trace[16 + 8 * 32];
+#define ATTN_TRACE_OFF (4 * 16384 + 4 * 4 * 256 + 16)       // behind the kernel's own LDS (two workgroups per CU still fit)
 #define ATTN_STAMP(i) do { ATTN_SB(); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                            tr_acc[i] += now_ - tr_last; \
-                           if (blockIdx.x == 0 && threadIdx.x == 0 && tr_tile < 32) reinterpret_cast<unsigned int*>(smem + 160 * 1024 - 1024)[tr_tile * 8 + (i)] = (unsigned int)(now_ - tr_last); \
+                           if (blockIdx.x == 0 && threadIdx.x == 0 && tr_tile < 32) reinterpret_cast<unsigned int*>(smem + ATTN_TRACE_OFF)[tr_tile * 8 + (i)] = (unsigned int)(now_ - tr_last); \
                            tr_last = now_; ATTN_SB(); } while (0)
 #else
 #define ATTN_STAMP(i) do { } while (0)
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
     constexpr int FLAG0 = KADD0 + NS * 4 * 256;           // 4 x int: "this wave wants the exact pass"
     constexpr int VM = 5;                                 // VMEM operations per wave and tile: 2 K + 2 V^T pieces + the key_add row
-    static_assert(NS >= 3 && NS <= 4, "ring depth");
+    static_assert(NS == 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
     int qb, h, b;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 #define ATTN_GLDS(src, dst, bytes) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                                                     (__attribute__((address_space(3))) void*)(dst), bytes, 0, 0)
     // one of the five DMA instructions of a round (i = 0, 1: K pieces, 2, 3: V^T pieces, 4: this wave's key_add row)
-    auto issue1 = [&](int t, int stage, auto ic) __attribute__((always_inline)) {
+    auto issue1 = [&](int t, int stage, auto ic) __attribute__((always_inline)) {      // stage: a constant wherever the ring is live
         constexpr int I = decltype(ic)::value;
         const int ST = stage;
         char* st = smem + ST * STAGE;
@@ -828,19 +829,40 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // =============================== pass 1: p = exp2(s), no maximum ===============================
+    // Software pipeline across tiles, four phases of 8 MFMAs, each beside ONE half of a block's softmax (16 exponentials, 16 row-sum
+    // adds, 8 packs: five single-issue fillers per MFMA, the guide's budget for one wave):
+    //   phase 1: scores of block 0, tile t      | softmax of block 1, tile t-1, keys 32..63   + this tile's DMA round (t + 2)
+    //   phase 2: scores of block 1, tile t      | softmax of block 0, tile t, keys 0..31      + V^T fragments of tile t-1
+    //   phase 3: P V of block 1, tile t-1       | softmax of block 0, tile t, keys 32..63     + V^T fragments of tile t
+    //   phase 4: P V of block 0, tile t         | softmax of block 1, tile t, keys 0..31
+    // Block 1 trails block 0 by half a tile, so no phase is MFMA-only or VALU-only.  Tile t-1's V^T stage is read in tile t: the
+    // ring has four stages (t-1, t, and rounds t+1, t+2 in flight) and round t+2 is issued behind tile t's barrier.
     {
-        float ps[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        static_assert(NS == 4, "the pipelined pass needs four stages");
+        float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        union PF { uint32_t u[4]; bf16x8 v; };
+        f32x16 s1c;                                         // scores of block 1, keys 32..63 of the previous tile (not yet exponentiated)
+        PF pf1a[2];                                         // P of block 1, keys 0..31 of the previous tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1c[r] = -INFINITY;    // "tile -1": p = 0
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf1a[t2].u[e] = 0u;
+
+        // The ring stage is a RUN-TIME LDS offset (one copy of the tile: 15 KB of code; unrolled by the ring depth it is 59 KB and
+        // spills).  hipcc cannot tell a run-time-staged ds_read from the round in flight and would drain the ring (s_waitcnt
+        // vmcnt(0)) in front of every fragment read, so the steady-state LDS reads are inline asm with hand-placed lgkmcnt waits
+        // (the phases are pinned with sched_barrier anyway); only the rare paths (mask term, tail fix-up) use ordinary LDS accesses.
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
         auto tile = [&](const int t, const int ST) __attribute__((always_inline)) {
-            const int STN = ST == 0 ? NS - 1 : ST - 1;      // the stage of the round issued in this tile
+            const int STN = (ST + 2) & 3;                   // the stage of the round issued in this tile (last read in tile t-1: V^T of t-2)
+            const int STP = t == 0 ? ST : ((ST + 3) & 3);   // the previous tile's stage ("tile -1" reads this tile's V^T against p = 0)
             char* sK = smem + ST * STAGE;
-            char* sV = sK + 8192;
+            const uint32_t aK = lds0 + ST * STAGE, aV = aK + 8192, aVp = lds0 + STP * STAGE + 8192;
             float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
-#ifdef ATTN_TRACE_CAL
-            if (tr_slot0) ATTN_STAMP(6); else
-#endif
             ATTN_STAMP(0);                                  // [0] = between tiles (loop control)
-            if (t + NS - 2 < nt) attn_wait_vmcnt<VM*(NS - 2)>();    // rounds t+1 .. t+NS-2 may stay in flight
-            else if (NS >= 4 && t + 1 < nt) attn_wait_vmcnt<VM>();
+            if (t + 1 < nt) attn_wait_vmcnt<VM>();          // round t+1 may stay in flight
             else attn_wait_vmcnt<0>();
             const int k0 = t * 64;
             if (t == nt - 1 && (N & 63)) {
@@ -849,32 +871,27 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
             }
             __builtin_amdgcn_s_barrier();
             ATTN_STAMP(1);                                  // [1] = DMA wait + barrier
-            const int tn = t + NS - 1;                        // the stage of round tn was last read in tile t-1
+            const int tn = t + 2;
             const bool do_issue = tn < nt;
             if (!active) { if (do_issue) issue(tn, STN); return; }
 
             bf16x8 kf[4][2];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) kf[kk][jb] = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
-            float ka = sA[lane];                              // this wave's own copy of the tile's key_add row: its latency rides on the K reads
-            ka = (k0 + lane < N) ? ka * ATTN_LOG2E : -INFINITY;                     // log2 domain; keys beyond N never count
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint32_t ak = aK + koff[kk];
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[kk][0]) : "v"(ak) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kf[kk][1]) : "v"(ak) : "memory");
+            }
+            float ka;                                         // this wave's own copy of the tile's key_add row: its latency rides on the K reads
+            {
+                const uint32_t aa = lds0 + KADD0 + (ST * 4 + wave) * 256 + lane * 4;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(ka) : "v"(aa) : "memory");
+            }
             f32x16 s0[2], s1[2];
-            bf16x8 vf[2][2][2];
-            union PF { uint32_t u[4]; bf16x8 v; };
-            PF pf0[2][2], pf1[2][2];
-            ATTN_SB();
-            // ---- phase 2: scores of block 0 ----
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-                    s0[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[0][kk], kk == 0 ? zero16 : s0[jb], 0, 0, 0);
-            const bool masked = __any(ka != 0.f);
-            ATTN_STAMP(2);                                  // [2] = K fragment reads + phase 2
+            bf16x8 vf[2][2][2], vfp[2][2][2];
+            PF pf0[2][2], pf1b[2];
             // the mask term of this tile (log2 domain, -inf beyond N), added in the score registers' key order; re-read from the
-            // staged row for each block (32 live registers across phase 3 otherwise)
+            // staged row for each block
             auto add_mask = [&](f32x16 (&sx)[2]) __attribute__((always_inline)) {
                 const int half = attn_opaque_lane() >> 5;
 #pragma unroll
@@ -888,97 +905,131 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
                         for (int e = 0; e < 4; ++e) sx[jb][4 * gq + e] += (k0 + kq + e < N) ? a[e] * ATTN_LOG2E : -INFINITY;
                     }
             };
-            if (masked) add_mask(s0);                         // wave-uniform
+            // half a block's softmax, slice i of 8: two exponentials, two row-sum adds, one pack (word i & 3 of P fragment i >> 2)
+#define ATTN_SM_SLICE(sblk, psx, pfarr, i)                                                                 \
+            do {                                                                                           \
+                sblk[2 * (i)] = __builtin_amdgcn_exp2f(sblk[2 * (i)]);                                     \
+                sblk[2 * (i) + 1] = __builtin_amdgcn_exp2f(sblk[2 * (i) + 1]);                             \
+                psx[0] = attn_vadd(psx[0], sblk[2 * (i)]);                                                 \
+                psx[1] = attn_vadd(psx[1], sblk[2 * (i) + 1]);                                             \
+                pfarr[(i) >> 2].u[(i) & 3] = pack_bf16x2(sblk[2 * (i)], sblk[2 * (i) + 1]);                \
+            } while (0)
+#define ATTN_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); ATTN_SB(); } while (0)
             ATTN_SB();
-            // ---- phase 3: scores of block 1 | exponentials, row sums, packing of block 0, V^T fragment reads ----
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kk = i >> 1, jb = i & 1;
-                s1[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[1][kk], kk == 0 ? zero16 : s1[jb], 0, 0, 0);
-                const int ej = i >> 2, r0 = 4 * (i & 3);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s0[ej][r0 + e] = __builtin_amdgcn_exp2f(s0[ej][r0 + e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ps[0][e] = attn_vadd(ps[0][e], s0[ej][r0 + e]);
-                pf0[ej][(i & 3) >> 1].u[2 * (i & 1) + 0] = pack_bf16x2(s0[ej][r0 + 0], s0[ej][r0 + 1]);
-                pf0[ej][(i & 3) >> 1].u[2 * (i & 1) + 1] = pack_bf16x2(s0[ej][r0 + 2], s0[ej][r0 + 3]);
-                if (i >= 4) {                                 // V^T fragments in the order P V consumes them
-                    const int j0 = 2 * (i - 4), vjb = j0 >> 2, vt2 = (j0 >> 1) & 1;
-                    vf[0][vjb][vt2] = *reinterpret_cast<const bf16x8*>(sV + 0 * 4096 + voff2[vjb][vt2]);
-                    vf[1][vjb][vt2] = *reinterpret_cast<const bf16x8*>(sV + 1 * 4096 + voff2[vjb][vt2]);
-                }
-                ATTN_SB();
-            }
-            ATTN_STAMP(3);                                  // [3] = (mask) + phase 3
-            if (masked) add_mask(s1);
-            ATTN_SB();
-            // ---- phase 4: P V of block 0 | exponentials, row sums, packing of block 1 ----
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
-                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf0[jb][t2].v, o[0][db], 0, 0, 0);
-                const int ej = j >> 2, r0 = 4 * (j & 3);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s1[ej][r0 + e] = __builtin_amdgcn_exp2f(s1[ej][r0 + e]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ps[1][e] = attn_vadd(ps[1][e], s1[ej][r0 + e]);
-                pf1[ej][(j & 3) >> 1].u[2 * (j & 1) + 0] = pack_bf16x2(s1[ej][r0 + 0], s1[ej][r0 + 1]);
-                pf1[ej][(j & 3) >> 1].u[2 * (j & 1) + 1] = pack_bf16x2(s1[ej][r0 + 2], s1[ej][r0 + 3]);
-                ATTN_SB();
-            }
-            ATTN_STAMP(4);                                  // [4] = (mask) + phase 4
-            // ---- phase 5: P V of block 1 | the next round's DMA issue (two bodies behind one wave-uniform branch) ----
+            // ---- phase 1: scores of block 0 | softmax of block 1, previous tile, keys 32..63 | this tile's DMA round ----
             if (do_issue) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
-                    o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf1[jb][t2].v, o[1][db], 0, 0, 0);
-                    if (j == 1) issue1(tn, STN, AttnIC<0>{});
-                    if (j == 2) issue1(tn, STN, AttnIC<1>{});
-                    if (j == 3) issue1(tn, STN, AttnIC<2>{});
-                    if (j == 4) issue1(tn, STN, AttnIC<3>{});
-                    if (j == 5) issue1(tn, STN, AttnIC<4>{});
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = i >> 1, jb = i & 1;
+                    ATTN_LGKM(8 - i);                         // K fragment i of 8 (+ the key_add word behind them)
+                    s0[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[0][kk], kk == 0 ? zero16 : s0[jb], 0, 0, 0);
+                    ATTN_SM_SLICE(s1c, ps[1], pf1b, i);
+                    if (i == 1) issue1(tn, STN, AttnIC<0>{});
+                    if (i == 2) issue1(tn, STN, AttnIC<1>{});
+                    if (i == 3) issue1(tn, STN, AttnIC<2>{});
+                    if (i == 4) issue1(tn, STN, AttnIC<3>{});
+                    if (i == 5) issue1(tn, STN, AttnIC<4>{});
                     ATTN_SB();
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
-                    o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf1[jb][t2].v, o[1][db], 0, 0, 0);
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = i >> 1, jb = i & 1;
+                    ATTN_LGKM(8 - i);                         // K fragment i of 8 (+ the key_add word behind them)
+                    s0[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[0][kk], kk == 0 ? zero16 : s0[jb], 0, 0, 0);
+                    ATTN_SM_SLICE(s1c, ps[1], pf1b, i);
+                    ATTN_SB();
                 }
             }
-            ATTN_STAMP(5);                                  // [5] = phase 5
+            ATTN_LGKM(0);
+            ka = (k0 + lane < N) ? ka * ATTN_LOG2E : -INFINITY;                     // log2 domain; keys beyond N never count
+            const bool masked = __any(ka != 0.f);
+            ATTN_STAMP(2);                                  // [2] = K fragment reads + phase 1
+            if (masked) add_mask(s0);                         // wave-uniform
+            ATTN_SB();
+            // ---- phase 2: scores of block 1 | softmax of block 0, keys 0..31 | V^T fragments of the previous tile ----
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = i >> 1, jb = i & 1;
+                s1[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[1][kk], kk == 0 ? zero16 : s1[jb], 0, 0, 0);
+                ATTN_SM_SLICE(s0[0], ps[0], pf0[0], i);
+                if (i >= 4) {                                 // in the order P V consumes them (behind the K fragments that die here)
+                    const int vjb = (i - 4) >> 1, vt2 = (i - 4) & 1;
+                    const uint32_t av = aVp + voff2[vjb][vt2];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(vfp[0][vjb][vt2]) : "v"(av) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(vfp[1][vjb][vt2]) : "v"(av) : "memory");
+                }
+                ATTN_SB();
+            }
+            ATTN_STAMP(3);                                  // [3] = (mask) + phase 2
+            if (masked) add_mask(s1);
+            ATTN_SB();
+            // ---- phase 3: P V of block 1, previous tile | softmax of block 0, keys 32..63 | V^T fragments of this tile ----
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                if (j == 0) ATTN_LGKM(6);                     // the previous tile's V^T fragments, pair by pair (in-order returns); from
+                if (j == 2) ATTN_LGKM(4);                     // group 4 on this tile's fragment reads queue up behind them
+                if (j == 4) ATTN_LGKM(2);
+                if (j == 6) ATTN_LGKM(4);
+                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfp[db][jb][t2], jb == 0 ? pf1a[t2].v : pf1b[t2].v, o[1][db], 0, 0, 0);
+                ATTN_SM_SLICE(s0[1], ps[0], pf0[1], j);
+                if (j >= 4) {
+                    const int vjb = (j - 4) >> 1, vt2 = (j - 4) & 1;
+                    const uint32_t av = aV + voff2[vjb][vt2];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0][vjb][vt2]) : "v"(av) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(vf[1][vjb][vt2]) : "v"(av) : "memory");
+                }
+                ATTN_SB();
+            }
+            ATTN_STAMP(4);                                  // [4] = (mask) + phase 3
+            ATTN_SB();
+            // ---- phase 4: P V of block 0 | softmax of block 1, keys 0..31 ----
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                if (j == 0) ATTN_LGKM(6);                     // this tile's V^T fragments
+                if (j == 2) ATTN_LGKM(4);
+                if (j == 4) ATTN_LGKM(2);
+                if (j == 6) ATTN_LGKM(0);
+                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf0[jb][t2].v, o[0][db], 0, 0, 0);
+                ATTN_SM_SLICE(s1[0], ps[1], pf1a, j);
+                ATTN_SB();
+            }
+            s1c = s1[1];
+            ATTN_STAMP(5);                                  // [5] = phase 4
 #ifdef ATTN_TRACE
             ++tr_tile;
 #endif
         };
 
+        // q has landed, and hipcc KNOWS it (the builtin, not inline asm): otherwise every MFMA that reads a q fragment inside the loop
+        // gets a compiler-inserted s_waitcnt vmcnt(0), which drains the DMA ring once per phase
+        __builtin_amdgcn_s_waitcnt(0);
         ATTN_STAMP(6);                                      // [6] = prologue (q loads, addresses)
         issue(0, 0);
         if (1 < nt) issue(1, 1);
-        if (NS == 4 && 2 < nt) issue(2, 2);
-        // NOT unrolled by the ring depth: three copies of the tile (34 KB of code) cost ~600 cycles per tile at the jump into the
-        // next copy (instruction fetch); the stage is a run-time LDS offset instead (a handful of address adds per tile)
-        int stage = 0;
-#ifdef ATTN_TRACE_CAL
-        for (int t = 0; t < nt; t += 2) {                   // calibration: the second tile of a pair is reached without a taken branch
-            tile(t, stage);
-            stage = stage + 1 == NS ? 0 : stage + 1;
-            if (t + 1 < nt) {
-                tr_slot0 = 6;
-                tile(t + 1, stage);
-                tr_slot0 = 0;
-                stage = stage + 1 == NS ? 0 : stage + 1;
-            }
-        }
-#else
-        for (int t = 0; t < nt; ++t) {
-            tile(t, stage);
-            stage = stage + 1 == NS ? 0 : stage + 1;
-        }
-#endif
+        for (int t = 0; t < nt; ++t) tile(t, t & 3);
+        // drain: block 1 of the last tile
+        if (active) {
+            PF pf1b[2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) l_run[x] = (ps[x][0] + ps[x][1]) + (ps[x][2] + ps[x][3]);
+            for (int i = 0; i < 8; ++i) ATTN_SM_SLICE(s1c, ps[1], pf1b, i);
+            const char* sVp = smem + ((nt - 1) & 3) * STAGE + 8192;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 vfr = *reinterpret_cast<const bf16x8*>(sVp + db * 4096 + voff2[jb][t2]);
+                        o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, jb == 0 ? pf1a[t2].v : pf1b[t2].v, o[1][db], 0, 0, 0);
+                    }
+        }
+#undef ATTN_SM_SLICE
+#undef ATTN_LGKM
+#pragma unroll
+        for (int x = 0; x < 2; ++x) l_run[x] = ps[x][0] + ps[x][1];
     }
 
     // one check per item: did exp2 overflow, or flush a whole row?  Workgroup-wide decision (pass 2 needs every wave for its DMA
@@ -1124,7 +1175,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         for (int i = 0; i < 8; ++i) g_attn_trace[i] = tr_acc[i];
         g_attn_trace[8] = tr_last - tr_start;
         g_attn_trace[9] = (unsigned long long)nt;
-        for (int i = 0; i < 8 * 32; ++i) g_attn_trace[16 + i] = reinterpret_cast<unsigned int*>(smem + 160 * 1024 - 1024)[i];
+        for (int i = 0; i < 8 * 32; ++i) g_attn_trace[16 + i] = reinterpret_cast<unsigned int*>(smem + ATTN_TRACE_OFF)[i];
     }
 #endif
 }
@@ -1132,7 +1183,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 template <int NS>
 static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
 #ifdef ATTN_TRACE
-    constexpr size_t lds = 160 * 1024;
+    constexpr size_t lds = (size_t)ATTN_TRACE_OFF + 1024;
 #else
     constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256 + 16;
 #endif
@@ -1254,8 +1305,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 7: return launch_attn_cfg<2, 4, 2>(p, s);     // 64 queries x 4 key quarters (8 waves, 133 KB of LDS)
         case 8: return launch_attn_stream<3>(p, s);        // batched: 128 queries per workgroup, speculative tiles
         case 9: return launch_attn_stream<2>(p, s);
-        case 10: return launch_attn_w64<3>(p, s);          // 64 queries per wave, one wave per SIMD
-        case 11: return launch_attn_w64<4>(p, s);
+        case 10: return launch_attn_w64<4>(p, s);          // 64 queries per wave, two workgroups per CU
     }
     return hipErrorInvalidValue;
 }
