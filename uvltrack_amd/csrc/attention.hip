@@ -703,7 +703,7 @@ __device__ __forceinline__ int attn_opaque_lane() {
 #ifdef ATTN_TRACE
 // development build only (tools/attn_trace.py): shader-clock stamps of wave 0 of workgroup 0, summed per phase over the tiles
 __device__ unsigned long long g_attn_trace[16 + 8 * 32];
-#define ATTN_TRACE_OFF (4 * 16384 + 16384)       // behind the kernel's own LDS (two workgroups per CU still fit)
+#define ATTN_TRACE_OFF (4 * 16384 + 4 * 4 * 256 + 16)       // behind the kernel's own LDS (two workgroups per CU still fit)
 #define ATTN_STAMP(i) do { ATTN_SB(); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                            tr_acc[i] += now_ - tr_last; \
                            if (blockIdx.x == 0 && threadIdx.x == 0 && tr_tile < 32) reinterpret_cast<unsigned int*>(smem + ATTN_TRACE_OFF)[tr_tile * 8 + (i)] = (unsigned int)(now_ - tr_last); \
@@ -715,9 +715,9 @@ __device__ unsigned long long g_attn_trace[16 + 8 * 32];
 template <int NS>
 __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
-    constexpr int QPARK = NS * STAGE;                     // [4 waves][4 k steps][64 lanes] x 16 B: the q fragments of block 0, parked (the
-                                                          // register file holds 2 x 256 per SIMD; ring + park = 80 KB: two workgroups per CU)
-    constexpr int VM = 4;                                 // VMEM operations per wave and round: 2 K + 2 V^T pieces
+    constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
+    constexpr int FLAG0 = KADD0 + NS * 4 * 256;           // 4 x int: "this wave wants the exact pass"
+    constexpr int VM = 5;                                 // VMEM operations per wave and tile: 2 K + 2 V^T pieces + the key_add row
     static_assert(NS == 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 #ifdef ATTN_TRACE
     unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
     const unsigned long long tr_start = tr_last;
-    int tr_tile = 0;
+    int tr_slot0 = 0, tr_tile = 0;
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -736,11 +736,11 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     const bf16_t* __restrict__ Q = p.q + bh * Npad * 64;
     const char* Kb = reinterpret_cast<const char*>(p.k + bh * Npad * 64);
     const char* Vb = reinterpret_cast<const char*>(p.vt + bh * 64 * Npad);
-    const float* __restrict__ kadd = p.key_add + (size_t)b * p.key_add_stride;
+    const char* Ab = reinterpret_cast<const char*>(p.key_add + (size_t)b * p.key_add_stride);
     const int nt = (N + 63) >> 6;
     const int q0 = (qb * 4 + wave) * 64;
     const bool active = q0 < N;                           // wave-uniform
-
+    bf16x8 qf[2][4];
     uint32_t voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -756,15 +756,17 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     };
 #define ATTN_GLDS(src, dst, bytes) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                                                     (__attribute__((address_space(3))) void*)(dst), bytes, 0, 0)
-    // one of the four DMA instructions of a round (i = 0, 1: K pieces, 2, 3: V^T pieces)
-    auto issue1 = [&](int t, int stage, auto ic) __attribute__((always_inline)) {
+    // one of the five DMA instructions of a round (i = 0, 1: K pieces, 2, 3: V^T pieces, 4: this wave's key_add row)
+    auto issue1 = [&](int t, int stage, auto ic) __attribute__((always_inline)) {      // stage: a constant wherever the ring is live
         constexpr int I = decltype(ic)::value;
-        char* st = smem + stage * STAGE;
+        const int ST = stage;
+        char* st = smem + ST * STAGE;
         if (I < 2) ATTN_GLDS(pin(Kb + (size_t)t * 8192) + voff[I], st + (wave + 4 * I) * 1024, 16);
-        else ATTN_GLDS(pin(Vb + (size_t)t * 128) + voff[I], st + 8192 + (wave + 4 * (I - 2)) * 1024, 16);
+        else if (I < 4) ATTN_GLDS(pin(Vb + (size_t)t * 128) + voff[I], st + 8192 + (wave + 4 * (I - 2)) * 1024, 16);
+        else ATTN_GLDS(pin(Ab + (size_t)t * 256) + lane * 4, smem + KADD0 + (ST * 4 + wave) * 256, 4);
     };
-    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
-        issue1(t, stage, AttnIC<0>{}); issue1(t, stage, AttnIC<1>{}); issue1(t, stage, AttnIC<2>{}); issue1(t, stage, AttnIC<3>{});
+    auto issue = [&](int t, int stc) __attribute__((always_inline)) {
+        issue1(t, stc, AttnIC<0>{}); issue1(t, stc, AttnIC<1>{}); issue1(t, stc, AttnIC<2>{}); issue1(t, stc, AttnIC<3>{}); issue1(t, stc, AttnIC<4>{});
     };
     // tail tile: zero K rows / V^T columns beyond N in LDS (own pieces, after the own DMA wait, before the barrier)
     auto tail_fix = [&](char* sK, int k0) __attribute__((always_inline)) {
@@ -794,49 +796,6 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         }
     };
 
-    // ---- prologue: the first two rounds go out before anything else; q and the mask summary share their flight ----
-    issue(0, 0);
-    if (1 < nt) issue(1, 1);
-    bf16x8 qf[2][4];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const int qrow = q0 + 32 * x + (lane & 31);
-        const int qld = qrow < N ? qrow : N - 1;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[x][kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
-    }
-    // which key tiles carry a mask term (key_add != 0 on a key < N), as a bit per tile: one pass over the key_add row per item
-    // instead of a staged copy, a DMA and a vote per tile.  Four keys per lane and load: load j covers tiles 4j .. 4j+3 (16 lanes
-    // each).  Tiles from 16 on (N > 1024) are simply treated as masked.
-    uint32_t maskbits = 0;
-    {
-        bool nz[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int key = 256 * j + 4 * lane;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (key < N) a4 = *reinterpret_cast<const float4*>(kadd + key);     // key + 3 < Npad: Npad is a multiple of 64
-            nz[j] = (key < N && a4.x != 0.f) || (key + 1 < N && a4.y != 0.f) || (key + 2 < N && a4.z != 0.f) || (key + 3 < N && a4.w != 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned long long bal = __ballot(nz[j]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if ((bal >> (16 * i)) & 0xffffull) maskbits |= 1u << (4 * j + i);
-        }
-        if (N & 63) maskbits |= 1u << ((nt - 1) & 31);      // the tail tile: keys beyond N must not count
-        if (nt > 16) maskbits |= 0xffff0000u;
-    }
-    if (!p.q_prescaled) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[x][kk][e] = f2bf(bf2f(qf[x][kk][e]) * (0.125f * ATTN_LOG2E));
-    }
-
     const int m31 = lane & 31;
     const int kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1);
     int koff[4], voff2[2][2];
@@ -854,41 +813,18 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[x][0][r] = 0.f; o[x][1][r] = 0.f; }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // the mask term of tile t for one query block (log2 domain, -inf beyond N), added in the score registers' key order.  Rare
-    // path: ordinary loads (hipcc drains the DMA ring around them)
-    auto add_mask = [&](f32x16 (&sx)[2], int k0) __attribute__((always_inline)) {
-        const int half = attn_opaque_lane() >> 5;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {                  // registers 4gq..4gq+3 = keys 16(gq>>1) + 8 half + 4(gq&1) + 0..3
-                const int kq = k0 + 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
-                const float4 a4 = *reinterpret_cast<const float4*>(kadd + kq);
-                const float a[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sx[jb][4 * gq + e] += (kq + e < N) ? a[e] * ATTN_LOG2E : -INFINITY;
-            }
-    };
 
     // =============================== pass 1: p = exp2(s), no maximum ===============================
-    // Software pipeline across tiles: 32 groups of ONE MFMA and its fillers per tile, in four phases of 8 (the group list with its
-    // reads and counted waits is GENERATED: tools/gen/attn_w64_tile.py -> attn_w64_tile.inc):
-    //   phase 1: scores of block 0, tile t      | softmax of block 1, tile t-1, keys 32..63   + the DMA round of tile t+2
-    //   phase 2: scores of block 1, tile t      | softmax of block 0, tile t, keys 0..31
-    //   phase 3: P V of block 1, tile t-1       | softmax of block 0, tile t, keys 32..63
-    //   ---- the tile's ONE barrier: every wave's pieces of round t+1 have landed ----
+    // Software pipeline across tiles, four phases of 8 MFMAs, each beside ONE half of a block's softmax (16 exponentials, 16 row-sum
+    // adds, 8 packs: five single-issue fillers per MFMA, the guide's budget for one wave):
+    //   phase 1: scores of block 0, tile t      | softmax of block 1, tile t-1, keys 32..63   + this tile's DMA round (t + 2)
+    //   phase 2: scores of block 1, tile t      | softmax of block 0, tile t, keys 0..31      + V^T fragments of tile t-1
+    //   phase 3: P V of block 1, tile t-1       | softmax of block 0, tile t, keys 32..63     + V^T fragments of tile t
     //   phase 4: P V of block 0, tile t         | softmax of block 1, tile t, keys 0..31
-    // Block 1 trails block 0 by half a tile, so every MFMA has the same five fillers beside it (two exponentials, two row-sum adds,
-    // one pack: the guide's budget for one wave) and no phase is MFMA-only or VALU-only.  Every MFMA's A operand (K / V^T fragment)
-    // streams from LDS through a ring of eight 16-byte register buffers, one ds_read_b128 per group, four groups ahead of its use --
-    // across phase boundaries, the barrier and the tile boundary (the next tile's first K fragments are requested behind the
-    // barrier) -- so fragments cost ~20 registers instead of 96 and no LDS latency is exposed.  The q fragments of block 0 live in an
-    // LDS park and come through a ring of three buffers.  Tile t-1's V^T stage is read in tile t and tile t+1's K stage in phase 4:
-    // the ring has four stages (t-1, t, t+1 and round t+2 in flight).  The ring stage is a RUN-TIME LDS offset (one copy of the
-    // tile).  hipcc cannot tell a run-time-staged ds_read from the round in flight and would drain the ring (s_waitcnt vmcnt(0)) in
-    // front of every fragment read, so the steady-state LDS reads are inline asm with counted lgkmcnt waits (LDS returns are in
-    // order; the generator simulates the issue order to get the counts); only the rare paths use ordinary memory accesses.
+    // Block 1 trails block 0 by half a tile, so no phase is MFMA-only or VALU-only.  Tile t-1's V^T stage is read in tile t: the
+    // ring has four stages (t-1, t, and rounds t+1, t+2 in flight) and round t+2 is issued behind tile t's barrier.
     {
+        static_assert(NS == 4, "the pipelined pass needs four stages");
         float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         union PF { uint32_t u[4]; bf16x8 v; };
         f32x16 s1c;                                         // scores of block 1, keys 32..63 of the previous tile (not yet exponentiated)
@@ -899,75 +835,183 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) pf1a[t2].u[e] = 0u;
+
+        // The ring stage is a RUN-TIME LDS offset (one copy of the tile: 15 KB of code; unrolled by the ring depth it is 59 KB and
+        // spills).  hipcc cannot tell a run-time-staged ds_read from the round in flight and would drain the ring (s_waitcnt
+        // vmcnt(0)) in front of every fragment read, so the steady-state LDS reads are inline asm with hand-placed lgkmcnt waits
+        // (the phases are pinned with sched_barrier anyway); only the rare paths (mask term, tail fix-up) use ordinary LDS accesses.
         const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-        const uint32_t aQ = lds0 + QPARK + wave * 4096 + lane * 16;
-        bf16x8 ab[8], qb[3];
-        bf16x8 (&qf1)[4] = qf[1];
-        // the synchronisation point of tile t (before phase 4; t = -1: before the first tile): this wave's pieces of round t+1 have
-        // landed (round t+2 may be in flight), the tail tile's padding is zeroed, and after the barrier every wave's are visible
-        auto sync_round = [&](int t) __attribute__((always_inline)) {
-            if (t + 2 < nt && t >= 0) attn_wait_vmcnt<VM>();
+        auto tile = [&](const int t, const int ST) __attribute__((always_inline)) {
+            const int STN = (ST + 2) & 3;                   // the stage of the round issued in this tile (last read in tile t-1: V^T of t-2)
+            const int STP = t == 0 ? ST : ((ST + 3) & 3);   // the previous tile's stage ("tile -1" reads this tile's V^T against p = 0)
+            char* sK = smem + ST * STAGE;
+            const uint32_t aK = lds0 + ST * STAGE, aV = aK + 8192, aVp = lds0 + STP * STAGE + 8192;
+            float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
+            ATTN_STAMP(0);                                  // [0] = between tiles (loop control)
+            if (t + 1 < nt) attn_wait_vmcnt<VM>();          // round t+1 may stay in flight
             else attn_wait_vmcnt<0>();
-            if (t + 1 == nt - 1 && (N & 63)) {
-                tail_fix(smem + ((t + 1) & 3) * STAGE, (t + 1) * 64);
+            const int k0 = t * 64;
+            if (t == nt - 1 && (N & 63)) {
+                tail_fix(sK, k0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
-        };
-#define ATTN_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); ATTN_SB(); } while (0)
-#define ATTN_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-        // half a block's softmax, slice i of 8: two exponentials, two row-sum adds, one pack (word i & 3 of P fragment i >> 2)
-#define ATTN_SM_SLICE(sblk, psx, pfarr, i)                                                                 \
-        do {                                                                                           \
-            sblk[2 * (i)] = __builtin_amdgcn_exp2f(sblk[2 * (i)]);                                     \
-            sblk[2 * (i) + 1] = __builtin_amdgcn_exp2f(sblk[2 * (i) + 1]);                             \
-            psx[0] = attn_vadd(psx[0], sblk[2 * (i)]);                                                 \
-            psx[1] = attn_vadd(psx[1], sblk[2 * (i) + 1]);                                             \
-            pfarr[(i) >> 2].u[(i) & 3] = pack_bf16x2(sblk[2 * (i)], sblk[2 * (i) + 1]);                \
-        } while (0)
-
-        auto tile = [&](const int t, auto lastc) __attribute__((always_inline)) {
-            constexpr bool LAST = decltype(lastc)::value;
-            const int ST = t & 3;
-            const int STN = (ST + 2) & 3;                   // the stage of the round issued in this tile (last read in tile t-1: V^T of t-2)
-            const int STP = t == 0 ? ST : ((ST + 3) & 3);   // the previous tile's stage ("tile -1" reads this tile's V^T against p = 0)
-            const uint32_t aK = lds0 + ST * STAGE, aKn = lds0 + ((ST + 1) & 3) * STAGE, aV = aK + 8192, aVp = lds0 + STP * STAGE + 8192;
+            ATTN_STAMP(1);                                  // [1] = DMA wait + barrier
             const int tn = t + 2;
             const bool do_issue = tn < nt;
-            const bool masked = t >= 32 || ((maskbits >> t) & 1u);
-            ATTN_STAMP(0);                                  // [0] = between tiles (loop control)
-            if (!active) {                                  // serve the DMA ring and the barrier only
-                if (do_issue) issue(tn, STN);
-                if (!LAST) sync_round(t);
-                return;
+            if (!active) { if (do_issue) issue(tn, STN); return; }
+
+            bf16x8 kf[4][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint32_t ak = aK + koff[kk];
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[kk][0]) : "v"(ak) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kf[kk][1]) : "v"(ak) : "memory");
+            }
+            float ka;                                         // this wave's own copy of the tile's key_add row: its latency rides on the K reads
+            {
+                const uint32_t aa = lds0 + KADD0 + (ST * 4 + wave) * 256 + lane * 4;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(ka) : "v"(aa) : "memory");
             }
             f32x16 s0[2], s1[2];
+            bf16x8 vf[2][2][2], vfp[2][2][2];
             PF pf0[2][2], pf1b[2];
+            // the mask term of this tile (log2 domain, -inf beyond N), added in the score registers' key order; re-read from the
+            // staged row for each block
+            auto add_mask = [&](f32x16 (&sx)[2]) __attribute__((always_inline)) {
+                const int half = attn_opaque_lane() >> 5;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {          // registers 4gq..4gq+3 = keys 16(gq>>1) + 8 half + 4(gq&1) + 0..3
+                        const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
+                        const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sx[jb][4 * gq + e] += (k0 + kq + e < N) ? a[e] * ATTN_LOG2E : -INFINITY;
+                    }
+            };
+            // half a block's softmax, slice i of 8: two exponentials, two row-sum adds, one pack (word i & 3 of P fragment i >> 2)
+#define ATTN_SM_SLICE(sblk, psx, pfarr, i)                                                                 \
+            do {                                                                                           \
+                sblk[2 * (i)] = __builtin_amdgcn_exp2f(sblk[2 * (i)]);                                     \
+                sblk[2 * (i) + 1] = __builtin_amdgcn_exp2f(sblk[2 * (i) + 1]);                             \
+                psx[0] = attn_vadd(psx[0], sblk[2 * (i)]);                                                 \
+                psx[1] = attn_vadd(psx[1], sblk[2 * (i) + 1]);                                             \
+                pfarr[(i) >> 2].u[(i) & 3] = pack_bf16x2(sblk[2 * (i)], sblk[2 * (i) + 1]);                \
+            } while (0)
+#define ATTN_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); ATTN_SB(); } while (0)
             ATTN_SB();
-#include "attn_w64_tile.inc"
+            // ---- phase 1: scores of block 0 | softmax of block 1, previous tile, keys 32..63 | this tile's DMA round ----
+            if (do_issue) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = i >> 1, jb = i & 1;
+                    ATTN_LGKM(8 - i);                         // K fragment i of 8 (+ the key_add word behind them)
+                    s0[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[0][kk], kk == 0 ? zero16 : s0[jb], 0, 0, 0);
+                    ATTN_SM_SLICE(s1c, ps[1], pf1b, i);
+                    if (i == 1) issue1(tn, STN, AttnIC<0>{});
+                    if (i == 2) issue1(tn, STN, AttnIC<1>{});
+                    if (i == 3) issue1(tn, STN, AttnIC<2>{});
+                    if (i == 4) issue1(tn, STN, AttnIC<3>{});
+                    if (i == 5) issue1(tn, STN, AttnIC<4>{});
+                    ATTN_SB();
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = i >> 1, jb = i & 1;
+                    ATTN_LGKM(8 - i);                         // K fragment i of 8 (+ the key_add word behind them)
+                    s0[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[0][kk], kk == 0 ? zero16 : s0[jb], 0, 0, 0);
+                    ATTN_SM_SLICE(s1c, ps[1], pf1b, i);
+                    ATTN_SB();
+                }
+            }
+            ATTN_LGKM(0);
+            ka = (k0 + lane < N) ? ka * ATTN_LOG2E : -INFINITY;                     // log2 domain; keys beyond N never count
+            const bool masked = __any(ka != 0.f);
+            ATTN_STAMP(2);                                  // [2] = K fragment reads + phase 1
+            if (masked) add_mask(s0);                         // wave-uniform
+            ATTN_SB();
+            // ---- phase 2: scores of block 1 | softmax of block 0, keys 0..31 | V^T fragments of the previous tile ----
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = i >> 1, jb = i & 1;
+                s1[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][jb], qf[1][kk], kk == 0 ? zero16 : s1[jb], 0, 0, 0);
+                ATTN_SM_SLICE(s0[0], ps[0], pf0[0], i);
+                if (i >= 4) {                                 // in the order P V consumes them (behind the K fragments that die here)
+                    const int vjb = (i - 4) >> 1, vt2 = (i - 4) & 1;
+                    const uint32_t av = aVp + voff2[vjb][vt2];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(vfp[0][vjb][vt2]) : "v"(av) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(vfp[1][vjb][vt2]) : "v"(av) : "memory");
+                }
+                ATTN_SB();
+            }
+            ATTN_STAMP(3);                                  // [3] = (mask) + phase 2
+            if (masked) add_mask(s1);
+            ATTN_SB();
+            // ---- phase 3: P V of block 1, previous tile | softmax of block 0, keys 32..63 | V^T fragments of this tile ----
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                if (j == 0) ATTN_LGKM(6);                     // the previous tile's V^T fragments, pair by pair (in-order returns); from
+                if (j == 2) ATTN_LGKM(4);                     // group 4 on this tile's fragment reads queue up behind them
+                if (j == 4) ATTN_LGKM(2);
+                if (j == 6) ATTN_LGKM(4);
+                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfp[db][jb][t2], jb == 0 ? pf1a[t2].v : pf1b[t2].v, o[1][db], 0, 0, 0);
+                ATTN_SM_SLICE(s0[1], ps[0], pf0[1], j);
+                if (j >= 4) {
+                    const int vjb = (j - 4) >> 1, vt2 = (j - 4) & 1;
+                    const uint32_t av = aV + voff2[vjb][vt2];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0][vjb][vt2]) : "v"(av) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(vf[1][vjb][vt2]) : "v"(av) : "memory");
+                }
+                ATTN_SB();
+            }
+            ATTN_STAMP(4);                                  // [4] = (mask) + phase 3
+            ATTN_SB();
+            // ---- phase 4: P V of block 0 | softmax of block 1, keys 0..31 ----
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jb = j >> 2, t2 = (j >> 1) & 1, db = j & 1;
+                if (j == 0) ATTN_LGKM(6);                     // this tile's V^T fragments
+                if (j == 2) ATTN_LGKM(4);
+                if (j == 4) ATTN_LGKM(2);
+                if (j == 6) ATTN_LGKM(0);
+                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jb][t2], pf0[jb][t2].v, o[0][db], 0, 0, 0);
+                ATTN_SM_SLICE(s1[0], ps[1], pf1a, j);
+                ATTN_SB();
+            }
             s1c = s1[1];
+            ATTN_STAMP(5);                                  // [5] = phase 4
 #ifdef ATTN_TRACE
             ++tr_tile;
 #endif
         };
 
-        // q, the mask summary and rounds 0 / 1 have landed, and hipcc KNOWS it (the builtin, not inline asm): otherwise every MFMA
-        // that reads a q fragment inside the loop gets a compiler-inserted s_waitcnt vmcnt(0), which drains the DMA ring
+        // the first two rounds go out before anything else; q shares their flight
+        issue(0, 0);
+        if (1 < nt) issue(1, 1);
+    #pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int qrow = q0 + 32 * x + (lane & 31);
+            const int qld = qrow < N ? qrow : N - 1;
+    #pragma unroll
+            for (int kk = 0; kk < 4; ++kk) qf[x][kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
+            if (!p.q_prescaled) {
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[x][kk][e] = f2bf(bf2f(qf[x][kk][e]) * (0.125f * ATTN_LOG2E));
+            }
+        }
+
+
+        // q has landed (and rounds 0 / 1 with it), and hipcc KNOWS it (the builtin, not inline asm): otherwise every MFMA that reads a
+        // q fragment inside the loop gets a compiler-inserted s_waitcnt vmcnt(0), which drains the DMA ring once per phase
         __builtin_amdgcn_s_waitcnt(0);
-        ATTN_STAMP(6);                                      // [6] = prologue
-        {
-            char* park = smem + QPARK + wave * 4096 + lane * 16;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<bf16x8*>(park + kk * 1024) = qf[0][kk];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        sync_round(-1);
-        if (active) {
-            const uint32_t aKn = lds0;
-#include "attn_w64_pre.inc"
-        }
-        for (int t = 0; t + 1 < nt; ++t) tile(t, AttnIC<0>{});
-        tile(nt - 1, AttnIC<1>{});
+        ATTN_STAMP(6);                                      // [6] = prologue (q loads, addresses)
+        for (int t = 0; t < nt; ++t) tile(t, t & 3);
         // drain: block 1 of the last tile
         if (active) {
             PF pf1b[2];
@@ -986,7 +1030,6 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         }
 #undef ATTN_SM_SLICE
 #undef ATTN_LGKM
-#undef ATTN_DSR
 #pragma unroll
         for (int x = 0; x < 2; ++x) l_run[x] = ps[x][0] + ps[x][1];
     }
@@ -1003,7 +1046,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         bad = __any(bad);
     }
     {
-        int* flags = reinterpret_cast<int*>(smem + (nt & 3) * STAGE);   // the K area of a stage nobody reads any more
+        int* flags = reinterpret_cast<int*>(smem + FLAG0);
         if (lane == 0) flags[wave] = bad ? 1 : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1015,11 +1058,6 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     // =============================== pass 2 (rare): online softmax with true row maxima ===============================
     if (bad) {
         __builtin_amdgcn_s_barrier();                       // every wave has read the flags; the ring may be refilled
-        {
-            const char* park = smem + QPARK + wave * 4096 + lane * 16;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) qf[0][kk] = *reinterpret_cast<const bf16x8*>(park + kk * 1024);
-        }
         float m_run[2] = {-INFINITY, -INFINITY};
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
@@ -1030,8 +1068,9 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         auto tile2 = [&](const int t, const int ST) __attribute__((always_inline)) {
             char* sK = smem + ST * STAGE;
             char* sV = sK + 8192;
+            float* sA = reinterpret_cast<float*>(smem + KADD0 + (ST * 4 + wave) * 256);
             if (t + NS - 2 < nt) attn_wait_vmcnt<VM*(NS - 2)>();    // rounds t+1 .. t+NS-2 may stay in flight
-            else if (t + 1 < nt) attn_wait_vmcnt<VM>();
+            else if (NS >= 4 && t + 1 < nt) attn_wait_vmcnt<VM>();
             else attn_wait_vmcnt<0>();
             const int k0 = t * 64;
             if (t == nt - 1 && (N & 63)) tail_fix(sK, k0);
@@ -1046,11 +1085,23 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb) {
-                        const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
-                        s[x][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[x][kk], kk == 0 ? zero16 : s[x][jb], 0, 0, 0);
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + jb * 4096 + koff[kk]);
+                        s[x][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[x][kk], kk == 0 ? zero16 : s[x][jb], 0, 0, 0);
                     }
-            add_mask(s[0], k0);
-            add_mask(s[1], k0);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int kq = 32 * jb + 16 * (gq >> 1) + 8 * half + 4 * (gq & 1);
+                    const float4 a4 = *reinterpret_cast<const float4*>(sA + kq);
+                    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ad = (k0 + kq + e < N) ? a[e] * ATTN_LOG2E : -INFINITY;
+                        s[0][jb][4 * gq + e] += ad;
+                        s[1][jb][4 * gq + e] += ad;
+                    }
+                }
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 float tmax = -INFINITY;
@@ -1090,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         };
         issue(0, 0);
         if (1 < nt) issue(1, 1);
-        if (2 < nt) issue(2, 2);
+        if (NS == 4 && 2 < nt) issue(2, 2);
         for (int t = 0; t < nt; ++t) tile2(t, t % NS);
     }
 #undef ATTN_GLDS
@@ -1136,7 +1187,7 @@ static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
 #ifdef ATTN_TRACE
     constexpr size_t lds = (size_t)ATTN_TRACE_OFF + 1024;
 #else
-    constexpr size_t lds = (size_t)NS * 16384 + 16384;
+    constexpr size_t lds = (size_t)NS * 16384 + (size_t)NS * 4 * 256 + 16;
 #endif
     auto kern = attn_w64_kernel<NS>;
     static bool attr_done = false;
@@ -1213,7 +1264,11 @@ static int pick_attn_cfg(const AttnParams& p) {
         const long wg1 = (long)((p.N + 31) / 32) * p.H * p.B;
         const long wg2 = (long)((p.N + 63) / 64) * p.H * p.B;
         const int nt = (p.N + 63) / 64;
-        if (wg4 >= 256 && nt >= 2) cfg = 8;          // batched: the streaming kernel, 3-stage ring, 3 workgroups per CU
+        const long wg64 = (long)((nt + 3) / 4) * p.H * p.B;     // 256-query workgroups of attn_w64_kernel (two per CU)
+        if (wg64 >= 384 && nt >= 2) cfg = 10;        // 1.5+ workgroups per CU of the 64-queries-per-wave kernel: +6..+29 % over the streaming
+                                                     // kernel on every measured shape from 384 workgroups up (profiles/r02_attention_w64.md),
+                                                     // except 576 workgroups of N = 553 (-4 %: a second round at 75 % wave occupancy)
+        else if (wg4 >= 256 && nt >= 2) cfg = 8;     // batched, fewer workgroups: the streaming kernel, 3-stage ring, 3 workgroups per CU
         else if (nt < 2) cfg = 0;
         else if (wg1 <= 288 && nt >= 5 && nt <= 6) cfg = 5;
         else if (wg1 <= 288 && nt >= 7 && nt <= 9) cfg = 6;
