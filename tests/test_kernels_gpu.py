@@ -134,6 +134,20 @@ def test_attention_token_counts(lib, N):
     _attention_case(lib, 1, 2, N, "fill", 10 + N)
 
 
+@pytest.mark.parametrize("cfg", [8, 10])
+@pytest.mark.parametrize("B,H,N,mode", [(1, 2, 1, "fill"), (1, 2, 33, "fill"), (2, 3, 64, "none"), (2, 3, 65, "bert"), (1, 2, 257, "fill"),
+                                         (3, 2, 321, "bert_all"), (2, 4, 553, "fill"), (1, 2, 1100, "fill")])
+def test_attention_batched_kernels_forced(lib, cfg, B, H, N, mode):
+    """The two kernels of the batched regime -- attn_stream_kernel (cfg 8) and attn_w64_kernel (cfg 10: 64 queries per wave, pass 1
+    without a running maximum, exact pass 2 on demand) -- on shapes the heuristic would not give them: one key tile, ragged tails,
+    waves without queries, every key masked (pass 2 of the w64 kernel), more than 16 key tiles."""
+    lib.uvl_tune_set(b"attn_cfg", cfg)
+    try:
+        _attention_case(lib, B, H, N, mode, 300 + N)
+    finally:
+        lib.uvl_tune_set(b"attn_cfg", -1)
+
+
 @pytest.mark.parametrize("mode", ["none", "fill", "bert", "bert_all"])
 @pytest.mark.parametrize("B,H,N", [(1, 12, 553), (3, 12, 40), (8, 16, 681), (2, 12, 321), (32, 12, 553), (24, 16, 873)])
 def test_attention_modes(lib, B, H, N, mode):
