@@ -160,17 +160,29 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 
 // NTW: the weight tiles are requested non-temporal (aux = 2).  For the text-branch riders of a one-sequence frame (M = 40 rows: every
 // weight byte is read once, by one CU) -- see the note at gemm_glds_pair_kernel.
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false>
+// BK: K extent of a stage, 64 or 32.  At BK = 32 a 128x128 stage is 16 KB, so four or five stages fit twice per CU: three or four
+// K tiles in flight per workgroup instead of one.  With two stages a K step costs a whole DMA round trip (~1.1 us issue -> landed)
+// plus its MFMAs, which is where the 31-33 % MFMA utilisation of the batched frame's GEMMs comes from.
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk, const int g, char* smem) {
-    constexpr int BK = 64;
+    static_assert(BK == 64 || (BK == 32 && !CONV), "K extent of a stage");
+    constexpr int RB = BK * 2;                       // bytes of a stage row
+    constexpr int LPR_ = RB / 16;                    // lanes (16-byte chunks) per row
+    constexpr int RPD = 1024 / RB;                   // rows per DMA instruction (1 KB)
+    constexpr int KS = BK / 16;                      // MFMA k steps per stage
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int ROWS = BM + BN;                    // stage = A rows then W rows, 128 B each
-    constexpr int STAGE = ROWS * 128;
+    constexpr int ROWS = BM + BN;                    // stage = A rows then W rows, RB bytes each
+    constexpr int STAGE = ROWS * RB;
     constexpr int NW = WGM * WGN;                    // waves per workgroup: 4 (tiles up to 128x128) or 8 (256-wide tiles)
-    constexpr int LPT = ROWS / (8 * NW);             // DMA instructions per wave per tile (each fills 8 rows)
-    constexpr int LPT_A = BM / (8 * NW);             // the first LPT_A instructions of a wave fill A rows, the rest W rows
-    static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && LPT * (NS - 2) <= 63, "geometry");
+    constexpr int LPT = ROWS / (RPD * NW);           // DMA instructions per wave per tile (each fills RPD rows)
+    constexpr int LPT_A = BM / (RPD * NW);           // the first LPT_A instructions of a wave fill A rows, the rest W rows
+    static_assert((NW == 4 || NW == 8) && BM % (RPD * NW) == 0 && BN % (RPD * NW) == 0 && LPT * (NS - 2) <= 63, "geometry");
+    // XOR swizzle of the 16-byte chunk index by row: 128-byte rows (row >> 1) & 7 (swz128), 64-byte rows (row >> 2) & 3 -- the 16
+    // lanes of a ds_read_b128 service group then hit 16 distinct 16-byte slots of the 256-byte bank row either way
+    auto swz = [](int row, int chunk) __attribute__((always_inline)) {
+        return BK == 64 ? swz128(row, chunk) : row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+    };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: LDS-DMA destinations (M0) stay scalar
@@ -213,8 +225,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     const char* w_base = reinterpret_cast<const char*>(p.W + ((size_t)g * p.N + n0) * p.ldw + kbase);
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        const int r = 8 * (wave + NW * i) + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);        // logical 16-byte chunk that belongs at this physical slot
+        const int r = RPD * (wave + NW * i) + lane / LPR_;
+        const int chunk = BK == 64 ? ((lane & 7) ^ ((r >> 1) & 7)) : ((lane & 3) ^ ((r >> 2) & 3));   // logical 16-byte chunk that belongs at this physical slot
         if (i < LPT_A) {
             int gm = m0 + r;
             gm = gm < p.M ? gm : p.M - 1;
@@ -296,22 +308,24 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight
         const int ahead = nk - 1 - kt;
         if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
+        else if (NS > 5 && ahead == 3) wait_vmcnt<LPT * 3>();
+        else if (NS > 4 && ahead == 2) wait_vmcnt<LPT * 2>();
         else if (NS > 3 && ahead == 1) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + NS - 1 < nk) issue(kt + NS - 1);            // its stage was last read in iteration kt-1
         const char* sA = smem + (kt % NS) * STAGE;
-        const char* sB = sA + BM * 128;
+        const char* sB = sA + BM * RB;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8 af[TM], bfr[TN];
             const int chunk = ks * 2 + (lane >> 5);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(sA + swz128(wm * WM + i * 32 + (lane & 31), chunk));
+                af[i] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * WM + i * 32 + (lane & 31), chunk));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sB + swz128(wn * WN + j * 32 + (lane & 31), chunk));
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * WN + j * 32 + (lane & 31), chunk));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -323,10 +337,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
+    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
 }
 
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false, int BK = 64>
 static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
@@ -361,8 +375,8 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     p.group_m = MT >= 16 ? 8 : MT;
     if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
     const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
-    const size_t lds = (size_t)NS * (BM + BN) * 128;
-    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW>;
+    const size_t lds = (size_t)NS * (BM + BN) * (BK * 2);
+    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -370,7 +384,7 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
+    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : BK == 64 ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,32>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
@@ -379,6 +393,7 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
 // tuning override for tools/gemm_bench.py: -1 = heuristic, otherwise index into the config table below
 int g_tune_gemm_cfg = -1;
 int g_tune_gemm_gm = -1;
+int g_tune_gemm_big = 1;        // tools: 0 = never pick the 256x256 tile (A/B of the heuristic)
 
 template <int EPI>
 static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) {
@@ -408,6 +423,11 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 13: return launch_glds<256, 128, 4, 2, EPI, 3>(p, s);
         case 14: return launch_glds<128, 256, 2, 4, EPI, 3>(p, s);
         case 15: return launch_glds<256, 128, 4, 2, EPI, 2>(p, s);
+        // 32-wide K stages: 16 KB per 128x128 stage, so a deeper ring fits two or three times per CU
+        case 16: return launch_glds<128, 128, 2, 2, EPI, 4, false, false, 32>(p, s);     // 64 KB: 2 workgroups per CU, 3 K tiles in flight each
+        case 17: return launch_glds<128, 128, 2, 2, EPI, 5, false, false, 32>(p, s);     // 80 KB: 2 per CU, 4 in flight
+        case 18: return launch_glds<128, 128, 2, 2, EPI, 3, false, false, 32>(p, s);     // 48 KB: 3 per CU, 2 in flight
+        case 19: return launch_glds<128, 128, 2, 2, EPI, 6, false, false, 32>(p, s);     // 96 KB: 1 per CU, 5 in flight
     }
     return hipErrorInvalidValue;
 }
@@ -426,6 +446,15 @@ static int pick_plain_cfg(const GemmParams& p) {
     }
     if (t64 < 768) return 4;
     if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
+    if (g_tune_gemm_big && p.N % 256 == 0 && p.K >= 1024 && p.splitk <= 1) {
+        // 256x256 tiles, 8 waves, one workgroup per CU: half the LDS-DMA instructions per MFMA of the 128x128 tile (an LDS-DMA
+        // instruction costs its wave ~55 cycles of issue).  Pays where the K loop is long enough to amortise the tile's prologue /
+        // epilogue and the tiles fill whole rounds of the 256 CUs: +20 % on fc1 at M = 6984, K = 1024 (448 tiles), +18 % on fc2 at
+        // M = 17696, K = 3072 (210 tiles); level or worse elsewhere (tools/gemm_ring_ab.py)
+        const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
+        const long rounds = (t256 + 255) / 256;
+        if (t256 * 10 >= rounds * 256 * 8) return 11;
+    }
     return n128 ? 6 : 9;                            // 128x128, 2 stages
 }
 
@@ -435,7 +464,8 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
         return launch_glds<128, 32, 4, 1, EPI, 3>(p, s);
     }
     int cfg = pick_plain_cfg(p);
-    if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15) && p.N % 128 != 0) cfg = 0;
+    if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 19)) && p.N % 128 != 0) cfg = 0;
+    if (cfg >= 16 && cfg <= 19 && p.splitk > 1) cfg = 6;
     if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
