@@ -134,6 +134,29 @@ def test_attention_token_counts(lib, N):
     _attention_case(lib, 1, 2, N, "fill", 10 + N)
 
 
+@pytest.mark.parametrize("cfg", [6, 11, 16, 17, 20, 21])
+@pytest.mark.parametrize("M,N,K,act", [(777, 512, 192, 0), (300, 256, 64, 1), (6200, 3072, 768, 1)])
+def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
+    """The tile / ring / wave-role forms of the batched GEMM on shapes the heuristic would not give them: 128x128 and 256x256 tiles,
+    32-wide K stages with 4 / 5 ring stages (cfg 16 / 17) and the producer-wave form (cfg 20 / 21: 2 / 4 extra waves issue every
+    LDS-DMA instruction, the four consumer waves only read fragments and issue MFMAs) -- ragged M, one K step, a long K loop."""
+    x = _rand((M, K), 1).bfloat16()
+    w = (_rand((N, K), 2, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
+    b = _rand((N,), 3, 0.5)
+    ref = x.float() @ w.float().t() + b
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lib.uvl_tune_set(b"gemm_cfg", cfg)
+    try:
+        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, _stream()), lib)
+        torch.cuda.synchronize()
+    finally:
+        lib.uvl_tune_set(b"gemm_cfg", -1)
+    err = (y.float() - ref).abs()
+    assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "cfg %d max err %g" % (cfg, float(err.max()))
+
+
 @pytest.mark.parametrize("cfg", [8, 10])
 @pytest.mark.parametrize("B,H,N,mode", [(1, 2, 1, "fill"), (1, 2, 33, "fill"), (2, 3, 64, "none"), (2, 3, 65, "bert"), (1, 2, 257, "fill"),
                                          (3, 2, 321, "bert_all"), (2, 4, 553, "fill"), (1, 2, 1100, "fill")])

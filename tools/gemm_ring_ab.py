@@ -13,7 +13,10 @@ from uvltrack_amd import _native  # noqa: E402
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-CFGS = {6: "128x128 k64 ns2", 18: "128x128 k32 ns3", 16: "128x128 k32 ns4", 17: "128x128 k32 ns5", 19: "128x128 k32 ns6", 11: "256x256 k64 ns2"}
+CFGS = {6: "128x128 k64 ns2", 20: "128x128 ns2 +2 producers", 21: "128x128 ns2 +4 producers", 18: "128x128 k32 ns3", 16: "128x128 k32 ns4", 17: "128x128 k32 ns5", 19: "128x128 k32 ns6", 11: "256x256 k64 ns2"}
+if "--short" in sys.argv:
+    sys.argv.remove("--short")
+    CFGS = {k: CFGS[k] for k in (6, 20, 21, 11)}
 
 
 def timeit(fn, iters=30):

@@ -163,9 +163,13 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 // BK: K extent of a stage, 64 or 32.  At BK = 32 a 128x128 stage is 16 KB, so four or five stages fit twice per CU: three or four
 // K tiles in flight per workgroup instead of one.  With two stages a K step costs a whole DMA round trip (~1.1 us issue -> landed)
 // plus its MFMAs, which is where the 31-33 % MFMA utilisation of the batched frame's GEMMs comes from.
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64>
+// PROD: 0 = every wave stages its share of a tile and computes; 2 / 4 = that many extra PRODUCER waves issue all LDS-DMA instructions (and
+// wait for them) while the WGM x WGN consumer waves only read fragments and issue MFMAs -- an LDS-DMA instruction costs the wave that
+// issues it ~55 cycles, half of what a consumer of the 128x128 tile issues per K step (profiles/r02_gemm_structure.md, probe 5).
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk, const int g, char* smem) {
     static_assert(BK == 64 || (BK == 32 && !CONV), "K extent of a stage");
+    static_assert(PROD == 0 || (!CONV && !NTW), "producer waves: plain GEMMs only");
     constexpr int RB = BK * 2;                       // bytes of a stage row
     constexpr int LPR_ = RB / 16;                    // lanes (16-byte chunks) per row
     constexpr int RPD = 1024 / RB;                   // rows per DMA instruction (1 KB)
@@ -174,10 +178,11 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int ROWS = BM + BN;                    // stage = A rows then W rows, RB bytes each
     constexpr int STAGE = ROWS * RB;
-    constexpr int NW = WGM * WGN;                    // waves per workgroup: 4 (tiles up to 128x128) or 8 (256-wide tiles)
-    constexpr int LPT = ROWS / (RPD * NW);           // DMA instructions per wave per tile (each fills RPD rows)
-    constexpr int LPT_A = BM / (RPD * NW);           // the first LPT_A instructions of a wave fill A rows, the rest W rows
-    static_assert((NW == 4 || NW == 8) && BM % (RPD * NW) == 0 && BN % (RPD * NW) == 0 && LPT * (NS - 2) <= 63, "geometry");
+    constexpr int NW = WGM * WGN;                    // (consumer) waves per workgroup: 4 (tiles up to 128x128) or 8 (256-wide tiles)
+    constexpr int NL = PROD ? PROD : NW;             // waves that issue LDS-DMA
+    constexpr int LPT = ROWS / (RPD * NL);           // DMA instructions per loading wave per tile (each fills RPD rows)
+    constexpr int LPT_A = BM / (RPD * NL);           // the first LPT_A instructions of a wave fill A rows, the rest W rows
+    static_assert((NW == 4 || NW == 8) && BM % (RPD * NL) == 0 && BN % (RPD * NL) == 0 && LPT * (NS - 2) <= 63, "geometry");
     // XOR swizzle of the 16-byte chunk index by row: 128-byte rows (row >> 1) & 7 (swz128), 64-byte rows (row >> 2) & 3 -- the 16
     // lanes of a ds_read_b128 service group then hit 16 distinct 16-byte slots of the 256-byte bank row either way
     auto swz = [](int row, int chunk) __attribute__((always_inline)) {
@@ -185,7 +190,9 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     };
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: LDS-DMA destinations (M0) stay scalar
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: LDS-DMA destinations (M0) stay scalar
+    const bool producer = PROD && wave_all >= NW;
+    const int wave = PROD ? (producer ? wave_all - NW : wave_all) : wave_all;     // index among the loading waves / among the consumers
     const int wm = wave / WGN, wn = wave % WGN;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
     // Workgroup b runs on XCD b % 8 (dispatch order; affects speed only), and every XCD has its own L2.
@@ -225,7 +232,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     const char* w_base = reinterpret_cast<const char*>(p.W + ((size_t)g * p.N + n0) * p.ldw + kbase);
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        const int r = RPD * (wave + NW * i) + lane / LPR_;
+        const int r = RPD * (wave + NL * i) + lane / LPR_;
         const int chunk = BK == 64 ? ((lane & 7) ^ ((r >> 1) & 7)) : ((lane & 3) ^ ((r >> 2) & 3));   // logical 16-byte chunk that belongs at this physical slot
         if (i < LPT_A) {
             int gm = m0 + r;
@@ -264,7 +271,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
                     gp = src[i] + kt * BK;
                 }
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(st + (wave + NL * i) * 1024), 16, 0, 0);
             }
         } else {
             // wave-uniform bases; the readfirstlane pair pins them in SGPRs (otherwise LLVM folds them back into per-lane
@@ -281,10 +288,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
                 const char* gp = (i < LPT_A ? ab : wb) + loff[i];
                 if (NTW && i >= LPT_A)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                     (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 2);
+                                                     (__attribute__((address_space(3))) void*)(st + (wave + NL * i) * 1024), 16, 0, 2);
                 else
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                     (__attribute__((address_space(3))) void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(st + (wave + NL * i) * 1024), 16, 0, 0);
             }
         }
     };
@@ -301,19 +308,38 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = kspan / BK;
+    if (!PROD || producer) {
 #pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
-        if (t < nk) issue(t);
+        for (int t = 0; t < NS - 1; ++t)
+            if (t < nk) issue(t);
+    }
+    if (PROD && producer) {
+        // producer waves: wait for the own pieces of tile kt, meet the consumers, request tile kt + NS - 1 into the stage they left
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = nk - 1 - kt;
+            if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
+            else if (NS > 5 && ahead == 3) wait_vmcnt<LPT * 3>();
+            else if (NS > 4 && ahead == 2) wait_vmcnt<LPT * 2>();
+            else if (NS > 3 && ahead == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        }
+        __builtin_amdgcn_s_barrier();                        // the epilogue's "every wave has finished reading the ring"
+        return;
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight
-        const int ahead = nk - 1 - kt;
-        if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
-        else if (NS > 5 && ahead == 3) wait_vmcnt<LPT * 3>();
-        else if (NS > 4 && ahead == 2) wait_vmcnt<LPT * 2>();
-        else if (NS > 3 && ahead == 1) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
+        if (!PROD) {
+            // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight
+            const int ahead = nk - 1 - kt;
+            if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
+            else if (NS > 5 && ahead == 3) wait_vmcnt<LPT * 3>();
+            else if (NS > 4 && ahead == 2) wait_vmcnt<LPT * 2>();
+            else if (NS > 3 && ahead == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue(kt + NS - 1);            // its stage was last read in iteration kt-1
+        if (!PROD && kt + NS - 1 < nk) issue(kt + NS - 1);            // its stage was last read in iteration kt-1
         const char* sA = smem + (kt % NS) * STAGE;
         const char* sB = sA + BM * RB;
 #pragma unroll
@@ -337,10 +363,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const GemmParams p) {
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
+__global__ __launch_bounds__(64 * (WGM * WGN + PROD), PROD ? (2 * (WGM * WGN + PROD)) / 4 : 1) void gemm_glds_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
+    gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
 }
 
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
@@ -364,7 +390,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false, int BK = 64>
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false, int BK = 64, int PROD = 0>
 static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
@@ -376,7 +402,7 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
     const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * (BK * 2);
-    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK>;
+    auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -384,15 +410,16 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : BK == 64 ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,32>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
+    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : PROD ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,64,p>" : BK == 64 ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,32>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
     g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * WGM * WGN), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * (WGM * WGN + PROD)), lds, s, p);
     return hipGetLastError();
 }
 
 // tuning override for tools/gemm_bench.py: -1 = heuristic, otherwise index into the config table below
 int g_tune_gemm_cfg = -1;
 int g_tune_gemm_gm = -1;
+int g_tune_gemm_prod = 1;       // tools: 0 = the wide bf16-output GEMMs of the batched frames keep the all-waves-load form (A/B)
 int g_tune_gemm_big = 1;        // tools: 0 = never pick the 256x256 tile (A/B of the heuristic)
 
 template <int EPI>
@@ -428,6 +455,9 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 17: return launch_glds<128, 128, 2, 2, EPI, 5, false, false, 32>(p, s);     // 80 KB: 2 per CU, 4 in flight
         case 18: return launch_glds<128, 128, 2, 2, EPI, 3, false, false, 32>(p, s);     // 48 KB: 3 per CU, 2 in flight
         case 19: return launch_glds<128, 128, 2, 2, EPI, 6, false, false, 32>(p, s);     // 96 KB: 1 per CU, 5 in flight
+        // producer waves: the consumers issue no LDS-DMA
+        case 20: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 2>(p, s);  // 4 consumers + 2 producers, 2 workgroups per CU (3 waves / SIMD)
+        case 21: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 4>(p, s);  // 4 + 4, 2 per CU (4 waves / SIMD: 128 registers)
     }
     return hipErrorInvalidValue;
 }
@@ -446,6 +476,7 @@ static int pick_plain_cfg(const GemmParams& p) {
     }
     if (t64 < 768) return 4;
     if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
+    if (g_tune_gemm_prod && p.epi != EPI_F32 && p.N >= 3072 && n128 && p.splitk <= 1) return 21;   // 4 consumers + 4 producers (probe 5)
     if (g_tune_gemm_big && p.N % 256 == 0 && p.K >= 1024 && p.splitk <= 1) {
         // 256x256 tiles, 8 waves, one workgroup per CU: half the LDS-DMA instructions per MFMA of the 128x128 tile (an LDS-DMA
         // instruction costs its wave ~55 cycles of issue).  Pays where the K loop is long enough to amortise the tile's prologue /
@@ -464,8 +495,8 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
         return launch_glds<128, 32, 4, 1, EPI, 3>(p, s);
     }
     int cfg = pick_plain_cfg(p);
-    if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 19)) && p.N % 128 != 0) cfg = 0;
-    if (cfg >= 16 && cfg <= 19 && p.splitk > 1) cfg = 6;
+    if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 21)) && p.N % 128 != 0) cfg = 0;
+    if (cfg >= 16 && cfg <= 21 && p.splitk > 1) cfg = 6;
     if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
