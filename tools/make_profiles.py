@@ -16,9 +16,10 @@ def short(name):
     """'void uvl::gemm_glds_kernel<64, 64, 2, 2, 1, 3, false>(uvl::GemmParams)' -> 'gemm_glds_kernel<64,64,2,2,1,3,0>'"""
     n = name.split("(")[0].replace("void ", "").replace("uvl::", "").replace(" ", "")
     n = n.replace("false", "0").replace("true", "1")
-    m = re.match(r"^(gemm_glds_kernel<\d+,\d+,\d+,\d+,\d+,\d+,\d+),(\d+)>$", n)
-    if m:          # the non-temporal-weights flag: written the way the library names its launches (bench.py keys on that name)
-        n = m.group(1) + (",nt>" if m.group(2) == "1" else ">")
+    m = re.match(r"^(gemm_glds_kernel<\d+,\d+,\d+,\d+,\d+,\d+,\d+),(\d+)(?:,(\d+))?(?:,(\d+))?>$", n)
+    if m:          # non-temporal weights / 32-wide K stages / producer waves: written the way the library names its launches (bench.py keys on that name)
+        ntw, bk, prod = m.group(2), m.group(3) or "64", m.group(4) or "0"
+        n = m.group(1) + (",nt>" if ntw == "1" else ",0,64,p>" if prod != "0" else ",0,32>" if bk == "32" else ">")
     return n
 
 
