@@ -225,7 +225,8 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 /* Tuning hooks for tools/gemm_bench.py (not part of the product path): force a plain-GEMM tile configuration
  * (key "gemm_cfg", -1 = heuristic), the tile order (key "gemm_gm": 0 = every XCD owns whole N panels, g > 0 = groups
  * of g M-tiles, -1 = heuristic), the attention variant (key "attn_cfg"), the split-K factor of the frame's residual GEMMs (keys "sk_k1":
- * K = D, "sk_k4": K = 4 D; -1 = heuristic; tools/ab_splitk.py) and run a GEMM with split-K f32 slabs [splitk][M,N]. */
+ * K = D, "sk_k4": K = 4 D; -1 = heuristic; tools/ab_splitk.py), switch two choices of the batched GEMM heuristic off (keys "gemm_big":
+ * the 256x256 tile, "gemm_prod": the producer-wave form; default 1; tools/ab_tune.py) and run a GEMM with split-K f32 slabs [splitk][M,N]. */
 int uvl_tune_set(const char* key, int value);
 int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, float* d_slabs,
                       int M, int N, int K, int splitk, void* stream);
