@@ -167,7 +167,8 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 // wait for them) while the WGM x WGN consumer waves only read fragments and issue MFMAs -- an LDS-DMA instruction costs the wave that
 // issues it ~55 cycles, half of what a consumer of the 128x128 tile issues per K step (profiles/r02_gemm_structure.md, probe 5).
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
-__device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk, const int g, char* smem) {
+__device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk_in, const int g, char* smem) {
+    int sk = sk_in;
     static_assert(BK == 64 || (BK == 32 && !CONV), "K extent of a stage");
     static_assert(PROD == 0 || (!CONV && !NTW), "producer waves: plain GEMMs only");
     constexpr int RB = BK * 2;                       // bytes of a stage row
@@ -198,7 +199,17 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     // Workgroup b runs on XCD b % 8 (dispatch order; affects speed only), and every XCD has its own L2.
     const int xcd = bx & 7, idx = bx >> 3;
     int nt, mt;
-    if (p.group_m == 0) {
+    if (p.group_m < 0) {
+        // K-SLICE map of a split-K GEMM with few M tiles (one or two sequences): the grid is 1-D over (tile, slice) and XCD x owns ONE
+        // K slice (x / nparts) and one contiguous share of the N panels (x % nparts, nparts = 8 / splitk): its L2 then holds
+        // A[:, slice] and its share of W[:, slice] -- with the tile map below every XCD pulls ALL of A through its L2 for every slice
+        // (fc2 of UVLTrack-B at one sequence: 8 x 3.4 MB of A per launch instead of 8 x 0.85 MB)
+        const int nparts = 8 / p.splitk, NTp = NT / nparts;
+        sk = xcd / nparts;
+        if (idx >= MT * NTp) return;
+        nt = (xcd % nparts) * NTp + idx / MT;
+        mt = idx % MT;
+    } else if (p.group_m == 0) {
         // panel map (UVL_GEMM_GM=0 only; the default of the first builds): an XCD owns whole N panels, so every weight byte enters
         // exactly one L2 -- but XCDs get unequal shares unless N / BN is a multiple of 8, see launch_glds
         nt = (idx / MT) * 8 + xcd;
@@ -390,6 +401,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     }
 }
 
+int g_tune_gemm_kxcd = 1;       // tools: 0 = split-K GEMMs of one or two sequences keep the tile map (A/B of the K-slice map)
+
+// K-slice map (see gemm_glds_body): a split-K GEMM with few M tiles whose slices and N panels divide over the 8 XCDs
+static bool gemm_kxcd_ok(const GemmParams& p, int MT, int NT) {
+    return g_tune_gemm_kxcd && p.splitk > 1 && 8 % p.splitk == 0 && NT % (8 / p.splitk) == 0 && MT < 16 && p.conv_F == 0 && p.groups <= 1;
+}
+
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false, int BK = 64, int PROD = 0>
 static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
@@ -400,7 +418,9 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     // half with 1 when N = 768 (12 panels): 1378-1405 -> 1468-1499 frames/s in the frame (text branch reused, same box).
     p.group_m = MT >= 16 ? 8 : MT;
     if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
-    const int nblk = p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
+    const bool kxcd = !CONV && g_tune_gemm_gm < 0 && gemm_kxcd_ok(p, MT, NT);
+    if (kxcd) p.group_m = -1;
+    const int nblk = kxcd ? 8 * MT * (NT / (8 / p.splitk)) : p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * (BK * 2);
     auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>;
     static bool attr_done = false;
@@ -412,7 +432,7 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     static char name[64];
     if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : PROD ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,64,p>" : BK == 64 ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,32>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
     g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(nblk, p.splitk > 1 ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * (WGM * WGN + PROD)), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(nblk, (p.splitk > 1 && !kxcd) ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * (WGM * WGN + PROD)), lds, s, p);
     return hipGetLastError();
 }
 
@@ -509,8 +529,11 @@ static hipError_t launch_pair_epi(const GemmParams& a_in, const GemmParams& b_in
     const int mta = (a.M + 63) / 64, mtb = (b.M + 63) / 64;
     a.group_m = mta;                       // N-major runs per XCD, as launch_glds does for few M tiles
     b.group_m = mtb;
-    const int ta = 8 * ((mta * (a.N / 64) + 7) / 8), tb = 8 * ((mtb * (b.N / 64) + 7) / 8);
-    const int ba = ta * a.splitk, bb = tb * b.splitk;
+    int ta = 8 * ((mta * (a.N / 64) + 7) / 8), tb = 8 * ((mtb * (b.N / 64) + 7) / 8);
+    int ba = ta * a.splitk, bb = tb * b.splitk;
+    // K-slice map: the grid of a problem is 1-D over (tile, slice); "tiles" = all its blocks makes the kernel pass the block id through
+    if (gemm_kxcd_ok(a, mta, a.N / 64)) { a.group_m = -1; ba = ta = 8 * mta * ((a.N / 64) / (8 / a.splitk)); }
+    if (gemm_kxcd_ok(b, mtb, b.N / 64)) { b.group_m = -1; bb = tb = 8 * mtb * ((b.N / 64) / (8 / b.splitk)); }
     constexpr size_t lds = 3 * (size_t)(64 + 64) * 128;
     auto kern = gemm_glds_pair_kernel<64, 64, 2, 2, EPI, 3>;
     static char name[64];

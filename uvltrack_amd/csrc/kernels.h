@@ -9,6 +9,7 @@ namespace uvl {
 // name of the kernel instantiation the last launcher picked (for per-kernel profiles)
 extern thread_local const char* g_last_kernel;
 extern int g_tune_gemm_prod;     // tools: 1 = producer-wave GEMM form for the wide bf16-output GEMMs of batched frames
+extern int g_tune_gemm_kxcd;     // tools: 0 = no K-slice map for the split-K GEMMs of one or two sequences
 extern int g_tune_gemm_big;      // tools: 0 = the GEMM heuristic never picks the 256x256 tile
 extern int g_tune_attn_cfg;      // tools/attn_bench.py override of the attention configuration (-1 = heuristic)
 extern int g_tune_gemm_gm;       // override of the grouped tile order (-1 = heuristic, 0 = panel map, g = group of g M-tiles)

@@ -920,6 +920,7 @@ extern "C" int uvl_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_gm")) { uvl::g_tune_gemm_gm = value; return UVL_OK; }
     if (!strcmp(key, "attn_cfg")) { uvl::g_tune_attn_cfg = value; return UVL_OK; }
     if (!strcmp(key, "gemm_big")) { uvl::g_tune_gemm_big = value; return UVL_OK; }
+    if (!strcmp(key, "gemm_kxcd")) { uvl::g_tune_gemm_kxcd = value; return UVL_OK; }
     if (!strcmp(key, "gemm_prod")) { uvl::g_tune_gemm_prod = value; return UVL_OK; }
     if (!strcmp(key, "sk_k1")) { g_tune_sk[0] = value; return UVL_OK; }
     if (!strcmp(key, "sk_k4")) { g_tune_sk[1] = value; return UVL_OK; }
