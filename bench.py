@@ -5,13 +5,20 @@ tracking/profile_model.py:30-47 (warm-up, then K timed forwards, sync only at bo
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model B|L] [--mode NLBBOX|NL|BBOX]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --model L --batch 8          # BASELINE configs[4]: 64 UVLTrack-L sequences, 8 per GPU; a plain
+                                                          # process with --gpus N > 1 launches its own N ranks (one per GPU)
 
 A step = one pass of the hot path over one batch of synthetic frames per GPU (inputs resident in HBM, weights
 from the deterministic generator).  Each rank owns its own sequences (independent per-sequence
 shards, weights replicated); after every step the per-shard boxes are all-gathered over RCCL on the process group's stream.
 A timed BLOCK is exactly `--steps` steps between barrier + synchronize on both sides, maximum over ranks; the line reports the
-MEDIAN of `--blocks` such blocks (default: as many as fit in about one second, at least 3), so a 20-step run of a 0.7 ms frame is
+MEDIAN of `--blocks` such blocks (default: as many as fit in about three seconds, 3..400), so a 20-step run of a 0.7 ms frame is
 not a 15 ms sample.  Rank 0 prints ONE JSON line.
+
+Launch forms.  Under `torch.distributed.run` (WORLD_SIZE in the environment) every rank joins an RCCL process group -- also when
+there is one rank, so the collective leg runs on a single GPU too.  A plain `python bench.py --gpus N` with N > 1 (or `--dist`)
+re-launches itself through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, the way the
+reference's evaluation spawns one worker per GPU (lib/test/evaluation/running.py:153-171); rank 0 still prints the one line.
 """
 from __future__ import annotations
 
@@ -52,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--profile-json", default=None, help="also write the per-kernel breakdown to this file")
+    ap.add_argument("--dist", action="store_true", help="run under torch.distributed.run even with --gpus 1 (RCCL process group of one rank)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="tools only: uvl_tune_set(KEY, VALUE) on the engine's handle (include/uvltrack_hip.h: uvl_tuning); recorded in the line")
     return ap.parse_args(argv)
 
 
@@ -127,7 +137,7 @@ def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmu
     (uvltrack_amd.shard.BoxGatherer, or None for one process) all-gathers them, double-buffered so the collective of step i
     overlaps step i + 1.  on_result(i, boxes) is called on every rank with the gathered boxes of step i once they are complete
     (one step late, as a consumer of the boxes would).  Returns the list of block times (seconds, maximum over ranks), `blocks`
-    entries (0 = choose from the first block: about one second in total, 3..25)."""
+    entries (0 = choose from the first block: about three seconds in total, 3..400)."""
     counter = [0]
     delivered = [-1]
 
@@ -170,7 +180,7 @@ def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmu
         sync()
         times.append(env.max_over_ranks(time.perf_counter() - t0))
         if want <= 0:
-            want = int(min(25, max(3, round(1.0 / max(times[0], 1e-6)))))
+            want = int(min(400, max(3, round(3.0 / max(times[0], 1e-6)))))
         if len(times) >= want:
             return times
 
@@ -182,6 +192,9 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     from uvltrack_amd.shard import BoxGatherer
     flags = [flag_val] * B
     eng = HipEngine(spec, dev, max_batch=max(B, 1))
+    for kv in args.tune:
+        k, v = kv.split("=", 1)
+        eng.tune_set(k.strip(), int(v))
     eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
     inp = wg.make_inputs(spec, batch=B, seed=seed + rank, flags=flags)      # every rank advances its own sequences
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -193,7 +206,7 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
         _, outs = eng.capture(*targs, skip_text=skip_text)
         step_fn = eng.replay
     # RCCL all-gather of the per-shard boxes: rank r owns sequences [r*B, (r+1)*B)
-    gatherer = BoxGatherer(env.world * B, dev) if env.world > 1 else None
+    gatherer = BoxGatherer(env.world * B, dev) if isinstance(env, DistEnv) else None      # also with ONE rank under torch.distributed.run
     times = timed_blocks(lambda i: step_fn(), lambda: outs["pred_boxes"].view(B, 4), gatherer, env, torch.cuda.synchronize, steps, warmup, blocks)
     finite = bool(torch.isfinite(outs["bbox_map"]).all().item()) and bool(torch.isfinite(outs["logits"]).all().item())
     if not finite:
@@ -229,7 +242,7 @@ def kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, singl
         frac_mfma, frac_hbm = tf / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see
         # profiles/*_pmc_summary.md); null when no PMC pass of this kernel instantiation on this workload has been committed
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             pdir = os.path.join(ROOT, "profiles")
             for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")):
@@ -237,16 +250,22 @@ def kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, singl
                 wl = doc.get("workload", {"model": "B", "batch": 1})
                 tb = doc.get("bytes_per_launch", {})
                 if name in tb and wl.get("batch") == B and wl.get("model") == model:
-                    traffic = tb[name]
+                    traffic, traffic_source = tb[name], "profiles/" + fn
         except OSError:
             pass
         bound = "mfma" if frac_mfma >= frac_hbm else "hbm"
-        return {"bound": bound, "kernel": name, "sites": sorted(set(d["sites"])), "launches_per_frame": d["launches"],
+        # neither roof within 1/0.15 of this kernel: it waits for latency (dependent round trips of a 5-10 us launch), and the
+        # label says so; achieved / peak / frac stay those of the nearer roof
+        regime = "latency" if max(frac_mfma, frac_hbm) < 0.15 else bound
+        return {"bound": bound, "regime": regime, "kernel": name, "sites": sorted(set(d["sites"])), "launches_per_frame": d["launches"],
                 "avg_launch_us": avg_ms * 1e3, "avg_launch_us_event_pair": raw_avg_ms * 1e3, "event_overhead_us": event_overhead_ms * 1e3,
                 "flops_per_launch": d["flops"] / max(d["launches"], 1), "bytes_per_launch": d["bytes"] / max(d["launches"], 1),
                 "achieved": tf if bound == "mfma" else gbs, "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(frac_mfma, frac_hbm),
-                "achieved_tflops": tf, "frac_mfma": frac_mfma, "achieved_gbs": gbs, "frac_hbm": frac_hbm, "traffic": traffic}
+                "achieved_tflops": tf, "frac_mfma": frac_mfma, "achieved_gbs": gbs, "frac_hbm": frac_hbm, "traffic": traffic,
+                # `traffic` is NOT measured in this run: HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3
+                # --pmc passes of this same command, looked up by kernel instantiation and workload
+                "traffic_source": traffic_source}
 
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
     roofline = block(dom_name, dom)
@@ -258,26 +277,48 @@ def kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, singl
     return roofline, roofline_attention, by_kernel, prof, n_launch
 
 
+def self_launch(n: int) -> int:
+    """Re-run this command line as `n` ranks, one per GPU, through torch.distributed.run on 127.0.0.1 (a free port); returns the
+    launcher's exit code.  Rank 0 of the child job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    envp = dict(os.environ)
+    envp.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [a for a in sys.argv[1:] if a != "--dist"]
+    if "--gpus" not in " ".join(argv):
+        argv += ["--gpus", str(n)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=envp)
+
+
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver (exported by the harness too)
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not under_launcher and (args.gpus > 1 or args.dist):
+        raise SystemExit(self_launch(max(1, args.gpus)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if under_launcher and world != max(1, args.gpus):
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU: %d device(s) visible, --gpus %d" % (rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if under_launcher:                                             # one rank included: the RCCL leg is the same code at every N
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)     # RCCL on ROCm
-    env = DistEnv(dist, dev) if world > 1 else NoDist()
+    env = DistEnv(dist, dev) if under_launcher else NoDist()
 
     spec = build_spec(args.model, args.template_size, args.search_size)
     B = args.batch
@@ -302,7 +343,8 @@ def main():
                                  if len(s) >= 2 and "embeddings" not in n and "pos_embed" not in n)
         line = {
             "metric": "tracker FPS (frames/sec) UVLTrack-%s forward_test" % args.model,
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": fps, "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if under_launcher else 0,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "blocks": len(times), "block_ms": [round(x * 1e3, 3) for x in times], "statistic": "median of the blocks (each: exactly `steps` steps, max over ranks)",
@@ -317,6 +359,8 @@ def main():
             "outputs_finite": True,
             "roofline": roofline,
         }
+        if args.tune:
+            line["config"]["tune"] = list(args.tune)              # NOT the default path: heuristics overridden for an A/B
         if roofline_attention is not None:
             line["roofline_attention"] = roofline_attention
     eng.close()
@@ -345,7 +389,7 @@ def main():
             with open(args.profile_json, "w") as f:
                 json.dump({"by_kernel": by_kernel, "sites": prof, "line": line}, f, indent=1)
         print(json.dumps(line))
-    if world > 1:
+    if under_launcher:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -222,14 +222,27 @@ int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int
  * contrast kernels, so that tests and tools can compare the launch forms (same results). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
-/* Tuning hooks for tools/gemm_bench.py (not part of the product path): force a plain-GEMM tile configuration
- * (key "gemm_cfg", -1 = heuristic), the tile order (key "gemm_gm": 0 = every XCD owns whole N panels, g > 0 = groups
- * of g M-tiles, -1 = heuristic), the attention variant (key "attn_cfg"), the split-K factor of the frame's residual GEMMs (keys "sk_k1":
- * K = D, "sk_k4": K = 4 D; -1 = heuristic; tools/ab_splitk.py), switch two choices of the batched GEMM heuristic off (keys "gemm_big":
- * the 256x256 tile, "gemm_prod": the producer-wave form; default 1; tools/ab_tune.py) and run a GEMM with split-K f32 slabs [splitk][M,N]. */
-int uvl_tune_set(const char* key, int value);
+/* Overrides of the launch heuristics, for tools and tests (not part of the product path).  There is NO process-global tuning
+ * state: a model handle owns one uvl_tuning (uvl_tune_set writes it; every launch of that handle's frames reads it), and the
+ * per-kernel entry points below take an optional `const uvl_tuning*` (NULL = heuristics).  Every field: -1 = heuristic / default.
+ *   gemm_cfg   index into the plain-GEMM tile configuration table (gemm.hip::launch_plain_cfg)
+ *   gemm_gm    tile order: 0 = every XCD owns whole N panels, g > 0 = groups of g M-tiles
+ *   gemm_prod  0 = the wide bf16-output GEMMs of batched frames keep the all-waves-load form (default: producer waves)
+ *   gemm_big   0 = never pick the 256x256 tile (default: where its tiles fill whole rounds of CUs)
+ *   gemm_kxcd  0 = split-K GEMMs of one or two sequences keep the tile map (default: K-slice map)
+ *   attn_cfg   index into the attention configuration table (attention.hip::launch_attention)
+ *   sk_k1 / sk_k4  split-K factor of the frame's residual GEMMs with K = D / K = 4 D
+ *   gemm_pipe  0 = never pick the phase-pipelined 256-wide GEMM (default: batched frames, see gemm.hip::pick_plain_cfg)
+ * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
+typedef struct uvl_tuning {
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe;
+    int32_t reserved[7];
+} uvl_tuning;
+void uvl_tuning_init(uvl_tuning* t);
+int uvl_tune_set(uvl_model_t* m, const char* key, int value);
+/* y[sk] (f32 slabs [splitk][M,N]) = partial sums over K-range sk (bias in slab 0): the split-K form of the frame's residual GEMMs */
 int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, float* d_slabs,
-                      int M, int N, int K, int splitk, void* stream);
+                      int M, int N, int K, int splitk, const uvl_tuning* tune, void* stream);
 
 /* ---- per-kernel entry points (used by the parity tests; same kernels the forward uses) ---------- */
 
@@ -238,7 +251,7 @@ int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, flo
  * act: 0 none, 1 erf-GELU, 2 ReLU.  out_f32 != 0: d_y is f32 [M,N] and `accumulate` adds into it
  * (the residual add of block.py:30-31); otherwise d_y is bf16 [M,N].  K % 64 == 0, N % 64 == 0. */
 int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
-               int M, int N, int K, int act, int out_f32, int accumulate, void* stream);
+               int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune, void* stream);
 
 /* Fused multi-head self-attention core of Attention.forward (block.py:50-58) and BertSelfAttention
  * (bert_backbone.py:311-324): softmax(q k^T / sqrt(64) + key_add) v.
@@ -249,13 +262,13 @@ int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
  * same); 0: d_q is the plain projection and the kernel applies the factor itself. */
 #define UVL_ATTN_QSCALE 0.18033688011112042f
 int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o,
-                  int B, int H, int N, int Npad, int q_prescaled, void* stream);
+                  int B, int H, int N, int Npad, int q_prescaled, const uvl_tuning* tune, void* stream);
 
 /* QKV projection with the scatter epilogue the attention kernel consumes (block.py:49-50):
  * d_x [B*N, D] bf16, d_w [3D, D] bf16, d_bias [3D] f32 -> q,k [B,H,Npad,64], vt [B,H,64,Npad]; q is multiplied by
  * q_scale before it is rounded (1.0f = the plain projection). */
 int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
-                    int B, int N, int Npad, int D, float q_scale, void* stream);
+                    int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune, void* stream);
 
 /* One layer of the box head's four 3x3 conv towers, conv(3x3, pad 1) + BatchNorm2d(eval) + ReLU (heads/utils.py:126-131;
  * towers of modality_adaptive_box_head.py:28-50), as the frame runs it: BatchNorm folded into bf16 weights, the four towers as
@@ -268,7 +281,7 @@ int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void*
 int uvl_fold_conv_bn(const float* d_w, const float* d_b, const float* d_bn_w, const float* d_bn_b, const float* d_bn_mean,
                      const float* d_bn_var, void* d_w_packed, float* d_bias_folded, int cout, int cin, void* stream);
 int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_ld, const int32_t x_group_offset[4], int cin, int cout,
-                         const void* d_w_packed, const float* d_bias_folded, void* d_y, float* d_slabs, void* stream);
+                         const void* d_w_packed, const float* d_bias_folded, void* d_y, float* d_slabs, const uvl_tuning* tune, void* stream);
 
 /* nn.LayerNorm / BertLayerNorm over the last dim (block.py:30-31 eps 1e-6; bert_backbone.py:231-244 eps 1e-12).
  * d_x [M,D] f32 -> d_y_bf16 [M,D] bf16 (may be NULL) and d_y_f32 [M,D] f32 (may be NULL, may alias d_x). */

@@ -51,6 +51,10 @@ def cases():
     c["b_z256_x256_b8"] = dict(spec=spec_b(256, 256), seed=0, in_seed=13, batch=8, flags=[2, 0, 1, 2, 2, 1, 0, 2], zero_text_rows=[5])
     # UVLTrack-L at the north-star sizes (template 256, search 384: 833 -> 873 tokens)
     c["l_z256_x384"] = dict(spec=spec_l(256, 384), seed=0, in_seed=14, batch=2, flags=[2, 0])
+    # the per-GPU shard of BASELINE configs[4] at its real shape: 8 sequences of UVLTrack-L z256/x384 (M = 6984 rows, 512 attention
+    # workgroups) -- at this size the heuristics choose the many-sequence kernels on their own, so the un-forced default path is
+    # what the reference pins here; mixed flags, one all-padding text
+    c["l_z256_x384_b8"] = dict(spec=spec_l(256, 384), seed=0, in_seed=15, batch=8, flags=[2, 1, 0, 2, 2, 0, 1, 2], zero_text_rows=[3])
     return c
 
 

@@ -8,11 +8,30 @@ The HIP path keeps the residual stream in f32 and feeds bf16 operands to the MFM
     search/template/text/tokens              3 % of the tensor's abs-max
     pred_boxes                               tie-aware: the reference score at our argmax must be within 1e-2
                                              of the reference max, then that bbox_map row must match to 1e-2
+    pred_boxes IoU                           the absolute gates above in TRACKER terms: IoU of the predicted box with the
+                                             reference's box (the reference's bbox_map row at our argmax -- tie-aware -- and its own
+                                             pred_boxes whenever the argmax agrees) >= 0.98 for UVLTrack-B and -L alike (no depth
+                                             scaling); the minimum IoU over ALL cells of bbox_map is reported beside it
 """
 import numpy as np
 
 ATOL = {"bbox_map": 1e-2, "cls_score": 1e-2, "cls_score_test": 1e-2, "cont_score": 5e-2, "logits": 0.15}
 REL_ABSMAX = {"search": 0.03, "template": 0.03, "text": 0.03, "vis_token": 0.03, "txt_token": 0.03}
+
+
+IOU_MIN = 0.98
+
+
+def box_iou_cxcywh(a, b):
+    """IoU of boxes [..., 4] = (cx, cy, w, h) (normalised units, head:108-119); degenerate boxes give 0."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    ax0, ay0, ax1, ay1 = a[..., 0] - a[..., 2] / 2, a[..., 1] - a[..., 3] / 2, a[..., 0] + a[..., 2] / 2, a[..., 1] + a[..., 3] / 2
+    bx0, by0, bx1, by1 = b[..., 0] - b[..., 2] / 2, b[..., 1] - b[..., 3] / 2, b[..., 0] + b[..., 2] / 2, b[..., 1] + b[..., 3] / 2
+    iw = np.clip(np.minimum(ax1, bx1) - np.maximum(ax0, bx0), 0, None)
+    ih = np.clip(np.minimum(ay1, by1) - np.maximum(ay0, by0), 0, None)
+    inter = iw * ih
+    union = np.clip(a[..., 2], 0, None) * np.clip(a[..., 3], 0, None) + np.clip(b[..., 2], 0, None) * np.clip(b[..., 3], 0, None) - inter
+    return np.where(union > 0, inter / np.maximum(union, 1e-30), 0.0)
 
 
 def softmax_np(x):
@@ -55,6 +74,19 @@ def compare_outputs(got, ref, skip=(), depth=12):
         box_err = float(np.abs(np.asarray(got["pred_boxes"])[:, 0] - ref["bbox_map"][np.arange(B), idx]).max())
         report["pred_boxes(tie-aware)"] = (max(gap, box_err), 1e-2 * scale)
         ok &= gap <= 1e-2 * scale and box_err <= 1e-2 * scale
+        # the same statement in tracker terms: IoU of our box with the reference's box for the cell we chose, and with the
+        # reference's own prediction wherever the two argmaxes agree (gate stated as 1 - IoU so that "err <= tol" reads the same)
+        mine = np.asarray(got["pred_boxes"])[:, 0]
+        iou = box_iou_cxcywh(mine, ref["bbox_map"][np.arange(B), idx])
+        ref_idx = score.argmax(-1)
+        same = ref_idx == idx
+        if same.any():
+            iou = np.where(same, np.minimum(iou, box_iou_cxcywh(mine, ref["pred_boxes"][:, 0])), iou)
+        report["pred_boxes 1-IoU"] = (float(1.0 - iou.min()), 1.0 - IOU_MIN)
+        ok &= float(iou.min()) >= IOU_MIN
+        if "bbox_map" in got:
+            cell_iou = box_iou_cxcywh(np.asarray(got["bbox_map"]), ref["bbox_map"])
+            report["bbox_map min IoU over all cells (informational)"] = "%.4f (mean %.4f)" % (float(cell_iou.min()), float(cell_iou.mean()))
     return ok, report
 
 

@@ -18,7 +18,7 @@ def lib():
 def test_every_declared_symbol_is_exported(lib):
     from uvltrack_amd import _native
     hdr = open(os.path.join(ROOT, "include", "uvltrack_hip.h")).read()
-    declared = set(re.findall(r"\b(uvl_[a-z0-9_]+)\s*\(", hdr)) - {"uvl_config", "uvl_inputs", "uvl_outputs", "uvl_model_t"}
+    declared = set(re.findall(r"\b(uvl_[a-z0-9_]+)\s*\(", hdr)) - {"uvl_config", "uvl_inputs", "uvl_outputs", "uvl_model_t", "uvl_tuning"}
     assert declared, "header parse failed"
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
@@ -29,6 +29,25 @@ def test_config_struct_layout_matches_header(lib):
     from uvltrack_amd import _native
     assert ctypes.sizeof(_native.UvlConfig) == 4 * (5 + 64 + 12)
     assert lib.uvl_version() >= 1
+
+
+def test_tuning_struct_and_no_global_tuning_state(lib):
+    """uvl_tuning is a plain 64-byte struct of int32 (-1 = heuristic) owned by a handle or passed per call; the library holds no
+    process-global tuning variable (no global mutable state besides the error string)."""
+    import subprocess
+    from uvltrack_amd import _native
+    assert ctypes.sizeof(_native.UvlTuning) == 64
+    t = _native.UvlTuning(gemm_cfg=11)
+    assert t.gemm_cfg == 11 and t.attn_cfg == -1
+    raw = (ctypes.c_int32 * 16)(*range(16))
+    lib.uvl_tuning_init(ctypes.cast(raw, ctypes.POINTER(_native.UvlTuning)))
+    assert list(raw) == [-1] * 16
+    hdr = open(os.path.join(ROOT, "include", "uvltrack_hip.h")).read()
+    fields = re.search(r"typedef struct uvl_tuning \{\s*int32_t ([^;]+);", hdr).group(1).replace(" ", "").split(",")
+    assert tuple(fields) == _native.TUNING_FIELDS
+    syms = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    assert "g_tune" not in syms
+    assert lib.uvl_tune_set(None, b"gemm_cfg", 3) < 0          # a handle is required
 
 
 def test_create_without_gpu_fails_loudly(lib):

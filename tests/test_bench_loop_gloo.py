@@ -77,3 +77,59 @@ def test_bench_loop_single_process():
     calls = []
     times = bench.timed_blocks(lambda i: calls.append(i), lambda: None, None, bench.NoDist(), lambda: None, 5, 2, 3)
     assert len(times) == 3 and calls == list(range(2 + 3 * 5))
+
+
+def test_self_launcher_builds_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` as a plain process re-launches itself through torch.distributed.run on 127.0.0.1 (what the
+    reference's evaluation does with one worker per GPU, lib/test/evaluation/running.py:153-171): N ranks, the same flags,
+    dmabuf IPC in the environment.  The command is checked here; a GPU test runs it for real with one rank."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--model", "L", "--batch", "8", "--steps", "5", "--dist"])
+    assert bench.self_launch(8) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--model", "L", "--batch", "8", "--steps", "5"]          # --dist is consumed by the launcher
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _worker_one(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from uvltrack_amd.shard import BoxGatherer
+        g = BoxGatherer(3, torch.device("cpu"))
+        ok = True
+        for i in range(4):
+            b = torch.stack([_boxes(s, i) for s in range(3)])
+            g.submit(i, b)
+            ok &= g._pending[i & 1] is not None            # a real collective was enqueued, also for a group of one rank
+            ok &= bool(torch.equal(g.result(i), b))
+        g.drain()
+        q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_runs_the_collective_for_a_group_of_one():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one, args=(port, q))
+    p.start()
+    assert q.get(timeout=120)
+    p.join(timeout=60)

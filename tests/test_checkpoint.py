@@ -1,4 +1,6 @@
 """Checkpoint ingest: `.pth.tar` files with a 'net' entry, loaded as the reference tracker does (tracker:24)."""
+import collections
+
 import numpy as np
 import pytest
 import torch
@@ -40,20 +42,64 @@ def test_roundtrip_and_gates(tmp_path):
         load_checkpoint(_model(spec), path)
 
 
+def test_real_reference_layout_loads_without_the_training_modules(tmp_path):
+    """The reference trainer's files carry a `Settings` object of lib.train.admin.settings, optimizer state and statistics
+    (lib/train/trainers/base_trainer.py:130-140).  That module does not exist here: the restricted unpickler must still return
+    'net' -- with no opt-in flag -- and must not need (or import) the missing module."""
+    import sys
+    import types
+    spec = spec_tiny()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in wg.make_state_dict(spec, 7, include_unused=True).items()}
+    mod = types.ModuleType("lib.train.admin.settings_for_test")
+
+    class Settings:
+        def __init__(self):
+            self.env = types.SimpleNamespace(workspace_dir="/x", tensorboard_dir="/y")
+            self.script_name, self.config_name, self.local_rank = "uvltrack", "baseline_base", -1
+
+    class StatValue:
+        def __init__(self):
+            self.history, self.val = [0.5, 0.25], 0.25
+    Settings.__module__ = StatValue.__module__ = mod.__name__
+    Settings.__qualname__, StatValue.__qualname__ = "Settings", "StatValue"
+    mod.Settings, mod.StatValue = Settings, StatValue
+    sys.modules[mod.__name__] = mod
+    path = str(tmp_path / "UVLTrack_ep0300.pth.tar")
+    try:
+        torch.save({"epoch": 300, "actor_type": "UVLTrackActor", "net_type": "UVLTrack", "net": sd, "net_info": None, "constructor": None,
+                    "optimizer": {"state": {0: {"exp_avg": torch.zeros(3)}}, "param_groups": [{"lr": 1e-4, "params": [0]}]},
+                    "stats": {"train": collections.OrderedDict(loss=StatValue())}, "settings": Settings()}, path)
+    finally:
+        del sys.modules[mod.__name__]
+    got = read_checkpoint(path)
+    assert mod.__name__ not in sys.modules                      # nothing was imported on the file's behalf
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    res = load_checkpoint(_model(spec), path)
+    assert not res.missing_keys and not res.unexpected_keys
+
+
 class _Evil:
+    def __init__(self, target):
+        self.target = target
+
     def __reduce__(self):
         import os
-        return (os.getenv, ("HOME",))
+        return (os.mkdir, (self.target,))
 
 
-def test_rejected_pickle_is_not_reloaded_unsafely(tmp_path):
-    """A checkpoint the restricted loader rejects must not be re-read with the full unpickler behind the caller's back."""
-    import pickle
+def test_code_in_a_checkpoint_is_never_executed(tmp_path):
+    """A tampered file that asks the unpickler to call a function: the call must not happen, the weights still load."""
     path = str(tmp_path / "tampered.pth.tar")
-    torch.save({"net": {"w": torch.zeros(1)}, "extra": _Evil()}, path)
-    with pytest.raises(pickle.UnpicklingError, match="allow_unsafe_pickle"):
+    target = str(tmp_path / "created_by_the_pickle")
+    torch.save({"net": {"w": torch.arange(3.0)}, "extra": _Evil(target)}, path)
+    import os
+    got = read_checkpoint(path)
+    assert not os.path.exists(target)
+    assert set(got) == {"w"} and torch.equal(got["w"], torch.arange(3.0))
+    torch.save({"net": {"w": _Evil(target)}}, path)              # a non-tensor where a weight should be
+    with pytest.raises(TypeError):
         read_checkpoint(path)
-    assert set(read_checkpoint(path, allow_unsafe_pickle=True)) == {"w"}      # explicit opt-in for a trusted file
+    assert not os.path.exists(target)
 
 
 def test_submodule_weight_changes_invalidate_the_packed_copy():

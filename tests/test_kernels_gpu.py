@@ -12,11 +12,21 @@ pytestmark = pytest.mark.gpu
 def lib():
     from uvltrack_amd import _native
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
-    handle = _native.load()
+    return _native.load()
+
+
+def _tune(**kw):
+    """A uvl_tuning for ONE call (include/uvltrack_hip.h): the library keeps no process-global tuning state, so a forced kernel
+    form cannot leak into another test.  UVL_TEST_ATTN_CFG is a development aid: every attention case on one forced variant."""
     import os
-    if os.environ.get("UVL_TEST_ATTN_CFG"):      # development aid: run the attention cases on one forced kernel variant
-        handle.uvl_tune_set(b"attn_cfg", int(os.environ["UVL_TEST_ATTN_CFG"]))
-    return handle
+    from uvltrack_amd import _native
+    if os.environ.get("UVL_TEST_ATTN_CFG") and "attn_cfg" not in kw:
+        kw["attn_cfg"] = int(os.environ["UVL_TEST_ATTN_CFG"])
+    return _native.UvlTuning(**kw) if kw else None
+
+
+def _tref(t):
+    return t.ref() if t is not None else None
 
 
 def _stream():
@@ -52,7 +62,7 @@ def test_linear(lib, M, N, K, mode):
         if act == 2:
             ref = torch.relu(ref)
         y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, _stream()), lib)
+        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, None, _stream()), lib)
         torch.cuda.synchronize()
         err = (y.float() - ref).abs()
         tol = 1e-2 * ref.abs() + 2e-2
@@ -61,7 +71,7 @@ def test_linear(lib, M, N, K, mode):
         acc = mode == "f32_acc"
         y0 = _rand((M, N), 4) if acc else torch.full((M, N), float("nan"), device="cuda")
         y = y0.clone()
-        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, 0, 1, int(acc), _stream()), lib)
+        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, 0, 1, int(acc), None, _stream()), lib)
         torch.cuda.synchronize()
         if acc:
             ref = ref + y0
@@ -87,7 +97,8 @@ def test_layernorm(lib, M, D):
 QSCALE = 0.18033688011112042          # UVL_ATTN_QSCALE = log2(e) / sqrt(64)
 
 
-def _attention_case(lib, B, H, N, mode, seed, prescaled=True):
+def _attention_case(lib, B, H, N, mode, seed, prescaled=True, tune=None):
+    tune = tune if tune is not None else _tune()
     D = H * 64
     Npad = (N + 63) // 64 * 64
     x = _rand((B * N, D), seed).bfloat16()
@@ -97,7 +108,7 @@ def _attention_case(lib, B, H, N, mode, seed, prescaled=True):
     q = torch.full((B, H, Npad, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     k = torch.full_like(q, float("nan"))
     vt = torch.full((B, H, 64, Npad), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_qkv_project(_p(x), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(QSCALE if prescaled else 1.0), _stream()), lib)
+    _chk(lib.uvl_qkv_project(_p(x), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(QSCALE if prescaled else 1.0), _tref(tune), _stream()), lib)
     qkv = (x.float() @ w.float().t() + bias).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     torch.cuda.synchronize()
     qs = QSCALE if prescaled else 1.0
@@ -116,7 +127,7 @@ def _attention_case(lib, B, H, N, mode, seed, prescaled=True):
         add[:, :N] = -10000.0
     add[:, N:] = float("nan")           # must be ignored
     o = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, int(prescaled), _stream()), lib)
+    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, int(prescaled), _tref(tune), _stream()), lib)
     torch.cuda.synchronize()
     qf, kf, vf = q[:, :, :N].float(), k[:, :, :N].float(), vt[:, :, :, :N].transpose(2, 3).float()
     s = (qf @ kf.transpose(-1, -2)) * (math.log(2.0) if prescaled else 0.125)      # pre-scaled q: q k^T is the score in log2 units
@@ -147,12 +158,8 @@ def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
     if act:
         ref = torch.nn.functional.gelu(ref)
     y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-    lib.uvl_tune_set(b"gemm_cfg", cfg)
-    try:
-        _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, _stream()), lib)
-        torch.cuda.synchronize()
-    finally:
-        lib.uvl_tune_set(b"gemm_cfg", -1)
+    _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, _tune(gemm_cfg=cfg).ref(), _stream()), lib)
+    torch.cuda.synchronize()
     err = (y.float() - ref).abs()
     assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "cfg %d max err %g" % (cfg, float(err.max()))
 
@@ -164,11 +171,7 @@ def test_attention_batched_kernels_forced(lib, cfg, B, H, N, mode):
     """The two kernels of the batched regime -- attn_stream_kernel (cfg 8) and attn_w64_kernel (cfg 10: 64 queries per wave, pass 1
     without a running maximum, exact pass 2 on demand) -- on shapes the heuristic would not give them: one key tile, ragged tails,
     waves without queries, every key masked (pass 2 of the w64 kernel), more than 16 key tiles."""
-    lib.uvl_tune_set(b"attn_cfg", cfg)
-    try:
-        _attention_case(lib, B, H, N, mode, 300 + N)
-    finally:
-        lib.uvl_tune_set(b"attn_cfg", -1)
+    _attention_case(lib, B, H, N, mode, 300 + N, tune=_tune(attn_cfg=cfg))
 
 
 @pytest.mark.parametrize("mode", ["none", "fill", "bert", "bert_all"])
@@ -202,7 +205,7 @@ def test_attention_spike_forces_rescale(lib, B, H, N, tile):
     k[B - 1, H - 1, key + 1] = q[B - 1, H - 1, 3] * (40.0 / QSCALE)          # and one that overflows exp2 against the stale maximum
     add = torch.zeros((B, Npad), device="cuda")
     o = torch.empty((B * N, H * 64), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, 1, _stream()), lib)
+    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, 1, _tref(_tune()), _stream()), lib)
     torch.cuda.synchronize()
     s = (q[:, :, :N].float() @ k[:, :, :N].float().transpose(-1, -2)) * math.log(2.0)
     ref = (s.softmax(-1) @ vt[:, :, :, :N].transpose(2, 3).float()).transpose(1, 2).reshape(B * N, H * 64)
@@ -241,7 +244,7 @@ def test_conv_tower_layer(lib, B, F, cin, cout, slabs):
     y = torch.full((B * S, 4 * cout), float("nan"), dtype=torch.bfloat16, device="cuda")
     scratch = torch.empty((8 * B * S * 4 * cout,), device="cuda") if slabs else None
     _chk(lib.uvl_conv_tower_layer(_p(x), B, F, x_ld, goff, cin, cout, _p(wpk), _p(bpk), _p(y),
-                                  C.c_void_p(scratch.data_ptr() if slabs else 0), _stream()), lib)
+                                  C.c_void_p(scratch.data_ptr() if slabs else 0), None, _stream()), lib)
     torch.cuda.synchronize()
     err = (y.float() - ref).abs()
     assert bool(torch.isfinite(y.float()).all())

@@ -8,16 +8,12 @@ from contextlib import redirect_stdout
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401  (before the library: one HIP runtime in the process)
-from uvltrack_amd import _native  # noqa: E402
 import bench  # noqa: E402
-
-lib = _native.load()
 
 
 def run(k1, k4, extra=()):
-    lib.uvl_tune_set(b"sk_k1", k1)
-    lib.uvl_tune_set(b"sk_k4", k4)
-    sys.argv = ["bench.py", "--no-cpu-baseline", "--no-batched", "--steps", "300", "--warmup", "50", "--blocks", "5", *extra]
+    sys.argv = ["bench.py", "--no-cpu-baseline", "--no-batched", "--steps", "300", "--warmup", "50", "--blocks", "5",
+                "--tune", "sk_k1=%d" % k1, "--tune", "sk_k4=%d" % k4, *extra]
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench.main()

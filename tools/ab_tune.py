@@ -1,4 +1,5 @@
-"""Interleaved A/B of one uvl_tune_set key in a bench.py workload, same box, same process.
+"""Interleaved A/B of one uvl_tune_set key (bench.py --tune key=value: the override lives in that run's model handle) in a bench.py
+workload, same box, same process.
 Usage (GPU box): python tools/ab_tune.py <key> <value A> <value B> [bench.py flags ...]
 e.g.  python tools/ab_tune.py gemm_big 0 1 --model L --batch 8 --template-size 256 --search-size 384 --steps 30 --warmup 5"""
 import io
@@ -9,15 +10,11 @@ from contextlib import redirect_stdout
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401  (before the library: one HIP runtime in the process)
-from uvltrack_amd import _native  # noqa: E402
 import bench  # noqa: E402
-
-lib = _native.load()
 
 
 def run(key, val, extra):
-    lib.uvl_tune_set(key.encode(), val)
-    sys.argv = ["bench.py", "--no-cpu-baseline", "--no-batched", *extra]
+    sys.argv = ["bench.py", "--no-cpu-baseline", "--no-batched", "--tune", "%s=%d" % (key, val), *extra]
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench.main()

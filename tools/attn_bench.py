@@ -9,8 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
-
-
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 def p(t):
     return C.c_void_p(t.data_ptr())
 
@@ -34,9 +33,9 @@ def main():
         vt = torch.randn(B, H, 64, Npad, device="cuda").bfloat16()
         add = torch.zeros(B, Npad, device="cuda")
         o = torch.empty(B * N, H * 64, device="cuda", dtype=torch.bfloat16)
-        fn = lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, 1, st)
+        fn = lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, 1, TUNE.ref(), st)
         for cfg in cfgs:
-            lib.uvl_tune_set(b"attn_cfg", cfg)
+            TUNE.attn_cfg = cfg
             for _ in range(5):
                 fn()
             torch.cuda.synchronize()
@@ -53,7 +52,7 @@ def main():
             us = best
             flops = 4.0 * N * N * H * 64 * B
             print("attention B=%3d H=%2d N=%4d cfg %2d  %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)" % (B, H, N, cfg, us, flops / us / 1e6, flops / us / 1e6 / 25), flush=True)
-    lib.uvl_tune_set(b"attn_cfg", -1)
+    TUNE.attn_cfg = -1
 
 
 if __name__ == "__main__":

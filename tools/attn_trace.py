@@ -40,9 +40,10 @@ def main():
     o = torch.empty(Bn * N, H * 64, device="cuda", dtype=torch.bfloat16)
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    lib.uvl_tune_set(b"attn_cfg", cfg)
+    from uvltrack_amd import _native
+    TUNE = _native.UvlTuning(attn_cfg=cfg)      # per-call override (no process-global tuning state)
     for _ in range(3):
-        lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), Bn, H, N, Npad, 1, st)
+        lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), Bn, H, N, Npad, 1, TUNE.ref(), st)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * (16 + 8 * 32))()
     assert lib.uvl_debug_attn_trace(buf) == 0

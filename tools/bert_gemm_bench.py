@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 p = lambda t: C.c_void_p(t.data_ptr())
 
 
@@ -36,17 +37,17 @@ def main():
         y = torch.empty(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
         res = []
         for cfg, nm in ((4, "64x64 ns3"), (0, "64x64 ns4"), (5, "64x64 ns6"), (7, "64x64 ns2")):
-            lib.uvl_tune_set(b"gemm_cfg", cfg)
-            us = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 0, f32, 0, st))
+            TUNE.gemm_cfg = cfg
+            us = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 0, f32, 0, TUNE.ref(), st))
             res.append("%s %.1f us" % (nm, us))
             if f32:
                 for sk in (2, 4):
                     if (K // 64) % sk:
                         continue
                     slabs = torch.empty(sk, M, N, device="cuda")
-                    us = timeit(lambda: lib.uvl_linear_splitk(p(x), p(w), p(bias), p(slabs), M, N, K, sk, st))
+                    us = timeit(lambda: lib.uvl_linear_splitk(p(x), p(w), p(bias), p(slabs), M, N, K, sk, TUNE.ref(), st))
                     res.append("%s sk%d %.1f us" % (nm, sk, us))
-        lib.uvl_tune_set(b"gemm_cfg", -1)
+        TUNE.gemm_cfg = -1
         print("%-8s M=%d N=%d K=%d | %s" % (name, M, N, K, " | ".join(res)))
 
 

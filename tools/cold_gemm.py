@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 M, N, K = 553, 3072, 768
@@ -28,7 +29,7 @@ def run(evict):
             evict.fill_(1)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 1, 0, 0, st)
+        lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 1, 0, 0, TUNE.ref(), st)
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e3)

@@ -2,6 +2,7 @@ import ctypes as C, sys, torch
 sys.path.insert(0, '/root/repo')
 from uvltrack_amd import _native
 lib = _native.load()
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def timeit(fn, iters=30):
@@ -18,7 +19,7 @@ for M in (4424, 17696):
         bias = torch.randn(N, device='cuda')
         yb = torch.empty(M, N, device='cuda', dtype=torch.bfloat16); yf = torch.zeros(M, N, device='cuda')
         for rep in range(2):
-            t0 = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(yb), M, N, K, 0, 0, 0, st))
-            t1 = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(yf), M, N, K, 0, 1, 0, st))
-            t2 = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(yf), M, N, K, 0, 1, 1, st))
+            t0 = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(yb), M, N, K, 0, 0, 0, TUNE.ref(), st))
+            t1 = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(yf), M, N, K, 0, 1, 0, TUNE.ref(), st))
+            t2 = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(yf), M, N, K, 0, 1, 1, TUNE.ref(), st))
         print("%s M=%d: bf16 out %.1f us | f32 out %.1f us | f32 accumulate %.1f us" % (name, M, t0, t1, t2))

@@ -9,6 +9,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 CFG = {0: "64x64 ns4", 4: "64x64 ns3", 7: "64x64 ns2", 8: "128x64 ns3", 9: "128x64 ns2", 10: "64x128 ns2", 2: "128x128 ns3", 6: "128x128 ns2"}
 
 
@@ -42,21 +43,21 @@ def main():
         for cfg in CFG:
             if cfg in (2, 3, 6, 10) and N % 128:
                 continue
-            lib.uvl_tune_set(b"gemm_cfg", cfg)
+            TUNE.gemm_cfg = cfg
             res = []
             if kind == "bf16":
                 y = torch.empty(M_, N, device="cuda", dtype=torch.bfloat16)
-                us = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M_, N, K, 0, 0, 0, st))
+                us = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M_, N, K, 0, 0, 0, TUNE.ref(), st))
                 res.append("sk1 %6.1f us %6.1f TF" % (us, flops / us / 1e6))
             else:
                 for sk in (1, 2, 4):
                     if (K // 64) % sk:
                         continue
                     slabs = torch.empty(sk, M_, N, device="cuda")
-                    us = timeit(lambda: lib.uvl_linear_splitk(p(x), p(w), p(bias), p(slabs), M_, N, K, sk, st))
+                    us = timeit(lambda: lib.uvl_linear_splitk(p(x), p(w), p(bias), p(slabs), M_, N, K, sk, TUNE.ref(), st))
                     res.append("sk%d %6.1f us %6.1f TF" % (sk, us, flops / us / 1e6))
             print("%-5s M=%5d N=%4d K=%4d  %-12s %s" % (name, M_, N, K, CFG[cfg], " | ".join(res)))
-    lib.uvl_tune_set(b"gemm_cfg", -1)
+    TUNE.gemm_cfg = -1
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 CFGS = {6: "128x128 k64 ns2", 20: "128x128 ns2 +2 producers", 21: "128x128 ns2 +4 producers", 18: "128x128 k32 ns3", 16: "128x128 k32 ns4", 17: "128x128 k32 ns5", 19: "128x128 k32 ns6", 11: "256x256 k64 ns2"}
@@ -51,12 +52,12 @@ for name, M, N, K, act in shapes:
     for cfg, label in CFGS.items():
         if (cfg == 11 and N % 256) or N % 128:
             continue
-        lib.uvl_tune_set(b"gemm_cfg", cfg)
+        TUNE.gemm_cfg = cfg
         y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-        fn = lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, act, 0, 0, st)
+        fn = lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, act, 0, 0, TUNE.ref(), st)
         us = timeit(fn)
         err = (y.float() - ref).abs()
         ok = bool((err <= 1e-2 * ref.abs() + 2e-2).all())
         row.append("%s %6.1f us %6.1f TF%s" % (label, us, flops / us / 1e6, "" if ok else " WRONG(max %.3g)" % float(err.max())))
     print("%-8s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
-lib.uvl_tune_set(b"gemm_cfg", -1)
+TUNE.gemm_cfg = -1

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, M, N, K, sk in (("fc2", 553, 768, 3072, 4), ("proj", 553, 768, 768, 2)):
@@ -19,8 +20,8 @@ for name, M, N, K, sk in (("fc2", 553, 768, 3072, 4), ("proj", 553, 768, 768, 2)
     bias = torch.randn(N, device="cuda")
     slabs = torch.empty(sk, M, N, device="cuda")
     for mode in (0, 1):
-        lib.uvl_tune_set(b"gemm_kxcd", mode)
+        TUNE.gemm_kxcd = mode
         for _ in range(20):
-            lib.uvl_linear_splitk(p(x), p(w), p(bias), p(slabs), M, N, K, sk, st)
+            lib.uvl_linear_splitk(p(x), p(w), p(bias), p(slabs), M, N, K, sk, TUNE.ref(), st)
         torch.cuda.synchronize()
-lib.uvl_tune_set(b"gemm_kxcd", 1)
+TUNE.gemm_kxcd = -1

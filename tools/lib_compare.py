@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
+TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
 CFGS = (4, 7, 9, 10, 6, 11)
 GMS = (0, 8)
 
@@ -42,22 +43,22 @@ def gemms(B, D, ntok):
         bias = torch.randn(N, device="cuda")
         y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         flops = 2.0 * M * N * K
-        lib.uvl_tune_set(b"gemm_cfg", -1)
-        mine = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 0, 0, 0, st))
+        TUNE.gemm_cfg = -1
+        mine = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 0, 0, 0, TUNE.ref(), st))
         best = (mine, "auto")
         allc = []
         for cfg in CFGS:
             if (cfg in (2, 3, 6, 10, 12, 13, 15) and N % 128) or (cfg in (11, 14) and N % 256):
                 continue
-            lib.uvl_tune_set(b"gemm_cfg", cfg)
+            TUNE.gemm_cfg = cfg
             for gm in GMS:
-                lib.uvl_tune_set(b"gemm_gm", gm)
-                us = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 0, 0, 0, st))
+                TUNE.gemm_gm = gm
+                us = timeit(lambda: lib.uvl_linear(p(x), p(w), p(bias), p(y), M, N, K, 0, 0, 0, TUNE.ref(), st))
                 allc.append("%d/g%d:%.0f" % (cfg, gm, flops / us / 1e6))
                 if us < best[0]:
                     best = (us, "cfg%d/g%d" % (cfg, gm))
-        lib.uvl_tune_set(b"gemm_gm", -1)
-        lib.uvl_tune_set(b"gemm_cfg", -1)
+        TUNE.gemm_gm = -1
+        TUNE.gemm_cfg = -1
         bb = bias.bfloat16()
         ven = timeit(lambda: F.linear(x, w, bb))
         print("gemm %-4s M=%6d N=%5d K=%5d | ours auto %7.1f us %6.1f TF | ours best %-9s %7.1f us %6.1f TF | hipBLASLt %7.1f us %6.1f TF"
@@ -73,8 +74,8 @@ def attn(B, H, N):
     add = torch.zeros(B, Npad, device="cuda")
     o = torch.empty(B * N, H * 64, device="cuda", dtype=torch.bfloat16)
     flops = 4.0 * N * N * H * 64 * B
-    lib.uvl_tune_set(b"attn_cfg", -1)
-    mine = timeit(lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, 1, st))
+    TUNE.attn_cfg = -1
+    mine = timeit(lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, 1, TUNE.ref(), st))
     q2, k2, v2 = (torch.randn(B, H, N, 64, device="cuda").bfloat16() for _ in range(3))
     ven = timeit(lambda: F.scaled_dot_product_attention(q2, k2, v2))
     print("attn B=%3d H=%2d N=%4d | ours %7.1f us %6.1f TF | torch SDPA (no mask) %7.1f us %6.1f TF"

@@ -683,8 +683,11 @@ static hipError_t launch_attn_stream(const AttnParams& p_in, hipStream_t s) {
 //     reads | P V MFMAs of block 0 beside the exponentials of block 1 | P V MFMAs of block 1 beside the next tile's DMA issue.
 //     hipcc's own order is all MFMAs, then all exponentials (measured 537 TFLOP/s against the stream kernel's 654 at B = 32,
 //     H = 16, N = 681)
-//   * pass 1 issues a DMA round in EVERY tile (tile index clamped: the last NS-1 rounds re-read the final tile into stages
-//     nobody reads again), so the counted vmcnt wait and the whole tile are branch-free
+//   * pass 1 issues a DMA round only while one is due (do_issue = t + 2 < nt): the tile exists in two phase-1 variants, with
+//     and without the round, and the counted vmcnt waits differ accordingly.  The steady-state LDS reads are inline asm with
+//     hand-counted lgkmcnt waits that hipcc cannot see: their correctness rests on the sched_barrier placement and on hipcc not
+//     inserting an LDS / SMEM operation between them -- re-run the forced attn_cfg = 10 parity cases (masked, tail, pass 2) after
+//     any toolchain change (tests/test_kernels_gpu.py::test_attention_batched_kernels_forced)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float attn_vadd(float a, float b) {   // one v_add_f32, never SLP-packed into v_pk_add_f32 (guide: anti-lever beside MFMAs)
     float d;
@@ -1252,10 +1255,8 @@ static hipError_t launch_attn_cfg(const AttnParams& p_in, hipStream_t s) {
 #ifdef ATTN_TRACE
 extern "C" int uvl_debug_attn_trace(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), (16 + 8 * 32) * sizeof(unsigned long long)); }
 #endif
-int g_tune_attn_cfg = -1;      // tools/attn_bench.py override
-
 static int pick_attn_cfg(const AttnParams& p) {
-    int cfg = g_tune_attn_cfg;
+    int cfg = tune_get(p.tune, &uvl_tuning::attn_cfg, -1);      // tools / tests: index into launch_attention's table
     if (cfg < 0) {
         // measured on MI355X (tools/attn_bench.py sweeps): 128-query workgroups share the K/V tiles once they fill the chip;
         // a single sequence of 5..9 key tiles runs "single shot" (one wave per key tile, every tile in flight) as long as

@@ -401,11 +401,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     }
 }
 
-int g_tune_gemm_kxcd = 1;       // tools: 0 = split-K GEMMs of one or two sequences keep the tile map (A/B of the K-slice map)
-
 // K-slice map (see gemm_glds_body): a split-K GEMM with few M tiles whose slices and N panels divide over the 8 XCDs
 static bool gemm_kxcd_ok(const GemmParams& p, int MT, int NT) {
-    return g_tune_gemm_kxcd && p.splitk > 1 && 8 % p.splitk == 0 && NT % (8 / p.splitk) == 0 && MT < 16 && p.conv_F == 0 && p.groups <= 1;
+    return tune_get(p.tune, &uvl_tuning::gemm_kxcd, 1) && p.splitk > 1 && 8 % p.splitk == 0 && NT % (8 / p.splitk) == 0 && MT < 16 && p.conv_F == 0 && p.groups <= 1;
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV = false, bool NTW = false, int BK = 64, int PROD = 0>
@@ -417,8 +415,9 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     // an L2 AND every XCD gets the same number of tiles -- "XCD x owns N panels x, x+8, ..." left half the XCDs with 2 panels and
     // half with 1 when N = 768 (12 panels): 1378-1405 -> 1468-1499 frames/s in the frame (text branch reused, same box).
     p.group_m = MT >= 16 ? 8 : MT;
-    if (g_tune_gemm_gm >= 0) p.group_m = g_tune_gemm_gm;
-    const bool kxcd = !CONV && g_tune_gemm_gm < 0 && gemm_kxcd_ok(p, MT, NT);
+    const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
+    if (forced_gm >= 0) p.group_m = forced_gm;
+    const bool kxcd = !CONV && forced_gm < 0 && gemm_kxcd_ok(p, MT, NT);
     if (kxcd) p.group_m = -1;
     const int nblk = kxcd ? 8 * MT * (NT / (8 / p.splitk)) : p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * (BK * 2);
@@ -430,17 +429,14 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : PROD ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,64,p>" : BK == 64 ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,32>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
+    if (!name[0]) {
+        if (PROD) snprintf(name, sizeof(name), "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,%d,%d>", BM, BN, WGM, WGN, EPI, NS, (int)CONV, BK, PROD);   // producer count in the name
+        else snprintf(name, sizeof(name), NTW ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,nt>" : BK == 64 ? "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d>" : "gemm_glds_kernel<%d,%d,%d,%d,%d,%d,%d,0,32>", BM, BN, WGM, WGN, EPI, NS, (int)CONV);
+    }
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk, (p.splitk > 1 && !kxcd) ? p.splitk : 1, CONV ? (p.groups > 0 ? p.groups : 1) : 1), dim3(64 * (WGM * WGN + PROD)), lds, s, p);
     return hipGetLastError();
 }
-
-// tuning override for tools/gemm_bench.py: -1 = heuristic, otherwise index into the config table below
-int g_tune_gemm_cfg = -1;
-int g_tune_gemm_gm = -1;
-int g_tune_gemm_prod = 1;       // tools: 0 = the wide bf16-output GEMMs of the batched frames keep the all-waves-load form (A/B)
-int g_tune_gemm_big = 1;        // tools: 0 = never pick the 256x256 tile (A/B of the heuristic)
 
 template <int EPI>
 static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) {
@@ -483,7 +479,8 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
 }
 
 static int pick_plain_cfg(const GemmParams& p) {
-    if (g_tune_gemm_cfg >= 0) return g_tune_gemm_cfg;
+    const int forced = tune_get(p.tune, &uvl_tuning::gemm_cfg, -1);      // tools / tests: index into the table above
+    if (forced >= 0) return forced;
     // measured on MI355X (tools/gemm_bench.py, tools/lib_compare.py, profiles/): co-resident workgroups matter more than
     // ring depth, so the 2-stage ring wins once there are enough tiles; few tiles keep 64x64 for parallelism
     const int mt64 = (p.M + 63) / 64;
@@ -496,8 +493,8 @@ static int pick_plain_cfg(const GemmParams& p) {
     }
     if (t64 < 768) return 4;
     if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
-    if (g_tune_gemm_prod && p.epi != EPI_F32 && p.N >= 3072 && n128 && p.splitk <= 1) return 21;   // 4 consumers + 4 producers (probe 5)
-    if (g_tune_gemm_big && p.N % 256 == 0 && p.K >= 1024 && p.splitk <= 1) {
+    if (tune_get(p.tune, &uvl_tuning::gemm_prod, 1) && p.epi != EPI_F32 && p.N >= 3072 && n128 && p.splitk <= 1) return 21;   // 4 consumers + 4 producers (probe 5)
+    if (tune_get(p.tune, &uvl_tuning::gemm_big, 1) && p.N % 256 == 0 && p.K >= 1024 && p.splitk <= 1) {
         // 256x256 tiles, 8 waves, one workgroup per CU: half the LDS-DMA instructions per MFMA of the 128x128 tile (an LDS-DMA
         // instruction costs its wave ~55 cycles of issue).  Pays where the K loop is long enough to amortise the tile's prologue /
         // epilogue and the tiles fill whole rounds of the 256 CUs: +20 % on fc1 at M = 6984, K = 1024 (448 tiles), +18 % on fc2 at
@@ -549,7 +546,7 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
                (p.splitk == 1 || (p.epi == EPI_F32 && !p.accumulate && (p.K / 64) % p.splitk == 0));
     };
     const bool pairable = plain(a) && plain(b) && a.epi == b.epi && pick_plain_cfg(a) == 4 && pick_plain_cfg(b) == 4 &&
-                          (g_tune_gemm_gm < 0) && (a.M + 63) / 64 < 16 && (b.M + 63) / 64 < 16;
+                          tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0 && (a.M + 63) / 64 < 16 && (b.M + 63) / 64 < 16;
     if (!pairable) {
         const hipError_t e = launch_gemm(a, s);
         return e != hipSuccess ? e : launch_gemm(b, s);

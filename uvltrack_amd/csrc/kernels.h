@@ -3,17 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "common.h"
+#include "../../include/uvltrack_hip.h"
 
 namespace uvl {
 
 // name of the kernel instantiation the last launcher picked (for per-kernel profiles)
 extern thread_local const char* g_last_kernel;
-extern int g_tune_gemm_prod;     // tools: 1 = producer-wave GEMM form for the wide bf16-output GEMMs of batched frames
-extern int g_tune_gemm_kxcd;     // tools: 0 = no K-slice map for the split-K GEMMs of one or two sequences
-extern int g_tune_gemm_big;      // tools: 0 = the GEMM heuristic never picks the 256x256 tile
-extern int g_tune_attn_cfg;      // tools/attn_bench.py override of the attention configuration (-1 = heuristic)
-extern int g_tune_gemm_gm;       // override of the grouped tile order (-1 = heuristic, 0 = panel map, g = group of g M-tiles)
-extern int g_tune_gemm_cfg;      // tools/gemm_bench.py override of the plain-GEMM tile configuration (-1 = heuristic)
+// Overrides of the launch heuristics (include/uvltrack_hip.h: uvl_tuning), owned by a model handle or passed by the caller of a
+// per-kernel entry point -- never process-global.  tune_get(t, &uvl_tuning::field, dflt): the field, or dflt when t is null / -1.
+inline int tune_get(const uvl_tuning* t, int32_t uvl_tuning::*field, int dflt) { return (t && t->*field >= 0) ? t->*field : dflt; }
 
 struct GemmParams {
     const bf16_t* A = nullptr; int lda = 0;      // [M,K] bf16 (plain) or NHWC activations (conv)
@@ -34,6 +32,7 @@ struct GemmParams {
     int a_goff[4] = {0, 0, 0, 0};                // conv mode: channel offset of each group's input inside a row
     int w_stream = 0;                            // 1: W is read once per frame and should not displace resident weights in the
                                                  // Infinity Cache (text branch): non-temporal weight-tile loads where instantiated
+    const uvl_tuning* tune = nullptr;            // host side only: overrides of the launch heuristics (null = heuristics)
     int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
 };
@@ -47,6 +46,7 @@ struct AttnParams {
     bf16_t* o = nullptr;                                      // [B*N, H*64]
     int B = 0, H = 0, N = 0, Npad = 0;
     int xcd_map = 0;                                          // set by the launcher: query blocks of a head share an XCD (see attn_decode_block)
+    const uvl_tuning* tune = nullptr;                         // host side only: overrides of the launch heuristics (null = heuristics)
     int q_prescaled = 0;                                      // 1: q already carries the factor log2(e)/8 (GemmParams.q_scale of the QKV GEMM)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);

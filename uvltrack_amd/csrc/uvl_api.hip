@@ -98,8 +98,15 @@ struct uvl_model {
     // profile of the last profiled call
     std::vector<ProfEntry> prof;
     int debug_stop_layer = -1;          // >= 0: leave the layer loop after this layer (tests localise errors with it)
+    uvl_tuning tune;                    // overrides of the launch heuristics for THIS handle (uvl_tune_set); all -1 = heuristics
+    uvl_model() { uvl_tuning_init(&tune); }
 };
 
+extern "C" void uvl_tuning_init(uvl_tuning* t) {
+    if (!t) return;
+    int32_t* f = reinterpret_cast<int32_t*>(t);
+    for (size_t i = 0; i < sizeof(uvl_tuning) / sizeof(int32_t); ++i) f[i] = -1;
+}
 extern "C" const char* uvl_last_error(void) { return g_err; }
 extern "C" int uvl_version(void) { return 1; }
 
@@ -373,10 +380,9 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
 
 // Split-K factor for an `x += A W^T` GEMM that would otherwise leave most CUs idle (batch-1 shapes): each split
 // writes an f32 slab, the consuming LayerNorm / contrast kernel adds the slabs on read (deterministic, no atomics).
-static int g_tune_sk[2] = {-1, -1};          // uvl_tune_set("sk_k1" / "sk_k4"): split-K of the residual GEMMs with K = D / K = 4 D (-1 = heuristic)
-static int choose_splitk(int M, int N, int K) {
+static int choose_splitk(int M, int N, int K, const uvl_tuning* tune) {
     const int cap = UVL_SKMAX;
-    const int forced = g_tune_sk[K > N ? 1 : 0];
+    const int forced = tune_get(tune, K > N ? &uvl_tuning::sk_k4 : &uvl_tuning::sk_k1, -1);   // uvl_tune_set("sk_k1" / "sk_k4")
     if (forced > 0 && (K / 64) % forced == 0 && forced <= cap) return forced;
     const long tiles = (long)((M + 63) / 64) * (N / 64);
     const int nk = K / 64;
@@ -472,12 +478,12 @@ static hipError_t tramp(void* ctx, hipStream_t s) { return F(*(const P_*)ctx, s)
 // One layer of the four conv towers (heads/utils.py:126-131 with BatchNorm folded, modality_adaptive_box_head.py:28-50): grouped
 // implicit GEMM over NHWC tokens; few output tiles and a long K (9 * Cin) split K into f32 slabs that a small kernel folds (+ReLU).
 static void run_conv_layer(Launcher& L, hipStream_t s, int layer, const bf16_t* x, int in_ld, const int goff[4], const bf16_t* wpk, const float* bias,
-                           int B, int F, int cin, int cout, bf16_t* y, float* slabs) {
+                           int B, int F, int cin, int cout, bf16_t* y, float* slabs, const uvl_tuning* tune) {
     static const char* const conv_site[4] = {"conv3x3.0", "conv3x3.1", "conv3x3.2", "conv3x3.3"};
     GemmParams p;
     p.A = x; p.lda = in_ld; p.W = wpk; p.ldw = 9 * cin; p.bias = bias;
     p.M = B * F * F; p.N = cout; p.K = 9 * cin; p.ldc = 4 * cout;
-    p.groups = 4; p.conv_F = F; p.cin_g = cin;
+    p.groups = 4; p.conv_F = F; p.cin_g = cin; p.tune = tune;
     for (int g = 0; g < 4; ++g) p.a_goff[g] = goff[g];
     const long tiles = (long)((p.M + 63) / 64) * (p.N / 64 > 0 ? p.N / 64 : 1) * 4;
     const int nk = p.K / 64;
@@ -512,10 +518,10 @@ static int run_prompter(uvl_model* m, const Workspace& w, int B, const float* te
     HIPCHK(launch_prompter_tokens(p, s));
     {   // src = mlp(src) + src  (utils.py:94)
         GemmParams g;
-        g.A = w.Xn; g.lda = D; g.W = m->pr_w1; g.ldw = D; g.bias = m->pr_b1; g.M = 3 * B; g.N = Fn; g.K = D; g.epi = 0; g.C = w.Hb; g.ldc = Fn; g.act = 1;
+        g.A = w.Xn; g.lda = D; g.W = m->pr_w1; g.ldw = D; g.bias = m->pr_b1; g.M = 3 * B; g.N = Fn; g.K = D; g.epi = 0; g.C = w.Hb; g.ldc = Fn; g.act = 1; g.tune = &m->tune;
         HIPCHK(launch_gemm(g, s));
         GemmParams h;
-        h.A = w.Hb; h.lda = Fn; h.W = m->pr_w2; h.ldw = Fn; h.bias = m->pr_b2; h.M = 3 * B; h.N = D; h.K = Fn; h.epi = 1; h.C = src; h.ldc = D; h.accumulate = 1;
+        h.A = w.Hb; h.lda = Fn; h.W = m->pr_w2; h.ldw = Fn; h.bias = m->pr_b2; h.M = 3 * B; h.N = D; h.K = Fn; h.epi = 1; h.C = src; h.ldc = D; h.accumulate = 1; h.tune = &m->tune;
         HIPCHK(launch_gemm(h, s));
     }
     HIPCHK(launch_prompter_select(src, src0, flag, prompt_out, B, 3 * D, s));
@@ -566,6 +572,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     struct LnPair { LnParams a, b; };
     // launch a visual kernel; if the next waiting text kernel is of the same kind (and, for GEMMs, the same epilogue), take it along
     auto run_gemm = [&](hipStream_t st, GemmParams& p, const char* what, bool is_text) {
+        p.tune = &m->tune;
         // BERT weights are read once per frame: up to four sequences (<= 3 M tiles share a weight tile through L2) they are loaded
         // non-temporal so that they do not displace the ViT weights from the Infinity Cache (+2-3 % at 2-4 sequences, -0.5 % from 8 on)
         if (is_text && p.M <= 192) p.w_stream = 1;
@@ -580,6 +587,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         L.run(st, what, fl, by, tramp<GemmParams, launch_gemm>, &p);
     };
     auto run_attn = [&](hipStream_t st, AttnParams& p, const char* what, double fl, double by, bool is_text) {
+        p.tune = &m->tune;
         if (paired && is_text) { Rider r{}; r.kind = R_ATTN; r.what = what; r.flops = fl; r.bytes = by; r.a = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_ATTN) {
             AttnPair ap{p, riders[rider_at].a};
@@ -642,7 +650,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                              int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false) {
         GemmParams p;
         p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
-        const int sk = allow_split ? choose_splitk(Mr, D, K) : 1;
+        const int sk = allow_split ? choose_splitk(Mr, D, K, &m->tune) : 1;
         if (sk > 1) {             // slabs [sk][Mr, D], folded in by the next LayerNorm / contrast kernel
             p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D;
             pd.part = slab; pd.nsplit = sk; pd.rows = rpb; pd.stride = p.part_stride;
@@ -723,7 +731,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         GemmParams p;
         p.A = w.P; p.lda = 768; p.W = m->w_patch; p.ldw = 768; p.bias = m->b_patch;
         p.M = B * (nz + nx); p.N = D; p.K = 768; p.epi = 1; p.C = w.X; p.ldc = D;
-        p.rpb = nz + nx; p.obs = nj; p.oro = 1; p.addtab = m->pos_tab;
+        p.rpb = nz + nx; p.obs = nj; p.oro = 1; p.addtab = m->pos_tab; p.tune = &m->tune;
         RUN_GEMM(L, s, p, "gemm.patch");
     }
     int cont_slot = 0;
@@ -862,7 +870,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         const ConvLayerW& cw = m->conv[l];
         int goff[4];
         for (int g = 0; g < 4; ++g) goff[g] = (l == 0) ? ((g == 0 && m->cfg.cls_tokenize) ? D : 0) : g * cw.cin;
-        run_conv_layer(L, s, l, cin[l], in_ld[l], goff, cw.w, cw.b, B, m->F, cw.cin, cw.cout, cout[l], w.ConvPart);
+        run_conv_layer(L, s, l, cin[l], in_ld[l], goff, cw.w, cw.b, B, m->F, cw.cin, cw.cout, cout[l], w.ConvPart, &m->tune);
     }
     {
         HeadTailParams p;
@@ -914,16 +922,15 @@ extern "C" int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* 
     return UVL_OK;
 }
 
-extern "C" int uvl_tune_set(const char* key, int value) {
-    if (!key) return fail(UVL_EINVAL, "null key");
-    if (!strcmp(key, "gemm_cfg")) { uvl::g_tune_gemm_cfg = value; return UVL_OK; }
-    if (!strcmp(key, "gemm_gm")) { uvl::g_tune_gemm_gm = value; return UVL_OK; }
-    if (!strcmp(key, "attn_cfg")) { uvl::g_tune_attn_cfg = value; return UVL_OK; }
-    if (!strcmp(key, "gemm_big")) { uvl::g_tune_gemm_big = value; return UVL_OK; }
-    if (!strcmp(key, "gemm_kxcd")) { uvl::g_tune_gemm_kxcd = value; return UVL_OK; }
-    if (!strcmp(key, "gemm_prod")) { uvl::g_tune_gemm_prod = value; return UVL_OK; }
-    if (!strcmp(key, "sk_k1")) { g_tune_sk[0] = value; return UVL_OK; }
-    if (!strcmp(key, "sk_k4")) { g_tune_sk[1] = value; return UVL_OK; }
+extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
+    if (!m || !key) return fail(UVL_EINVAL, "uvl_tune_set: null argument");
+    static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
+        {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
+        {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}};
+    for (const auto& k : keys)
+        if (!strcmp(key, k.key)) { m->tune.*(k.field) = value < 0 ? -1 : value; return UVL_OK; }
+    if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown tuning key '%s'", key);
 }
 
@@ -1143,21 +1150,22 @@ extern "C" int uvl_normalize_u8(const uint8_t* d_patch_hwc, int height, int widt
 
 // ---- per-kernel entry points -----------------------------------------------------------------------
 extern "C" int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
-                          int accumulate, void* stream) {
+                          int accumulate, const uvl_tuning* tune, void* stream) {
     if (!d_x || !d_w || !d_y || M <= 0 || N % 32 != 0 || K % 64 != 0) return fail(UVL_EINVAL, "uvl_linear: need N %% 32 == 0 and K %% 64 == 0");
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
-    p.epi = out_f32 ? 1 : 0; p.C = d_y; p.ldc = N; p.act = act; p.accumulate = accumulate;
+    p.epi = out_f32 ? 1 : 0; p.C = d_y; p.ldc = N; p.act = act; p.accumulate = accumulate; p.tune = tune;
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
 
 /* tuning entry: y[sk] (f32 slabs [splitk][M,N]) = partial sums over K-range sk (bias in slab 0) */
-extern "C" int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, float* d_slabs, int M, int N, int K, int splitk, void* stream) {
+extern "C" int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, float* d_slabs, int M, int N, int K, int splitk,
+                                 const uvl_tuning* tune, void* stream) {
     if (!d_x || !d_w || !d_slabs || M <= 0) return fail(UVL_EINVAL, "uvl_linear_splitk: bad argument");
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
-    p.epi = 1; p.C = d_slabs; p.ldc = N; p.splitk = splitk; p.part_stride = (size_t)M * N;
+    p.epi = 1; p.C = d_slabs; p.ldc = N; p.splitk = splitk; p.part_stride = (size_t)M * N; p.tune = tune;
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
@@ -1172,30 +1180,32 @@ extern "C" int uvl_fold_conv_bn(const float* d_w, const float* d_b, const float*
 }
 
 extern "C" int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_ld, const int32_t x_group_offset[4], int cin, int cout,
-                                    const void* d_w_packed, const float* d_bias_folded, void* d_y, float* d_slabs, void* stream) {
+                                    const void* d_w_packed, const float* d_bias_folded, void* d_y, float* d_slabs, const uvl_tuning* tune, void* stream) {
     if (!d_x || !d_w_packed || !d_bias_folded || !d_y || !x_group_offset || batch <= 0 || feat <= 0) return fail(UVL_EINVAL, "uvl_conv_tower_layer: bad argument");
     if (cin % 64 != 0 || cout % 32 != 0) return fail(UVL_EINVAL, "uvl_conv_tower_layer: need cin %% 64 == 0 and cout %% 32 == 0");
     Launcher L{nullptr};
     int goff[4] = {x_group_offset[0], x_group_offset[1], x_group_offset[2], x_group_offset[3]};
     run_conv_layer(L, (hipStream_t)stream, 0, (const bf16_t*)d_x, x_ld, goff, (const bf16_t*)d_w_packed, d_bias_folded, batch, feat, cin, cout,
-                   (bf16_t*)d_y, d_slabs);
+                   (bf16_t*)d_y, d_slabs, tune);
     return L.err;
 }
 
-extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o, int B, int H, int N, int Npad, int q_prescaled, void* stream) {
+extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o, int B, int H, int N, int Npad, int q_prescaled,
+                             const uvl_tuning* tune, void* stream) {
     if (!d_q || !d_k || !d_vt || !d_key_add || !d_o) return fail(UVL_EINVAL, "uvl_attention: null pointer");
     AttnParams p;
     p.q = (const bf16_t*)d_q; p.k = (const bf16_t*)d_k; p.vt = (const bf16_t*)d_vt; p.key_add = d_key_add; p.key_add_stride = Npad;
-    p.o = (bf16_t*)d_o; p.B = B; p.H = H; p.N = N; p.Npad = Npad; p.q_prescaled = q_prescaled ? 1 : 0;
+    p.o = (bf16_t*)d_o; p.B = B; p.H = H; p.N = N; p.Npad = Npad; p.q_prescaled = q_prescaled ? 1 : 0; p.tune = tune;
     HIPCHK(launch_attention(p, (hipStream_t)stream));
     return UVL_OK;
 }
 
-extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream) {
+extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
+                               const uvl_tuning* tune, void* stream) {
     if (!d_x || !d_w || !d_q || !d_k || !d_vt || D % 64 != 0) return fail(UVL_EINVAL, "uvl_qkv_project: bad argument");
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = D; p.W = (const bf16_t*)d_w; p.ldw = D; p.bias = d_bias; p.M = B * N; p.N = 3 * D; p.K = D;
-    p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale;
+    p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale; p.tune = tune;
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }

@@ -68,6 +68,26 @@ class HipEngine:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ tuning (tools / tests)
+    def tune_set(self, key: str, value: int):
+        """uvl_tune_set on THIS engine's handle (there is no process-global tuning state); -1 restores the heuristic."""
+        _native.check(self.lib.uvl_tune_set(self.handle, key.encode(), int(value)), "uvl_tune_set(%s)" % key)
+
+    def tuned(self, **kw):
+        """Context manager: `with eng.tuned(gemm_cfg=11): ...` -- the keys are reset to their heuristics on exit, whatever happens."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            try:
+                for k, v in kw.items():
+                    self.tune_set(k, v)
+                yield self
+            finally:
+                for k in kw:
+                    self.tune_set(k, -1)
+        return cm()
+
     # ------------------------------------------------------------------ weights
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

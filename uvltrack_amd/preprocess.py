@@ -83,19 +83,18 @@ class WindowUploader:
     HEADER = 256
 
     def __init__(self, max_side: int = 0, device="cuda"):
-        """Buffers are sized lazily from the first window (max_side = 0) and grow when a later window is larger -- a target that
-        fills a 4K frame needs a bigger window than one in 720p video, and a batch tracker holds one uploader per sequence."""
+        """Buffers always exist: a small one from construction (or max_side x max_side pixels when given), replaced on the first
+        frame by one that holds a whole frame -- a window never exceeds the frame it is cut from, so after that the buffers only
+        grow if a larger frame arrives (a batch tracker holds one uploader per sequence; growing mid-sequence would stall them all)."""
         self.device = device
-        self.max_side = 0
-        if max_side:
-            self._resize(max_side)
+        self.capacity = 0
+        self._resize(max(int(max_side), 64) ** 2 * 3)
 
-    def _resize(self, side: int):
-        side = int(side)
-        n = self.HEADER + side * side * 3
+    def _resize(self, pixel_bytes: int):
+        n = self.HEADER + int(pixel_bytes)
         self.stage = torch.empty(n, dtype=torch.uint8).pin_memory()       # flat: every window is one contiguous copy
         self.dev = torch.empty(n, dtype=torch.uint8, device=self.device)
-        self.max_side = side
+        self.capacity = int(pixel_bytes)
         self._stage_np = self.stage.numpy()                               # views made once: no tensor slicing per frame
         self._meta_np = self._stage_np[:28].view(np.float32)
         self._meta_dev = self.dev[:28].view(torch.float32)
@@ -115,11 +114,11 @@ class WindowUploader:
         x0, x1 = g.x1 + g.x1_pad, g.x1 + g.crop_sz - g.x2_pad
         y0, y1 = g.y1 + g.y1_pad, g.y1 + g.crop_sz - g.y2_pad
         ww, wh = x1 - x0, y1 - y0
-        if ww > self.max_side or wh > self.max_side:
-            # grow (rare: the first frame, or a target that got much larger); the previous device buffer may still be read by a
-            # queued kernel, so let the stream finish before it is released
-            torch.cuda.current_stream(self.dev.device if self.max_side else None).synchronize()
-            self._resize(max(64, int(1.25 * max(ww, wh)) + 16))
+        if ww * wh * 3 > self.capacity:
+            # grow to a whole frame (the first frame, or a larger video): the previous device buffer may still be read by a queued
+            # kernel, so let the stream finish before it is released
+            torch.cuda.current_stream(self.dev.device).synchronize()
+            self._resize(max(H * W * 3, ww * wh * 3))
         nbytes = wh * ww * 3
         hdr = self.HEADER
         np.copyto(self._stage_np[hdr:hdr + nbytes].reshape(wh, ww, 3), im[y0:y1, x0:x1])   # host gather into pinned memory

@@ -52,7 +52,7 @@ class BoxGatherer:
         if tuple(local_boxes.shape) != (n_local, 4):
             raise ValueError("expected [%d, 4] local boxes, got %s" % (n_local, tuple(local_boxes.shape)))
         self._in[k][:n_local].copy_(local_boxes)
-        if self.world > 1:
+        if dist.is_initialized():          # also a group of ONE rank: the collective leg (RCCL on GPUs) is the same code at every world size
             self._pending[k] = dist.all_gather_into_tensor(self._out[k], self._in[k], group=self.group, async_op=True)
         else:
             self._out[k].copy_(self._in[k])
