@@ -12,6 +12,7 @@
 // XOR-swizzled (on the per-lane DMA source address and again on the fragment read) so ds_read_b128 is conflict-free.
 // The workgroup -> tile map is XCD-aware (see gemm_glds_body).
 #include <cstdio>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -95,32 +96,37 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 }
             }
         if constexpr (EPI == EPI_F32) {
-            // the table / residual operands of all row groups are requested together (one wait), then added in the same order
+            // the table / residual operands of a chunk of row groups are requested together (one wait), then added in the same order;
+            // the chunk is all 32 rows except where the accumulators already fill half the register file (128 x 64 per wave)
             constexpr int NIT = 32 / RPI;
-            f32x4 v[NIT], tv[NIT], ov[NIT];
-            float* dst[NIT];
-            bool inb[NIT];
+            constexpr int CH = (TM * TN >= 8 && NIT > 4) ? 4 : NIT;
             const int c16 = lane % LPR, col = colw + c16 * (16 / ES);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int r = it * RPI + lane / LPR;
-                const int row = m0 + wm * WM + i * 32 + r;
-                inb[it] = row < p.M;
-                const int rc = inb[it] ? row : p.M - 1;
-                const int b = rc / p.rpb, rem = rc - b * p.rpb;
-                v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
-                dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
-                if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
-            }
-            if (p.accumulate) {
+            for (int h0 = 0; h0 < NIT; h0 += CH) {
+                f32x4 v[CH], tv[CH], ov[CH];
+                float* dst[CH];
+                bool inb[CH];
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) ov[it] = *reinterpret_cast<const f32x4*>(dst[it]);
-            }
+                for (int it = 0; it < CH; ++it) {
+                    const int r = (h0 + it) * RPI + lane / LPR;
+                    const int row = m0 + wm * WM + i * 32 + r;
+                    inb[it] = row < p.M;
+                    const int rc = inb[it] ? row : p.M - 1;
+                    const int b = rc / p.rpb, rem = rc - b * p.rpb;
+                    v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
+                    dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
+                    if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
+                }
+                if (p.accumulate) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                if (p.addtab) v[it] += tv[it];
-                if (p.accumulate) v[it] += ov[it];
-                if (inb[it]) *reinterpret_cast<f32x4*>(dst[it]) = v[it];
+                    for (int it = 0; it < CH; ++it) ov[it] = *reinterpret_cast<const f32x4*>(dst[it]);
+                }
+#pragma unroll
+                for (int it = 0; it < CH; ++it) {
+                    if (p.addtab) v[it] += tv[it];
+                    if (p.accumulate) v[it] += ov[it];
+                    if (inb[it]) *reinterpret_cast<f32x4*>(dst[it]) = v[it];
+                }
             }
             continue;
         }
@@ -380,6 +386,250 @@ __global__ __launch_bounds__(64 * (WGM * WGN + PROD), PROD ? (2 * (WGM * WGN + P
     gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Phase-pipelined 256-wide GEMM for frames of many sequences (M >= ~4k rows): BM x 256 tile, 8 waves as 2 (M) x 4 (N), a wave owns
+// (BM/2) x 64 of the output (128 x 64 at BM = 256: 128 accumulator registers, 0.75 fragment reads and 0.25 LDS-DMA instructions per
+// MFMA -- the loop of gemm_glds_body pays 1.0 and 0.5 at 128 x 128).  What bounds gemm_glds_body at these sizes is not issue alone
+// but its shape (profiles/r03_gemm_pipe.md, ISA of the 256 x 256 instantiation): two ring stages mean `s_waitcnt vmcnt(0)` in front
+// of EVERY K step -- a K step costs a whole L2 -> LDS round trip -- and hipcc emits the fragment reads four at a time, each group
+// followed by `lgkmcnt(0)` and four MFMAs, so neither memory level overlaps the matrix pipe inside a wave.  Here:
+//   * a K tile (64 wide) is FOUR phases of 8 MFMAs (one quadrant of the wave's block: A rows lo/hi x B columns lo/hi, visited
+//     lo-lo, lo-hi, hi-hi, hi-lo so that one operand's fragments stay in registers between phases);
+//   * the two wave groups of a workgroup (wm = 0 / 1: waves w and w + 4 share a SIMD) run HALF A PHASE APART -- group 1 executes one
+//     extra s_barrier up front -- so on every SIMD one wave issues its phase's MFMAs (s_setprio 1) while the other issues the next
+//     phase's fragment reads and LDS-DMA, two raw s_barriers per phase keeping them in that relation;
+//   * a K tile is staged as four GROUPS of rows -- exactly what each phase reads (A-lo, B-lo | B-hi | A-hi | -) -- into two 64-KB
+//     buffers; every phase issues one group (2 LDS-DMA instructions per wave) SIX groups ahead of the one read next and waits with a
+//     COUNTED vmcnt that leaves the four youngest groups (64 KB per CU) in flight: a group has >= 4 phases to land, and no wait in
+//     the loop ever drains the queue.  Write-after-read: a group's slot is re-filled two phases after its last read (the reads of
+//     phase p by BOTH wave groups are complete at the second barrier after p); read-after-write: a wave waits for its own pieces in
+//     phase p, all waves have done so by the end of p, the group is read in p + 1.
+// Epilogue, tile order and the split of rows over lanes are those of gemm_glds_body (same gemm_epilogue_lds).
+// ------------------------------------------------------------------------------------------------
+// VAR 1 (the product form): the phase's two LDS-DMA instructions are issued BETWEEN its MFMAs (behind the 2nd and the 5th) instead of
+// in front of the barrier -- an LDS-DMA instruction costs the issuing wave 60-120 cycles, which the other wave group's 256-cycle MFMA
+// block cannot hide together with up to 12 fragment reads; between MFMAs it rides on the matrix pipe's own latency (+2..5 % at
+// 256 x 256, +5..9 % at 128 x 256; VAR 0 is kept as cfg 32 / 33 for the A/B).
+template <int BM, int EPI, int VAR = 0>
+__device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx, char* smem) {
+    constexpr int BN = 256, NW = 8, WGN = 4, WM = BM / 2, WN = 64, TM = WM / 32, TN = 2, HB = TM / 2;   // HB: A blocks of a half (lo / hi)
+    constexpr int STAGE = (BM + BN) * 128;                   // one K tile: A rows then W rows, 128 bytes each
+    constexpr int NA = BM / 128, NB = 2;                     // LDS-DMA instructions per wave for an A group / a B group (8 rows each)
+    constexpr int LPT = 2 * NA + 2 * NB;                     // ... per K tile
+    static_assert(BM == 256 || BM == 128, "tile height");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
+    int nt, mt;
+    {   // grouped tile order cut into 8 contiguous runs, one per XCD (see gemm_glds_body)
+        const int xcd = bx & 7, idx = bx >> 3;
+        const int T = MT * NT, base = T >> 3, rem = T & 7;
+        const int cnt = base + (xcd < rem ? 1 : 0);
+        if (idx >= cnt) return;
+        const int L = xcd * base + (xcd < rem ? xcd : rem) + idx;
+        const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
+        const int gm = min(p.group_m, MT - gi * p.group_m);
+        nt = within / gm;
+        mt = gi * p.group_m + (within - nt * gm);
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
+
+    // ---- LDS-DMA plan.  Group g of a K tile: 0 = A-lo (rows wm' * WM + [0, WM/2) of both wave groups), 1 = B-lo (rows wn' * 64 + [0, 32)
+    // of the four wave columns), 2 = B-hi, 3 = A-hi.  Instruction n of a group, issued by this wave, fills 8 consecutive tile rows.
+    uint32_t loff[4][2];                                     // per-lane source byte offset (row * ld * 2 + swizzled 16-byte chunk)
+    int dst[4][2];                                           // wave-uniform LDS byte offset of the 8-row piece inside a K-tile buffer
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const bool isA = (g == 0 || g == 3), hi = (g >= 2);
+#pragma unroll
+        for (int n = 0; n < (isA ? NA : NB); ++n) {
+            const int gr0 = 8 * (wave + NW * n);             // first row of the piece within the group
+            const int R0 = isA ? (gr0 / (WM / 2)) * WM + (hi ? WM / 2 : 0) + gr0 % (WM / 2) : (gr0 / 32) * 64 + (hi ? 32 : 0) + gr0 % 32;
+            const int R = R0 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((R >> 1) & 7);
+            dst[g][n] = (isA ? 0 : BM * 128) + R0 * 128;
+            if (isA) {
+                int gmr = m0 + R;
+                gmr = gmr < p.M ? gmr : p.M - 1;
+                loff[g][n] = (uint32_t)(gmr - m0) * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
+            } else {
+                loff[g][n] = (uint32_t)R * (uint32_t)p.ldw * 2u + (uint32_t)chunk * 16u;
+            }
+        }
+    }
+    auto pin = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    auto issue_part = [&](auto G, int kt, int n0_, int n1_) __attribute__((always_inline)) {      // instructions [n0_, n1_) of group G of K tile kt
+        constexpr int g = decltype(G)::value;
+        constexpr bool isA = (g == 0 || g == 3);
+        const char* gb = pin((isA ? a_base : w_base) + (size_t)kt * 128);
+        char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int n = 0; n < (isA ? NA : NB); ++n)
+            if (n >= n0_ && n < n1_)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + loff[g][n]),
+                                                 (__attribute__((address_space(3))) void*)(st + dst[g][n]), 16, 0, 0);
+    };
+    auto issue = [&](auto G, int kt) __attribute__((always_inline)) { issue_part(G, kt, 0, 2); };      // group G of K tile kt into buffer kt & 1
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ---- fragment addresses: row = block row + (lane & 31), 16-byte chunk 2 ks + (lane >> 5), XOR-swizzled by the row
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a_off[ks] = swz128(wm * WM + (lane & 31), ks * 2 + (lane >> 5));
+        b_off[ks] = BM * 128 + swz128(wn * WN + (lane & 31), ks * 2 + (lane >> 5));
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 af[HB][4], bl[4], bh[4];
+
+    const int nk = p.K / 64;                                 // >= 2 (launcher)
+    // the tile's 256 bias values: requested before the first DMA (so the first tile wait retires them), parked in LDS behind the
+    // ring -- 32 registers per lane cannot be held across the loop, and fetched behind it they cost a dependent L2 round trip per tile
+    float* sbias = reinterpret_cast<float*>(smem + 2 * STAGE);
+    // (load and LDS store are inline asm: hipcc would drain the whole DMA queue -- s_waitcnt vmcnt(0) -- in front of the first use of
+    // an ordinary load's result and in front of an LDS store while LDS-DMA is in flight; the counted wait below covers the load)
+    f32x4 bias_in;
+    if (wave == 0) {
+        const float* bsrc = (p.bias ? p.bias + n0 : reinterpret_cast<const float*>(g_zero_page)) + lane * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_in) : "v"(bsrc) : "memory");
+    }
+    // prologue: K tile 0 and the first two groups of K tile 1; A-lo / B-lo of tile 0 must have landed before phase 0 reads them
+    issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I3{}, 0); issue(I0{}, 1); issue(I1{}, 1);
+    wait_vmcnt<LPT>();
+    if (wave == 0) {
+        const uint32_t sb_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 2 * STAGE + lane * 16;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(sb_addr), "v"(bias_in) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // wave group 1 runs half a phase behind group 0 from here on
+
+    // one phase: fragment reads of quadrant Q | the group due this phase | counted wait | barrier | 8 MFMAs | barrier
+    auto phase = [&](auto Q, auto ISS, auto VM, int t) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value;
+        constexpr bool iss = decltype(ISS)::value != 0;
+        constexpr int vm = decltype(VM)::value;
+        const char* sb = smem + (t & 1) * STAGE;
+        if constexpr (q == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bl[ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (q == 0 || q == 2) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(sb + a_off[ks] + ((q == 2 ? HB : 0) + i) * 4096);
+        }
+        if constexpr (q == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bh[ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[ks] + 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto issue_now = [&](int n0_, int n1_) __attribute__((always_inline)) {   // group (q + 2) % 4 of K tile t + 1 (q < 2) or t + 2
+            if constexpr (q == 0) issue_part(I2{}, t + 1, n0_, n1_);
+            if constexpr (q == 1) issue_part(I3{}, t + 1, n0_, n1_);
+            if constexpr (q == 2) issue_part(I0{}, t + 2, n0_, n1_);
+            if constexpr (q == 3) issue_part(I1{}, t + 2, n0_, n1_);
+        };
+        constexpr int cnt_g = (q == 1 || q == 2) ? NA : NB;  // instructions of the group this phase issues
+        if constexpr (VAR == 0 && iss) issue_now(0, 2);
+        // VAR 1 waits BEFORE its issue: one group fewer may be outstanding
+        constexpr int vm_eff = (VAR == 1 && iss) ? vm - cnt_g : vm;
+        if constexpr (vm >= 0) wait_vmcnt<(vm_eff >= 0 ? vm_eff : 0)>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int i0 = (q >= 2) ? HB : 0, j = (q == 1 || q == 2) ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(j ? bh[ks] : bl[ks], af[i][ks], acc[i0 + i][j], 0, 0, 0);
+                if constexpr (VAR == 1 && iss) {
+                    constexpr int NM = 4 * HB;               // MFMAs of the phase
+                    const int mi = ks * HB + i;
+                    if (mi == NM / 4) { __builtin_amdgcn_sched_barrier(0); issue_now(0, 1); __builtin_amdgcn_sched_barrier(0); }
+                    if (mi == (5 * NM) / 8) { __builtin_amdgcn_sched_barrier(0); issue_now(1, 2); __builtin_amdgcn_sched_barrier(0); }
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using Y = std::integral_constant<int, 1>; using N_ = std::integral_constant<int, 0>;
+    using VF = std::integral_constant<int, LPT>;             // steady state: the four youngest groups stay in flight
+    for (int t = 0; t < nk - 2; ++t) {
+        phase(I0{}, Y{}, VF{}, t); phase(I1{}, Y{}, VF{}, t); phase(I2{}, Y{}, VF{}, t); phase(I3{}, Y{}, VF{}, t);
+    }
+    {   // last two K tiles: nothing left to issue after (nk - 2, phase 1); the allowed in-flight count shrinks group by group
+        const int t = nk - 2;
+        phase(I0{}, Y{}, VF{}, t); phase(I1{}, Y{}, VF{}, t);
+        phase(I2{}, N_{}, std::integral_constant<int, NB + NB + NA>{}, t);
+        phase(I3{}, N_{}, std::integral_constant<int, NB + NA>{}, t);
+        phase(I0{}, N_{}, std::integral_constant<int, NA>{}, t + 1);
+        phase(I1{}, N_{}, std::integral_constant<int, 0>{}, t + 1);
+        phase(I2{}, N_{}, std::integral_constant<int, -1>{}, t + 1);
+        phase(I3{}, N_{}, std::integral_constant<int, -1>{}, t + 1);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // group 0 waits for group 1's last phase
+
+    f32x4 bias_v[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5));
+    static_assert(32 * (WN * 4 + 16) * NW <= 2 * STAGE, "epilogue staging fits in the two buffers");
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
+}
+
+template <int BM, int EPI, int VAR>
+__global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_pipe_body<BM, EPI, VAR>(p, blockIdx.x, smem);
+}
+
+template <int BM, int EPI, int VAR = 0>
+static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (p.N % 256 != 0 || p.K < 128 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return hipErrorInvalidValue;
+    const int MT = (p.M + BM - 1) / BM, NT = p.N / 256;
+    p.group_m = MT >= 16 ? 8 : MT;
+    const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
+    if (forced_gm > 0) p.group_m = forced_gm;
+    const int nblk = 8 * ((MT * NT + 7) / 8);
+    constexpr size_t lds = 2 * (size_t)(BM + 256) * 128 + 1024;      // two K-tile buffers + the tile's bias row
+    auto kern = gemm_pipe_kernel<BM, EPI, VAR>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[48];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_kernel<%d,%d,%d>", BM, EPI, VAR);
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
 // visual GEMM of the same kind).  1-D grid: problem A owns [0, blocks_a) = tiles_a x splitk_a, problem B the rest; tile
 // counts are multiples of 8, so the workgroup -> XCD relation of both tile maps is preserved.
@@ -438,8 +688,20 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Ring depth of the one-sequence tile (64 x 64, 16 KB per stage; two workgroups per CU up to 5 stages = 80 KB): 3 unless a tool
+// overrides it (uvl_tuning.ring1).  The weights of a one-sequence frame stream from HBM and a K step waits for (latency / tiles in flight).
+static int ring1_depth(const GemmParams& p) {
+    const int r = tune_get(p.tune, &uvl_tuning::ring1, 3);
+    return (r >= 3 && r <= 5) ? r : 3;
+}
+
 template <int EPI>
 static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) {
+    if (cfg == 4 && ring1_depth(p) != 3) {
+        const bool ns5 = ring1_depth(p) == 5;
+        if (p.w_stream) return ns5 ? launch_glds<64, 64, 2, 2, EPI, 5, false, true>(p, s) : launch_glds<64, 64, 2, 2, EPI, 4, false, true>(p, s);
+        return ns5 ? launch_glds<64, 64, 2, 2, EPI, 5>(p, s) : launch_glds<64, 64, 2, 2, EPI, 4>(p, s);
+    }
     if (p.w_stream) {                      // the configurations the text branch resolves to (M = 40 rows per sequence)
         switch (cfg) {
             case 4: return launch_glds<64, 64, 2, 2, EPI, 3, false, true>(p, s);
@@ -474,6 +736,11 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         // producer waves: the consumers issue no LDS-DMA
         case 20: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 2>(p, s);  // 4 consumers + 2 producers, 2 workgroups per CU (3 waves / SIMD)
         case 21: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 4>(p, s);  // 4 + 4, 2 per CU (4 waves / SIMD: 128 registers)
+        // phase-pipelined 256-wide tiles (gemm_pipe_body)
+        case 30: return launch_pipe<256, EPI, 1>(p, s);      // product form: LDS-DMA issued between the MFMAs
+        case 31: return launch_pipe<128, EPI, 1>(p, s);
+        case 32: return launch_pipe<256, EPI, 0>(p, s);      // LDS-DMA issued in front of the barrier (A/B: -2..-9 %)
+        case 33: return launch_pipe<128, EPI, 0>(p, s);
     }
     return hipErrorInvalidValue;
 }
@@ -493,6 +760,16 @@ static int pick_plain_cfg(const GemmParams& p) {
     }
     if (t64 < 768) return 4;
     if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
+    if (tune_get(p.tune, &uvl_tuning::gemm_pipe, 1) && p.N % 256 == 0 && p.K >= 128 && p.splitk <= 1 && !(p.epi == EPI_F32 && p.K < 2048)) {
+        // phase-pipelined 256-wide tiles (gemm_pipe_body), one workgroup per CU: taken where the tiles fill >= 80 % of whole rounds
+        // of the 256 CUs -- 256 x 256 first (7.8 bytes of LDS fill per KFLOP, 0.75 fragment reads per MFMA), else 128 x 256.  One
+        // workgroup per CU exposes the epilogue, so the read-modify-write f32 epilogue only takes it behind a long K loop (fc2).
+        // Measured against the 128 x 128 loop in isolation (tools/gemm_pipe_ab.py, profiles/r03_gemm_pipe.md): +5..+25 %.
+        auto fill = [](long t) { const long rounds = (t + 255) / 256; return (double)t / (double)(rounds * 256); };
+        const long nt256 = p.N / 256;
+        if (fill((long)((p.M + 255) / 256) * nt256) >= 0.8) return 30;
+        if (fill((long)((p.M + 127) / 128) * nt256) >= 0.8) return 31;
+    }
     if (tune_get(p.tune, &uvl_tuning::gemm_prod, 1) && p.epi != EPI_F32 && p.N >= 3072 && n128 && p.splitk <= 1) return 21;   // 4 consumers + 4 producers (probe 5)
     if (tune_get(p.tune, &uvl_tuning::gemm_big, 1) && p.N % 256 == 0 && p.K >= 1024 && p.splitk <= 1) {
         // 256x256 tiles, 8 waves, one workgroup per CU: half the LDS-DMA instructions per MFMA of the 128x128 tile (an LDS-DMA
@@ -514,13 +791,13 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
     int cfg = pick_plain_cfg(p);
     if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 21)) && p.N % 128 != 0) cfg = 0;
     if (cfg >= 16 && cfg <= 21 && p.splitk > 1) cfg = 6;
-    if ((cfg == 11 || cfg == 14) && p.N % 256 != 0) cfg = 0;
+    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 33)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
 
 // Both problems in one launch when they resolve to the same 64x64 / 3-stage instantiation (the batch-1 configuration);
 // otherwise two launches on the same stream -- same results either way.
-template <int EPI>
+template <int EPI, int NS>
 static hipError_t launch_pair_epi(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
     GemmParams a = a_in, b = b_in;
     const int mta = (a.M + 63) / 64, mtb = (b.M + 63) / 64;
@@ -531,10 +808,16 @@ static hipError_t launch_pair_epi(const GemmParams& a_in, const GemmParams& b_in
     // K-slice map: the grid of a problem is 1-D over (tile, slice); "tiles" = all its blocks makes the kernel pass the block id through
     if (gemm_kxcd_ok(a, mta, a.N / 64)) { a.group_m = -1; ba = ta = 8 * mta * ((a.N / 64) / (8 / a.splitk)); }
     if (gemm_kxcd_ok(b, mtb, b.N / 64)) { b.group_m = -1; bb = tb = 8 * mtb * ((b.N / 64) / (8 / b.splitk)); }
-    constexpr size_t lds = 3 * (size_t)(64 + 64) * 128;
-    auto kern = gemm_glds_pair_kernel<64, 64, 2, 2, EPI, 3>;
+    constexpr size_t lds = NS * (size_t)(64 + 64) * 128;
+    auto kern = gemm_glds_pair_kernel<64, 64, 2, 2, EPI, NS>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
     static char name[64];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_pair_kernel<64,64,2,2,%d,3>", EPI);
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_pair_kernel<64,64,2,2,%d,%d>", EPI, NS);
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(256), lds, s, a, b, ba, ta, tb);
     return hipGetLastError();
@@ -551,10 +834,17 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
         const hipError_t e = launch_gemm(a, s);
         return e != hipSuccess ? e : launch_gemm(b, s);
     }
-    switch (a.epi) {
-        case EPI_BF16: return launch_pair_epi<EPI_BF16>(a, b, s);
-        case EPI_F32: return launch_pair_epi<EPI_F32>(a, b, s);
-        case EPI_QKV: return launch_pair_epi<EPI_QKV>(a, b, s);
+    const int ns = ring1_depth(a);
+    switch (a.epi * 8 + ns) {
+        case EPI_BF16 * 8 + 3: return launch_pair_epi<EPI_BF16, 3>(a, b, s);
+        case EPI_F32 * 8 + 3: return launch_pair_epi<EPI_F32, 3>(a, b, s);
+        case EPI_QKV * 8 + 3: return launch_pair_epi<EPI_QKV, 3>(a, b, s);
+        case EPI_BF16 * 8 + 4: return launch_pair_epi<EPI_BF16, 4>(a, b, s);
+        case EPI_F32 * 8 + 4: return launch_pair_epi<EPI_F32, 4>(a, b, s);
+        case EPI_QKV * 8 + 4: return launch_pair_epi<EPI_QKV, 4>(a, b, s);
+        case EPI_BF16 * 8 + 5: return launch_pair_epi<EPI_BF16, 5>(a, b, s);
+        case EPI_F32 * 8 + 5: return launch_pair_epi<EPI_F32, 5>(a, b, s);
+        case EPI_QKV * 8 + 5: return launch_pair_epi<EPI_QKV, 5>(a, b, s);
     }
     return hipErrorInvalidValue;
 }
