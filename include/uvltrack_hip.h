@@ -233,7 +233,7 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   attn_cfg   index into the attention configuration table (attention.hip::launch_attention)
  *   sk_k1 / sk_k4  split-K factor of the frame's residual GEMMs with K = D / K = 4 D
  *   gemm_pipe  0 = never pick the phase-pipelined 256-wide GEMM (default: batched frames, see gemm.hip::pick_plain_cfg)
- *   ring1      ring depth (3..5 stages of 16 KB) of the 64x64 tile that one-sequence frames use (default 3)
+ *   ring1      ring depth (3..5 stages of 16 KB) of the 64x64 tile that one-sequence frames use (default 4)
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
     int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1;

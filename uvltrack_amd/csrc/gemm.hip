@@ -688,11 +688,12 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Ring depth of the one-sequence tile (64 x 64, 16 KB per stage; two workgroups per CU up to 5 stages = 80 KB): 3 unless a tool
-// overrides it (uvl_tuning.ring1).  The weights of a one-sequence frame stream from HBM and a K step waits for (latency / tiles in flight).
+// Ring depth of the one-sequence tile (64 x 64, 16 KB per stage; two workgroups per CU up to 5 stages = 80 KB).  Measured in the
+// one-sequence frame, same box, three interleaved repeats (tools/ab_tune.py ring1 ...): 3 stages 1347-1353 frames/s, 4 stages
+// 1354-1375 (+1 %), 5 stages 1314-1322 (-2.5 %); 2 stages lost 5 % in round 1.  uvl_tuning.ring1 overrides it.
 static int ring1_depth(const GemmParams& p) {
-    const int r = tune_get(p.tune, &uvl_tuning::ring1, 3);
-    return (r >= 3 && r <= 5) ? r : 3;
+    const int r = tune_get(p.tune, &uvl_tuning::ring1, 4);
+    return (r >= 3 && r <= 5) ? r : 4;
 }
 
 template <int EPI>
