@@ -6,7 +6,7 @@ from uvltrack_amd import _native
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for M, D in [(553, 768), (40, 768), (4424, 768), (681, 1024)]:
+for M, D in [(553, 768), (40, 768), (4424, 768), (681, 1024), (6984, 1024), (17696, 768)]:
     x = torch.randn(M, D, device="cuda"); g = torch.ones(D, device="cuda"); b = torch.zeros(D, device="cuda")
     yb = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
     fn = lambda: lib.uvl_layernorm(p(x), p(g), p(b), C.c_float(1e-6), p(yb), None, M, D, st)

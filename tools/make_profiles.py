@@ -19,7 +19,7 @@ def short(name):
     m = re.match(r"^(gemm_glds_kernel<\d+,\d+,\d+,\d+,\d+,\d+,\d+),(\d+)(?:,(\d+))?(?:,(\d+))?>$", n)
     if m:          # non-temporal weights / 32-wide K stages / producer waves: written the way the library names its launches (bench.py keys on that name)
         ntw, bk, prod = m.group(2), m.group(3) or "64", m.group(4) or "0"
-        n = m.group(1) + (",nt>" if ntw == "1" else ",0,64,p>" if prod != "0" else ",0,32>" if bk == "32" else ">")
+        n = m.group(1) + (",nt>" if ntw == "1" else ",0,%s,%s>" % (bk, prod) if prod != "0" else ",0,32>" if bk == "32" else ">")
     return n
 
 

@@ -406,6 +406,15 @@ __global__ __launch_bounds__(64 * (WGM * WGN + PROD), PROD ? (2 * (WGM * WGN + P
 //     phase p, all waves have done so by the end of p, the group is read in p + 1.
 // Epilogue, tile order and the split of rows over lanes are those of gemm_glds_body (same gemm_epilogue_lds).
 // ------------------------------------------------------------------------------------------------
+#ifdef GEMM_TRACE
+// development build only (tools/gemm_trace.py, -DGEMM_TRACE into a separate .so): shader-clock stamps of wave 0 (wave group 0) and wave 4
+// (group 1) of workgroup 0, four per phase -- phase start | counted wait done | barrier + fragment reads done | MFMAs issued -- taken with
+// s_memtime into SGPRs and only READ behind the next lgkmcnt(0) the loop has anyway, so the stamps add no wait of their own.
+__device__ unsigned int g_gemm_trace[2 * 64 * 4 * 4 + 16];
+#define GT_STAMP(v) asm volatile("s_memtime %0" : "=s"(v)::"memory")
+#else
+#define GT_STAMP(v) do { } while (0)
+#endif
 // VAR 1 (the product form): the phase's two LDS-DMA instructions are issued BETWEEN its MFMAs (behind the 2nd and the 5th) instead of
 // in front of the barrier -- an LDS-DMA instruction costs the issuing wave 60-120 cycles, which the other wave group's 256-cycle MFMA
 // block cannot hide together with up to 12 fragment reads; between MFMAs it rides on the matrix pipe's own latency (+2..5 % at
@@ -519,12 +528,19 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();               // wave group 1 runs half a phase behind group 0 from here on
 
+#ifdef GEMM_TRACE
+    unsigned long long gt[4][4] = {};                        // [quadrant][stamp]: every quadrant has its own SGPRs, nothing is copied
+    int gt_n = 0;                                            // phases completed
+    const bool gt_on = bx == 0 && (wave == 0 || wave == 4);
+    unsigned int* gt_lds = reinterpret_cast<unsigned int*>(smem + 2 * STAGE + 1024) + (wave >> 2) * (64 * 4 * 4);
+#endif
     // one phase: fragment reads of quadrant Q | the group due this phase | counted wait | barrier | 8 MFMAs | barrier
     auto phase = [&](auto Q, auto ISS, auto VM, int t) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value;
         constexpr bool iss = decltype(ISS)::value != 0;
         constexpr int vm = decltype(VM)::value;
         const char* sb = smem + (t & 1) * STAGE;
+        GT_STAMP(gt[q][0]);
         if constexpr (q == 0) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) bl[ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[ks]);
@@ -552,10 +568,19 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
         // VAR 1 waits BEFORE its issue: one group fewer may be outstanding
         constexpr int vm_eff = (VAR == 1 && iss) ? vm - cnt_g : vm;
         if constexpr (vm >= 0) wait_vmcnt<(vm_eff >= 0 ? vm_eff : 0)>();
+        GT_STAMP(gt[q][1]);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#ifdef GEMM_TRACE
+        if (gt_on && gt_n > 0 && gt_n <= 256 && lane == 0) {      // the PREVIOUS phase's four stamps are valid behind the lgkmcnt(0) above
+            unsigned int* e = gt_lds + (gt_n - 1) * 4;
+            constexpr int pq = (q + 3) & 3;
+            e[0] = (unsigned int)gt[pq][0]; e[1] = (unsigned int)gt[pq][1]; e[2] = (unsigned int)gt[pq][2]; e[3] = (unsigned int)gt[pq][3];
+        }
+#endif
+        GT_STAMP(gt[q][2]);
         __builtin_amdgcn_s_setprio(1);
         constexpr int i0 = (q >= 2) ? HB : 0, j = (q == 1 || q == 2) ? 1 : 0;
 #pragma unroll
@@ -571,8 +596,12 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
                 }
             }
         __builtin_amdgcn_s_setprio(0);
+        GT_STAMP(gt[q][3]);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+#ifdef GEMM_TRACE
+        ++gt_n;
+#endif
     };
     using Y = std::integral_constant<int, 1>; using N_ = std::integral_constant<int, 0>;
     using VF = std::integral_constant<int, LPT>;             // steady state: the four youngest groups stay in flight
@@ -590,6 +619,17 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
         phase(I3{}, N_{}, std::integral_constant<int, -1>{}, t + 1);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();               // group 0 waits for group 1's last phase
+#ifdef GEMM_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (gt_on && lane == 0) {
+        unsigned int* e = gt_lds + (gt_n - 1) * 4;           // the last phase is quadrant 3
+        e[0] = (unsigned int)gt[3][0]; e[1] = (unsigned int)gt[3][1]; e[2] = (unsigned int)gt[3][2]; e[3] = (unsigned int)gt[3][3];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n = gt_n < 256 ? gt_n : 256;
+        for (int i = 0; i < n * 4; ++i) g_gemm_trace[(wave >> 2) * (64 * 4 * 4) + i] = gt_lds[i];
+        g_gemm_trace[2 * 64 * 4 * 4 + (wave >> 2)] = (unsigned int)n;
+    }
+#endif
 
     f32x4 bias_v[TN][4];
 #pragma unroll
@@ -615,7 +655,11 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
     const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
     if (forced_gm > 0) p.group_m = forced_gm;
     const int nblk = 8 * ((MT * NT + 7) / 8);
+#ifdef GEMM_TRACE
+    constexpr size_t lds = 2 * (size_t)(BM + 256) * 128 + 1024 + 2 * 64 * 4 * 4 * 4;
+#else
     constexpr size_t lds = 2 * (size_t)(BM + 256) * 128 + 1024;      // two K-tile buffers + the tile's bias row
+#endif
     auto kern = gemm_pipe_kernel<BM, EPI, VAR>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -849,6 +893,10 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
     }
     return hipErrorInvalidValue;
 }
+
+#ifdef GEMM_TRACE
+extern "C" int uvl_debug_gemm_trace(unsigned int* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), (2 * 64 * 4 * 4 + 16) * sizeof(unsigned int)); }
+#endif
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.K % 64 != 0 || p.M <= 0 || p.N <= 0 || p.N % 32 != 0 || p.splitk < 1) return hipErrorInvalidValue;
