@@ -99,6 +99,7 @@ struct uvl_model {
     std::vector<ProfEntry> prof;
     int debug_stop_layer = -1;          // >= 0: leave the layer loop after this layer (tests localise errors with it)
     uvl_tuning tune;                    // overrides of the launch heuristics for THIS handle (uvl_tune_set); all -1 = heuristics
+    uvl_tuning tune_text;               // = tune with gemm_cfg replaced by text_cfg: what the text-branch GEMMs of multi-sequence frames see
     uvl_model() { uvl_tuning_init(&tune); }
 };
 
@@ -573,6 +574,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // launch a visual kernel; if the next waiting text kernel is of the same kind (and, for GEMMs, the same epilogue), take it along
     auto run_gemm = [&](hipStream_t st, GemmParams& p, const char* what, bool is_text) {
         p.tune = &m->tune;
+        if (is_text && !paired && m->tune.text_cfg >= 0) { m->tune_text = m->tune; m->tune_text.gemm_cfg = m->tune.text_cfg; p.tune = &m->tune_text; }
         // BERT weights are read once per frame: up to four sequences (<= 3 M tiles share a weight tile through L2) they are loaded
         // non-temporal so that they do not displace the ViT weights from the Infinity Cache (+2-3 % at 2-4 sequences, -0.5 % from 8 on)
         if (is_text && p.M <= 192) p.w_stream = 1;
@@ -927,7 +929,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
     static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
         {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
-        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}};
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) { m->tune.*(k.field) = value < 0 ? -1 : value; return UVL_OK; }
     if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
