@@ -16,7 +16,7 @@ from uvltrack_amd import _native  # noqa: E402
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-LABEL = {6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 dma-pre", 33: "pipe128 dma-pre", -1: "auto"}
+LABEL = {6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 dma-pre", -1: "auto"}
 
 
 def arg(name, default):
@@ -60,7 +60,7 @@ def main():
         flops = 2.0 * M * N * K
         fns, notes = {}, {}
         for cfg in cfgs:
-            if cfg in (11, 30, 31, 32, 33) and N % 256:
+            if cfg in (11, 30, 31, 32) and N % 256:
                 continue
             if cfg in (6, 21) and N % 128:
                 continue

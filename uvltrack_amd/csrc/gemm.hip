@@ -640,6 +640,217 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 128 x 256 tile of the same family with TWO phases of 8 MFMAs per K tile and THREE 48-KB buffers (cfg 31).  gemm_pipe_body at BM = 128
+// would have four phases of FOUR MFMAs (measured first: 1-3 % slower than this form on every shape of the frames; a hand-over between
+// the two wave groups costs the same ~110 cycles whether the MFMA block is 128 or 256 cycles long).  Here a wave (64 x 64 of the
+// output) reads both A blocks and B-lo in phase 0 (12 fragment reads, 8 MFMAs into acc[.][0]) and B-hi in phase 1 (4 reads, 8 MFMAs
+// into acc[.][1]); a K tile is staged as three row groups -- A (128 rows), B-lo, B-hi (128 rows each: the lo / hi 32 columns of the
+// four wave columns) -- TWO K tiles ahead: phase 0 of tile t issues A and B-lo of tile t + 2 (4 LDS-DMA instructions per wave, between
+// the MFMAs), phase 1 issues B-hi of t + 2.  Three buffers because a group read in phase p may be refilled in p + 2 at the earliest and
+// must be waited for in the phase before its read: with two buffers a group would have ONE phase to land.  Counted wait: 6 instructions
+// may stay outstanding in every steady-state phase (derived as in gemm_pipe_body: wait in p, read in p + 1, wait placed before the
+// phase's own issue).  Epilogue, tile order, bias row in LDS: as gemm_pipe_body.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int bx, char* smem) {
+    constexpr int BM = 128, BN = 256, NW = 8, WM = 64, WN = 64, TM = 2, TN = 2, NBUF = 3;
+    constexpr int STAGE = (BM + BN) * 128;                   // 48 KB: A rows then W rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
+    int nt, mt;
+    {
+        const int xcd = bx & 7, idx = bx >> 3;
+        const int T = MT * NT, base = T >> 3, rem = T & 7;
+        const int cnt = base + (xcd < rem ? 1 : 0);
+        if (idx >= cnt) return;
+        const int L = xcd * base + (xcd < rem ? xcd : rem) + idx;
+        const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
+        const int gm = min(p.group_m, MT - gi * p.group_m);
+        nt = within / gm;
+        mt = gi * p.group_m + (within - nt * gm);
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
+
+    // group 0 = A (tile rows 0..127), 1 = B-lo (rows wn' * 64 + [0, 32)), 2 = B-hi; instruction n (0, 1) of a group fills 8 rows
+    uint32_t loff[3][2];
+    int dst[3][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int gr0 = 8 * (wave + NW * n);
+            const int R0 = g == 0 ? gr0 : (gr0 / 32) * 64 + (g == 2 ? 32 : 0) + gr0 % 32;
+            const int R = R0 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((R >> 1) & 7);
+            dst[g][n] = (g == 0 ? 0 : BM * 128) + R0 * 128;
+            if (g == 0) {
+                int gmr = m0 + R;
+                gmr = gmr < p.M ? gmr : p.M - 1;
+                loff[g][n] = (uint32_t)(gmr - m0) * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
+            } else {
+                loff[g][n] = (uint32_t)R * (uint32_t)p.ldw * 2u + (uint32_t)chunk * 16u;
+            }
+        }
+    auto pin = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    auto issue1 = [&](auto G, int kt, int buf, int n) __attribute__((always_inline)) {       // instruction n of group G of K tile kt
+        constexpr int g = decltype(G)::value;
+        const char* gb = pin((g == 0 ? a_base : w_base) + (size_t)kt * 128);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + loff[g][n]),
+                                         (__attribute__((address_space(3))) void*)(smem + buf * STAGE + dst[g][n]), 16, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
+        issue1(I0{}, kt, buf, 0); issue1(I0{}, kt, buf, 1); issue1(I1{}, kt, buf, 0); issue1(I1{}, kt, buf, 1); issue1(I2{}, kt, buf, 0); issue1(I2{}, kt, buf, 1);
+    };
+
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a_off[ks] = swz128(wm * WM + (lane & 31), ks * 2 + (lane >> 5));
+        b_off[ks] = BM * 128 + swz128(wn * WN + (lane & 31), ks * 2 + (lane >> 5));
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 af[2][4], bl[4], bh[4];
+
+    const int nk = p.K / 64;                                 // >= 2 (launcher)
+    f32x4 bias_in;
+    if (wave == 0) {
+        const float* bsrc = (p.bias ? p.bias + n0 : reinterpret_cast<const float*>(g_zero_page)) + lane * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_in) : "v"(bsrc) : "memory");
+    }
+    issue_tile(0, 0);
+    issue_tile(1, 1);
+    wait_vmcnt<8>();                                         // A and B-lo of tile 0 (and the bias row in front of them) have landed
+    if (wave == 0) {
+        const uint32_t sb_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + NBUF * STAGE + lane * 16;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(sb_addr), "v"(bias_in) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // wave group 1 runs half a phase behind group 0
+
+    // H = 0: A + B-lo | H = 1: B-hi.  ISS: issue tile t + 2's share (H = 0: A, B-lo; H = 1: B-hi) into buffer nb between the MFMAs.
+    auto phase = [&](auto H, auto ISS, auto VM, int t, int cb, int nb) __attribute__((always_inline)) {
+        constexpr int h = decltype(H)::value;
+        constexpr bool iss = decltype(ISS)::value != 0;
+        constexpr int vm = decltype(VM)::value;
+        const char* sb = smem + cb * STAGE;
+        if constexpr (h == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bl[ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(sb + a_off[ks] + i * 4096);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bh[ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[ks] + 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (vm >= 0) wait_vmcnt<(vm >= 0 ? vm : 0)>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? bh[ks] : bl[ks], af[i][ks], acc[i][h], 0, 0, 0);
+                if constexpr (iss) {
+                    const int mi = ks * 2 + i;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (h == 0) {
+                        if (mi == 0) issue1(I0{}, t + 2, nb, 0);
+                        if (mi == 2) issue1(I0{}, t + 2, nb, 1);
+                        if (mi == 4) issue1(I1{}, t + 2, nb, 0);
+                        if (mi == 6) issue1(I1{}, t + 2, nb, 1);
+                    } else {
+                        if (mi == 1) issue1(I2{}, t + 2, nb, 0);
+                        if (mi == 5) issue1(I2{}, t + 2, nb, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using Y = std::integral_constant<int, 1>; using N_ = std::integral_constant<int, 0>;
+    using V6 = std::integral_constant<int, 6>;
+    int cb = 0;                                              // buffer of K tile t
+    for (int t = 0; t < nk - 2; ++t) {
+        const int nb = cb == 0 ? 2 : cb - 1;                 // buffer of K tile t + 2 = (t + 2) % 3 = (t - 1) % 3
+        phase(I0{}, Y{}, V6{}, t, cb, nb);
+        phase(I1{}, Y{}, V6{}, t, cb, nb);
+        cb = cb == 2 ? 0 : cb + 1;
+    }
+    {   // last two K tiles: nothing left to issue
+        phase(I0{}, N_{}, V6{}, nk - 2, cb, 0);
+        phase(I1{}, N_{}, std::integral_constant<int, 2>{}, nk - 2, cb, 0);
+        cb = cb == 2 ? 0 : cb + 1;
+        phase(I0{}, N_{}, std::integral_constant<int, 0>{}, nk - 1, cb, 0);
+        phase(I1{}, N_{}, std::integral_constant<int, -1>{}, nk - 1, cb, 0);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // group 0 waits for group 1's last phase
+
+    const float* sbias = reinterpret_cast<const float*>(smem + NBUF * STAGE);
+    f32x4 bias_v[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5));
+    static_assert(32 * (WN * 4 + 16) * NW <= NBUF * STAGE, "epilogue staging fits in the buffers");
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pipe128_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_pipe128_body<EPI>(p, blockIdx.x, smem);
+}
+
+template <int EPI>
+static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (p.N % 256 != 0 || p.K < 128 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return hipErrorInvalidValue;
+    const int MT = (p.M + 127) / 128, NT = p.N / 256;
+    p.group_m = MT >= 16 ? 8 : MT;
+    const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
+    if (forced_gm > 0) p.group_m = forced_gm;
+    const int nblk = 8 * ((MT * NT + 7) / 8);
+    constexpr size_t lds = 3 * (size_t)(128 + 256) * 128 + 1024;      // three K-tile buffers + the tile's bias row
+    auto kern = gemm_pipe128_kernel<EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[48];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe128_kernel<%d>", EPI);
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
 template <int BM, int EPI, int VAR>
 __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -782,10 +993,9 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 20: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 2>(p, s);  // 4 consumers + 2 producers, 2 workgroups per CU (3 waves / SIMD)
         case 21: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 4>(p, s);  // 4 + 4, 2 per CU (4 waves / SIMD: 128 registers)
         // phase-pipelined 256-wide tiles (gemm_pipe_body)
-        case 30: return launch_pipe<256, EPI, 1>(p, s);      // product form: LDS-DMA issued between the MFMAs
-        case 31: return launch_pipe<128, EPI, 1>(p, s);
-        case 32: return launch_pipe<256, EPI, 0>(p, s);      // LDS-DMA issued in front of the barrier (A/B: -2..-9 %)
-        case 33: return launch_pipe<128, EPI, 0>(p, s);
+        case 30: return launch_pipe<256, EPI, 1>(p, s);      // 256 x 256, product form: LDS-DMA issued between the MFMAs
+        case 31: return launch_pipe128<EPI>(p, s);           // 128 x 256: two phases of 8 MFMAs per K tile, three buffers
+        case 32: return launch_pipe<256, EPI, 0>(p, s);      // 256 x 256 with the LDS-DMA issued in front of the barrier (A/B: -2..-5 %)
     }
     return hipErrorInvalidValue;
 }
@@ -836,7 +1046,7 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
     int cfg = pick_plain_cfg(p);
     if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 21)) && p.N % 128 != 0) cfg = 0;
     if (cfg >= 16 && cfg <= 21 && p.splitk > 1) cfg = 6;
-    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 33)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
+    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 32)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
 
