@@ -24,6 +24,25 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I", INCLUDE, "-I", CSRC]
 
 
+# The kernels pin their instruction order with sched_barrier and count s_waitcnt by hand around inline-asm LDS reads / LDS-DMA
+# (attention.hip::attn_w64_kernel, gemm.hip::gemm_pipe_body): correct for THIS compiler's code generation.  Another hipcc builds too, but
+# the forced-kernel parity tests (tests/test_kernels_gpu.py: attn_cfg 8 / 10, gemm_cfg 30-32) must be re-run on it before its output is trusted.
+TESTED_HIPCC = "HIP version: 7.2.26015"
+
+
+def check_toolchain(hipcc: str, verbose: bool = True) -> bool:
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        return False
+    ok = TESTED_HIPCC in out
+    if not ok and verbose:
+        sys.stderr.write("uvltrack_amd.build: hipcc is not the tested toolchain (%s); got: %s\n"
+                         "  re-run `pytest tests -m gpu -k 'forced or tile_forms'` before trusting hand-counted waits.\n"
+                         % (TESTED_HIPCC, out.splitlines()[0] if out else "?"))
+    return ok
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -39,6 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    check_toolchain(hipcc, verbose)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 

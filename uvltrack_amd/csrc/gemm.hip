@@ -125,7 +125,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 for (int it = 0; it < CH; ++it) {
                     if (p.addtab) v[it] += tv[it];
                     if (p.accumulate) v[it] += ov[it];
-                    if (inb[it]) *reinterpret_cast<f32x4*>(dst[it]) = v[it];
+                    if (inb[it]) {
+                        if (p.c_store == 1) __builtin_nontemporal_store(v[it], reinterpret_cast<f32x4*>(dst[it]));
+                        else if (p.c_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst[it]), "v"(v[it]) : "memory");
+                        else *reinterpret_cast<f32x4*>(dst[it]) = v[it];
+                    }
                 }
             }
             continue;
@@ -1014,17 +1018,21 @@ static int pick_plain_cfg(const GemmParams& p) {
         return n128 ? 10 : 9;
     }
     if (t64 < 768) return 4;
-    if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
-    if (tune_get(p.tune, &uvl_tuning::gemm_pipe, 1) && p.N % 256 == 0 && p.K >= 128 && p.splitk <= 1 && !(p.epi == EPI_F32 && p.K < 2048)) {
-        // phase-pipelined 256-wide tiles (gemm_pipe_body), one workgroup per CU: taken where the tiles fill >= 80 % of whole rounds
-        // of the 256 CUs -- 256 x 256 first (7.8 bytes of LDS fill per KFLOP, 0.75 fragment reads per MFMA), else 128 x 256.  One
-        // workgroup per CU exposes the epilogue, so the read-modify-write f32 epilogue only takes it behind a long K loop (fc2).
-        // Measured against the 128 x 128 loop in isolation (tools/gemm_pipe_ab.py, profiles/r03_gemm_pipe.md): +5..+25 %.
+    if (p.M >= 2048 && tune_get(p.tune, &uvl_tuning::gemm_pipe, 1) && p.N % 256 == 0 && p.K >= 128 && p.splitk <= 1 && !(p.epi == EPI_F32 && p.K < 2048)) {
+        // phase-pipelined 256-wide tiles (gemm_pipe_body / gemm_pipe128_body), one workgroup per CU: 256 x 256 (7.8 bytes of LDS fill
+        // per KFLOP, 0.75 fragment reads per MFMA) where its tiles fill >= 80 % of whole rounds of the 256 CUs, else 128 x 256 under
+        // the same rule, else the better-filling of the two from 60 % on.  One workgroup per CU exposes the epilogue, so the
+        // read-modify-write f32 epilogue only takes them behind a long K loop (fc2).  Measured against the round-2 kernels in
+        // isolation (tools/gemm_pipe_ab.py, tools/lib_compare.py, profiles/r03_gemm_pipe.md): +5..+35 % from 8 UVLTrack-B sequences
+        // (M = 4424: fc1 605 -> 811 TFLOP/s) to 32 UVLTrack-L sequences.
         auto fill = [](long t) { const long rounds = (t + 255) / 256; return (double)t / (double)(rounds * 256); };
         const long nt256 = p.N / 256;
-        if (fill((long)((p.M + 255) / 256) * nt256) >= 0.8) return 30;
-        if (fill((long)((p.M + 127) / 128) * nt256) >= 0.8) return 31;
+        const double f256 = fill((long)((p.M + 255) / 256) * nt256), f128 = fill((long)((p.M + 127) / 128) * nt256);
+        if (f256 >= 0.8) return 30;
+        if (f128 >= 0.8) return 31;
+        if (f256 >= 0.6 || f128 >= 0.6) return f256 >= f128 ? 30 : 31;
     }
+    if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
     if (tune_get(p.tune, &uvl_tuning::gemm_prod, 1) && p.epi != EPI_F32 && p.N >= 3072 && n128 && p.splitk <= 1) return 21;   // 4 consumers + 4 producers (probe 5)
     if (tune_get(p.tune, &uvl_tuning::gemm_big, 1) && p.N % 256 == 0 && p.K >= 1024 && p.splitk <= 1) {
         // 256x256 tiles, 8 waves, one workgroup per CU: half the LDS-DMA instructions per MFMA of the 128x128 tile (an LDS-DMA

@@ -494,7 +494,7 @@ static void run_conv_layer(Launcher& L, hipStream_t s, int layer, const bf16_t* 
             if (nk % c == 0 && nk / c >= 6 && tiles * c <= 768) sk = c;
     const char* site = conv_site[layer & 3];
     if (sk > 1) {
-        p.epi = 1; p.C = slabs; p.splitk = sk; p.part_stride = (size_t)p.M * p.ldc;
+        p.epi = 1; p.C = slabs; p.splitk = sk; p.part_stride = (size_t)p.M * p.ldc; p.c_store = tune_get(tune, &uvl_tuning::slab_store, 2);
         RUN_GEMM(L, s, p, site);
         struct RCtx { const float* slabs; int sk; size_t stride; bf16_t* out; size_t n; } rc{slabs, sk, p.part_stride, y, p.part_stride};
         L.run(s, "conv_fold", 0, 0, [](void* c, hipStream_t st) { auto* x = (RCtx*)c; return launch_slab_relu(x->slabs, x->sk, x->stride, x->out, x->n, st); }, &rc);
@@ -654,10 +654,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
         const int sk = allow_split ? choose_splitk(Mr, D, K, &m->tune) : 1;
         if (sk > 1) {             // slabs [sk][Mr, D], folded in by the next LayerNorm / contrast kernel
-            p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D;
+            p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D; p.c_store = tune_get(&m->tune, &uvl_tuning::slab_store, 2);   // write-through slabs: +1 % at one sequence (both A/B orders)
             pd.part = slab; pd.nsplit = sk; pd.rows = rpb; pd.stride = p.part_stride;
         } else {                  // x += A W^T + b in place
-            p.C = w.X; p.accumulate = 1; p.rpb = rpb; p.obs = nj; p.oro = oro;
+            // write-through (sc1) stores of x: no dirty lines wait for the end-of-kernel write-back, and the LayerNorm that follows reads
+            // x from memory, not from another XCD's L2 anyway (+0.9 % at 8 sequences of UVLTrack-B / -L, 0 at 32; tools/ab_tune.py res_store 0 2)
+            p.C = w.X; p.accumulate = 1; p.rpb = rpb; p.obs = nj; p.oro = oro; p.c_store = tune_get(&m->tune, &uvl_tuning::res_store, 2);
         }
         run_gemm(st, p, what, is_text);
     };
@@ -929,7 +931,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
     static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
         {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
-        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}};
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) { m->tune.*(k.field) = value < 0 ? -1 : value; return UVL_OK; }
     if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
