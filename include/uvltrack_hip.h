@@ -237,10 +237,11 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   res_store  cache policy of the in-place f32 residual stores (x += ...) of the GEMM epilogue: 0 plain, 1 non-temporal, 2 write-through (default)
  *   slab_store the same for the split-K f32 slabs of one-sequence frames (default 2)
  *   text_cfg   tile configuration (as gemm_cfg) of the text-branch GEMMs of multi-sequence frames, which run on the second stream
+ *   attn_wgs   persistent workgroups of the hand-scheduled attention kernel (attention.hip::launch_attn_p64; default 512 = two per CU)
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
-    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store;
-    int32_t reserved[3];
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs;
+    int32_t reserved[2];
 } uvl_tuning;
 void uvl_tuning_init(uvl_tuning* t);
 int uvl_tune_set(uvl_model_t* m, const char* key, int value);

@@ -166,12 +166,13 @@ def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
     assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "cfg %d max err %g" % (cfg, float(err.max()))
 
 
-@pytest.mark.parametrize("cfg", [8, 10])
+@pytest.mark.parametrize("cfg", [8, 10, 11])
 @pytest.mark.parametrize("B,H,N,mode", [(1, 2, 1, "fill"), (1, 2, 33, "fill"), (2, 3, 64, "none"), (2, 3, 65, "bert"), (1, 2, 257, "fill"),
                                          (3, 2, 321, "bert_all"), (2, 4, 553, "fill"), (1, 2, 1100, "fill")])
 def test_attention_batched_kernels_forced(lib, cfg, B, H, N, mode):
-    """The two kernels of the batched regime -- attn_stream_kernel (cfg 8) and attn_w64_kernel (cfg 10: 64 queries per wave, pass 1
-    without a running maximum, exact pass 2 on demand) -- on shapes the heuristic would not give them: one key tile, ragged tails,
+    """The kernels of the batched regime -- attn_stream_kernel (cfg 8), attn_w64_kernel (cfg 10: 64 queries per wave, pass 1
+    without a running maximum, exact pass 2 on demand) and its hand-scheduled persistent form attn_p64_kernel (cfg 11; one key tile
+    falls back to cfg 10) -- on shapes the heuristic would not give them: one key tile, ragged tails,
     waves without queries, every key masked (pass 2 of the w64 kernel), more than 16 key tiles."""
     _attention_case(lib, B, H, N, mode, 300 + N, tune=_tune(attn_cfg=cfg))
 

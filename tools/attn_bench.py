@@ -17,12 +17,16 @@ def p(t):
 def main():
     """usage: attn_bench.py [B H N] [--cfgs 3,8,9]   (cfg -1 = the library's heuristic)"""
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    shapes = [(1, 12, 553), (8, 12, 553), (64, 12, 553), (1, 16, 681), (8, 16, 681), (8, 16, 873), (32, 16, 681), (64, 16, 681)]
+    shapes = [(1, 12, 553), (8, 12, 553), (64, 12, 553), (1, 16, 681), (8, 16, 681), (8, 16, 873), (32, 16, 681), (32, 16, 873), (64, 16, 681)]
     args = sys.argv[1:]
     cfgs = [-1]
     if "--cfgs" in args:
         i = args.index("--cfgs")
         cfgs = [int(c) for c in args[i + 1].split(",")]
+        del args[i:i + 2]
+    if "--wgs" in args:                       # persistent workgroups of attn_p64_kernel (cfg 11)
+        i = args.index("--wgs")
+        TUNE.attn_wgs = int(args[i + 1])
         del args[i:i + 2]
     if len(args) >= 3:
         shapes = [(int(args[0]), int(args[1]), int(args[2]))]

@@ -1,0 +1,726 @@
+"""Generator of the hand-scheduled fused-attention item walk (attn_p64_kernel, uvltrack_amd/csrc/attention.hip).
+
+    python tools/gen/attn_p64_gen.py          # rewrites uvltrack_amd/csrc/attn_p64_asm.inc
+
+The output is ONE inline-asm statement body (a C string literal): the whole pass-1 walk of a persistent workgroup over its items --
+item decode, q loads, DMA ring, key tiles, drain, normalise + store -- with every register owned by this file.  hipcc sees only SGPR
+operands and the clobber list, so its register allocator (the 256-register wall of attn_w64_kernel) is out of the picture.
+
+Same math, LDS image and MFMA operand trick as attn_w64_kernel (reference: lib/models/backbones/block.py:47-61 -- q k^T * scale,
+masked_fill, softmax, @ v): S^T = K Q^T per 32 keys x 32 queries, p = exp2(s) with NO running maximum (checked once per item, failing
+items are redone by the compiler-scheduled exact pass), P^T feeds V^T P^T as the B operand without data movement.
+
+Schedule.  A wave owns 64 queries = two 32-query blocks x (A, B); a 64-key tile is four UNITS (x, jb) = (A,0) (B,0) (A,1) (B,1), each
+4 score MFMAs + 40 VALU (16 exp2, 16 row-sum adds, 8 bf16 packs) + 4 P V MFMAs.  Slot u runs  score MFMAs of unit u+1 | softmax VALU of
+unit u | P V MFMAs of unit u-1, MFMAs alternating between the two accumulator chains, the 40 VALU spread over the eight MFMA gaps
+(5 per gap).  Only 32 score registers and 16 P registers are live, K / V^T fragments are read once per tile and double-buffered
+(4 ds_read_b128 per slot), one barrier and five LDS-DMA instructions per tile, the ring runs three rounds ahead.
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, "uvltrack_amd", "csrc", "attn_p64_asm.inc")
+
+# ---------------------------------------------------------------- LDS image (bytes from the workgroup's LDS base)
+STAGE = 16384            # K tile 8 KB + V^T tile 8 KB
+NS = 4
+KADD0 = NS * STAGE       # [stage][wave][64] f32 key_add rows
+FLAG0 = KADD0 + NS * 4 * 256
+LDS_BYTES = FLAG0 + 16
+
+# ---------------------------------------------------------------- VGPR map
+def O(x, db, r): return 32 * x + 16 * db + r
+def Q(x, kk): return 64 + 16 * x + 4 * kk
+def S(par, r): return 96 + 16 * par + r
+def P(par, t2): return 128 + 8 * par + 4 * t2
+def KF(buf, k): return 144 + 16 * buf + 4 * k
+def VF(buf, f): return 176 + 16 * buf + 4 * f          # f = 2 * t2 + db
+def KA(r): return 208 + r
+def PS(x, i): return 224 + 2 * x + i
+def KOFF(kk): return 228 + kk
+def VOFF(jb, t2): return 232 + 2 * jb + t2
+def DK(i): return 236 + i
+def DV(i): return 238 + i
+V_DKA, V_KAREAD, V_KAADDR, V_LIM, V_NEGINF, V_KACUR = 240, 241, 242, 243, 244, 245
+def QOFF(x): return 246 + x
+V_HALF8 = 255
+T = [248, 249, 250, 251, 252, 253, 254]          # T[2..5] is an aligned quad
+
+# ---------------------------------------------------------------- SGPR map (fixed; the operands are copied here first)
+SG = dict(q=40, k=42, vt=44, ka=46, o=48, N=50, Npad=51, H=52, total=53, cnt=54, v=55, G=56, vend=57, kas=58, wave=59, lds=60,
+          nqb=61, mq=62, mh=63, nt=64, ntail=65, tailf=66, qb=67, h=68, b=69, Kp=70, Vp=72, Ap=74, Qp=76, Op=78, t=80, masked=81,
+          mnext=82, active=83, r=84, it=85, bad=86, x0=88, x1=89, x2=90, x3=91, x4=92, x5=93, wl=94, wa=95, ibad=96, q0=97, vrow=98, x6=99)
+
+
+def s(n): return "s%d" % SG[n]
+def s2(n): return "s[%d:%d]" % (SG[n], SG[n] + 1)
+def shi(n): return "s%d" % (SG[n] + 1)
+def v(n): return "v%d" % n
+def vr(n, c): return "v[%d:%d]" % (n, n + c - 1)
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+        self.nlabel = 0
+
+    def e(self, text):
+        self.lines.append(text)
+
+    def label(self, name):
+        self.lines.append(name + "_%=:")
+
+    def ref(self, name):
+        return name + "_%="
+
+    def comment(self, text):
+        self.lines.append("; " + text)
+
+
+# ---------------------------------------------------------------- pieces
+def mfma(dst, a, b, c):
+    return "v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (vr(dst, 16), vr(a, 4), vr(b, 4), "0" if c is None else vr(c, 16))
+
+
+def dma_round(stage):
+    """The five LDS-DMA instructions of one round into `stage`, as (m0 set, load) pairs; the pointer update comes last."""
+    out = []
+    for i in range(2):
+        out.append(["s_add_u32 m0, %s, %d" % (s("wl"), stage * STAGE + i * 4096), "s_nop 0", "global_load_lds_dwordx4 %s, %s" % (v(DK(i)), s2("Kp"))])
+    for i in range(2):
+        out.append(["s_add_u32 m0, %s, %d" % (s("wl"), stage * STAGE + 8192 + i * 4096), "s_nop 0", "global_load_lds_dwordx4 %s, %s" % (v(DV(i)), s2("Vp"))])
+    out.append(["s_add_u32 m0, %s, %d" % (s("wa"), stage * 1024), "s_nop 0", "global_load_lds_dword %s, %s" % (v(V_DKA), s2("Ap"))])
+    return out
+
+
+def advance_round():
+    """Round pointers walk to the next key tile; past the item's last tile they stay (the surplus rounds reload the last tile into
+    stages nobody reads: the vmcnt arithmetic stays uniform and no address leaves the allocation)."""
+    return ["s_add_u32 %s, %s, 1" % (s("r"), s("r")),
+            "s_cmp_lt_u32 %s, %s" % (s("r"), s("nt")),
+            "s_cselect_b32 %s, 8192, 0" % s("x0"),
+            "s_add_u32 %s, %s, %s" % (s("Kp"), s("Kp"), s("x0")),
+            "s_addc_u32 %s, %s, 0" % (shi("Kp"), shi("Kp")),
+            "s_lshr_b32 %s, %s, 6" % (s("x1"), s("x0")),
+            "s_add_u32 %s, %s, %s" % (s("Vp"), s("Vp"), s("x1")),
+            "s_addc_u32 %s, %s, 0" % (shi("Vp"), shi("Vp")),
+            "s_lshr_b32 %s, %s, 5" % (s("x1"), s("x0")),
+            "s_add_u32 %s, %s, %s" % (s("Ap"), s("Ap"), s("x1")),
+            "s_addc_u32 %s, %s, 0" % (shi("Ap"), shi("Ap"))]
+
+
+def tail_fix(a, stage, tag):
+    """Zero the V^T columns of keys >= N in this wave's own two pieces of the tail tile (NaN-proof: 0 x garbage would poison P V);
+    executed once per item, behind the wave's own vmcnt wait and in front of the barrier.  The K rows need nothing: scores of keys
+    >= N are replaced, not added to."""
+    skip = "tfx%s" % tag
+    a.e("s_add_u32 %s, %s, 2" % (s("x0"), s("t")))                       # this barrier publishes tile t + 1; the tail tile is nt - 1
+    a.e("s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")))
+    a.e("s_cselect_b32 %s, %s, 0" % (s("x0"), s("tailf")))
+    a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip))
+    t0, t1, m1, m2 = T[0], T[1], T[6], V_KACUR
+    d = T[2]                                                              # T[2..5] = v250..v253, an aligned quad
+    a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(t1))
+    a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(t1), v(t1)))                 # lane
+    a.e("v_and_b32 %s, 7, %s" % (v(t0), v(t1)))
+    a.e("v_lshrrev_b32 %s, 4, %s" % (v(m1), v(t1)))
+    a.e("s_and_b32 %s, %s, 1" % (s("x0"), s("wave")))
+    a.e("s_lshl_b32 %s, %s, 2" % (s("x0"), s("x0")))
+    a.e("v_add_u32 %s, %s, %s" % (v(m1), s("x0"), v(m1)))
+    a.e("v_xor_b32 %s, %s, %s" % (v(t0), v(t0), v(m1)))
+    a.e("v_lshlrev_b32 %s, 3, %s" % (v(t0), v(t0)))                       # 8 * chunk
+    a.e("v_sub_u32 %s, %s, %s" % (v(t0), s("ntail"), v(t0)))              # valid keys of this lane's 8
+    a.e("v_lshlrev_b32 %s, 4, %s" % (v(t1), v(t1)))
+    a.e("v_add_u32 %s, %s, %s" % (v(t1), s("wl"), v(t1)))                 # own piece 0 of stage 0's K half
+    for i in range(2):
+        off = stage * STAGE + 8192 + i * 4096
+        a.e("ds_read_b128 %s, %s offset:%d" % (vr(d, 4), v(t1), off))
+        a.e("s_waitcnt lgkmcnt(0)")
+        for e in range(4):
+            a.e("v_cmp_lt_i32 vcc, %d, %s" % (2 * e, v(t0)))
+            a.e("v_cndmask_b32_e64 %s, 0, -1, vcc" % v(m1))
+            a.e("v_cmp_lt_i32 vcc, %d, %s" % (2 * e + 1, v(t0)))
+            a.e("v_cndmask_b32_e64 %s, 0, -1, vcc" % v(m2))
+            a.e("v_and_b32 %s, 0xffff, %s" % (v(m1), v(m1)))
+            a.e("v_and_b32 %s, 0xffff0000, %s" % (v(m2), v(m2)))
+            a.e("v_or_b32 %s, %s, %s" % (v(m1), v(m1), v(m2)))
+            a.e("v_and_b32 %s, %s, %s" % (v(d + e), v(d + e), v(m1)))
+        a.e("ds_write_b128 %s, %s offset:%d" % (v(t1), vr(d, 4), off))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.label(skip)
+
+
+def ka_load(stage, jb):
+    """masked variant: this wave's copy of the tile's key_add row, the 16 values of key block jb in score-register order"""
+    out = []
+    for gq in range(4):
+        off = stage * 1024 + jb * 128 + (gq >> 1) * 64 + (gq & 1) * 16
+        out.append("ds_read_b128 %s, %s offset:%d" % (vr(KA(4 * gq), 4), v(V_KAADDR), off))
+    return out
+
+
+def ka_scale():
+    return ["v_mul_f32 %s, 0x3fb8aa3b, %s" % (v(KA(r)), v(KA(r))) for r in range(16)]       # log2 domain
+
+
+def mask_apply(par, jb):
+    """s = key < limit ? s + key_add : -inf   (limit = valid keys of the tile - 8 * half; 64 - 8 * half unless it is the tail)"""
+    out = []
+    for r in range(16):
+        key = 32 * jb + 16 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3)
+        out.append("v_add_f32 %s, %s, %s" % (v(S(par, r)), v(S(par, r)), v(KA(r))))
+        out.append("v_cmp_lt_i32 vcc, %d, %s" % (key, v(V_LIM)))
+        out.append("v_cndmask_b32 %s, %s, %s, vcc" % (v(S(par, r)), v(V_NEGINF), v(S(par, r))))
+    return out
+
+
+def softmax_gaps(par, x):
+    """The 40 VALU of one unit's softmax by MFMA gap (0..7): exp2 pairs lead, their row-sum adds and the pack trail one gap."""
+    ex = lambda r: "v_exp_f32 %s, %s" % (v(S(par, r)), v(S(par, r)))
+    ad = lambda r: "v_add_f32 %s, %s, %s" % (v(PS(x, r & 1)), v(PS(x, r & 1)), v(S(par, r)))
+    cv = lambda i: "v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P(par, i >> 2) + (i & 3)), v(S(par, 2 * i)), v(S(par, 2 * i + 1)))
+    gaps = [[] for _ in range(8)]
+    for i in range(8):
+        gaps[i] += [ex(2 * i), ex(2 * i + 1)]
+        if i >= 1:
+            gaps[i] += [ad(2 * i - 2), ad(2 * i - 1), cv(i - 1)]
+    gaps[7] += [ad(14), ad(15), cv(7)]
+    return gaps
+
+
+def slot(a, j, st, masked, qk=True, pv=True, sm=True, reads=True, body=True):
+    """One slot of the tile body at ring stage st: j = 0..3 = units (A,0) (B,0) (A,1) (B,1) of tile t."""
+    par = j & 1
+    x, jb = j & 1, j >> 1
+    jn = (j + 1) & 3                       # unit u + 1 (tile t + 1 when j == 3)
+    xn, jbn = jn & 1, jn >> 1
+    jp = (j - 1) & 3                       # unit u - 1 (tile t - 1 when j == 0)
+    xp, jbp = jp & 1, jp >> 1
+    sn = (st + 1) & 3
+    mf = []
+    for k in range(4):
+        mf.append(mfma(S(par ^ 1, 0), KF(jbn, k), Q(xn, k), None if k == 0 else S(par ^ 1, 0)) if qk else None)
+        db, t2 = k & 1, k >> 1
+        mf.append(mfma(O(xp, db, 0), VF(jbp, 2 * t2 + db), P(par ^ 1, t2), O(xp, db, 0)) if pv else None)
+    gaps = softmax_gaps(par, x) if sm else [[] for _ in range(8)]
+    head = []                              # in front of m0
+    g0 = []                                # leading fillers of gap 0
+    if reads:
+        kread = lambda buf, k, stage, jbk: "ds_read_b128 %s, %s offset:%d" % (vr(KF(buf, k), 4), v(KOFF(k)), stage * STAGE + jbk * 4096)
+        vread = lambda buf, f, stage: "ds_read_b128 %s, %s offset:%d" % (vr(VF(buf, f), 4), v(VOFF(buf, f >> 1)), stage * STAGE + (f & 1) * 4096)
+        if j == 0:
+            lds = [kread(1, 2, st, 1), kread(1, 3, st, 1), vread(0, 2, st), vread(0, 3, st)]
+        elif j == 1:
+            lds = [kread(0, 0, sn, 0), kread(0, 1, sn, 0), vread(1, 0, st), vread(1, 1, st)]
+        elif j == 2:
+            lds = [kread(0, 2, sn, 0), kread(0, 3, sn, 0), vread(1, 2, st), vread(1, 3, st)]
+        else:
+            lds = [kread(1, 0, sn, 1), kread(1, 1, sn, 1), vread(0, 0, sn), vread(0, 1, sn)]
+    else:
+        lds = []
+    head.append("s_waitcnt lgkmcnt(0)")
+    extra = {i: [] for i in range(8)}
+    if body and j == 1:
+        # barrier of tile t + 1: own pieces of round t + 1 landed (round t + 2 may fly), tail fix, barrier; then round t + 3 goes out
+        g0.append("@BARRIER")
+        rd = dma_round((st + 3) & 3)
+        extra[2] += rd[0]
+        extra[4] += rd[1]
+        extra[6] += rd[2]
+    if body and j == 2:
+        rd = dma_round((st + 3) & 3)
+        extra[2] += rd[3]
+        extra[4] += rd[4]
+        extra[1] += ["v_cmp_neq_f32 vcc, 0, %s" % v(V_KACUR)]
+        extra[3] += ["s_cmp_lg_u64 vcc, 0", "s_cselect_b32 %s, 1, 0" % s("mnext")]
+    if body and j == 3:
+        adv = advance_round()
+        extra[1] += adv[0:3]
+        extra[2] += adv[3:5]
+        extra[3] += adv[5:8]
+        extra[4] += adv[8:11]
+    g0 += lds
+    if body and j == 1:
+        g0.append("ds_read_b32 %s, %s offset:%d" % (v(V_KACUR), v(V_KAREAD), sn * 1024))
+    pre = []
+    if masked and sm:
+        pre = mask_apply(par, jb)
+        if j == 1:                         # key block 1's values: read behind this slot's use of block 0's, scaled before slot 2
+            extra[1] += ka_load(st, 1)
+            extra[5] += ["s_waitcnt lgkmcnt(0)"] + ka_scale()[:8]
+            extra[6] += ka_scale()[8:]
+    # emit
+    for t in head:
+        a.e(t)
+    for i in range(8):
+        if mf[i] is not None:
+            a.e(mf[i])
+        fill = []
+        if i == 0:
+            fill += g0 + pre
+        fill += extra[i]
+        for t in fill:
+            if t == "@BARRIER":
+                a.e("s_waitcnt vmcnt(5)")
+                tail_fix(a, sn, "%d%d%s" % (st, j, "m" if masked else "p"))
+                a.e("s_barrier")
+            else:
+                a.e(t)
+        for t in gaps[i]:
+            a.e(t)
+
+
+def tile_body(a, st, masked):
+    if masked:
+        # v_lim = (tail tile ? ntail : 64) - 8 * half; key block 0's key_add values
+        a.e("s_add_u32 %s, %s, 1" % (s("x0"), s("t")))
+        a.e("s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")))
+        a.e("s_cselect_b32 %s, %s, 0" % (s("x0"), s("tailf")))
+        a.e("s_cmp_lg_u32 %s, 0" % s("x0"))
+        a.e("s_cselect_b32 %s, %s, 64" % (s("x0"), s("ntail")))
+        a.e("v_sub_u32 %s, %s, %s" % (v(V_LIM), s("x0"), v(V_HALF8)))
+        for t in ka_load(st, 0):
+            a.e(t)
+        a.e("s_waitcnt lgkmcnt(0)")
+        for t in ka_scale():
+            a.e(t)
+    for j in range(4):
+        slot(a, j, st, masked)
+    # tile t + 1 carries a mask term (any key_add != 0) or is the cut tail tile
+    a.e("s_add_u32 %s, %s, 1" % (s("t"), s("t")))
+    a.e("s_add_u32 %s, %s, 1" % (s("x0"), s("t")))
+    a.e("s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")))
+    a.e("s_cselect_b32 %s, %s, 0" % (s("x0"), s("tailf")))
+    a.e("s_or_b32 %s, %s, %s" % (s("masked"), s("mnext"), s("x0")))
+
+
+def item_decode(a, done_label, skip_label):
+    """virtual block v -> (qb, h, b) with attn_decode_block's XCD map: L = (v & 7) * cnt + (v >> 3)"""
+    a.e("s_cmp_ge_u32 %s, %s" % (s("v"), s("vend")))
+    a.e("s_cbranch_scc1 %s" % a.ref(done_label))
+    a.e("s_and_b32 %s, %s, 7" % (s("x0"), s("v")))
+    a.e("s_lshr_b32 %s, %s, 3" % (s("x1"), s("v")))
+    a.e("s_mul_i32 %s, %s, %s" % (s("x0"), s("x0"), s("cnt")))
+    a.e("s_add_u32 %s, %s, %s" % (s("x0"), s("x0"), s("x1")))                         # L
+    a.e("s_cmp_ge_u32 %s, %s" % (s("x0"), s("total")))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip_label))
+    a.e("s_mul_hi_u32 %s, %s, %s" % (s("x1"), s("x0"), s("mq")))                      # L / nqb (magic multiply; a divisor of 1 has none)
+    a.e("s_cmp_eq_u32 %s, 1" % s("nqb"))
+    a.e("s_cselect_b32 %s, %s, %s" % (s("x1"), s("x0"), s("x1")))
+    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("x1"), s("nqb")))
+    a.e("s_sub_u32 %s, %s, %s" % (s("qb"), s("x0"), s("x2")))
+    a.e("s_mul_hi_u32 %s, %s, %s" % (s("b"), s("x1"), s("mh")))                       # (L / nqb) / H
+    a.e("s_cmp_eq_u32 %s, 1" % s("H"))
+    a.e("s_cselect_b32 %s, %s, %s" % (s("b"), s("x1"), s("b")))
+    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("b"), s("H")))
+    a.e("s_sub_u32 %s, %s, %s" % (s("h"), s("x1"), s("x2")))
+    # byte offset of head (b, h) in q / k / v^T: bh * Npad * 128
+    a.e("s_lshl_b32 %s, %s, 7" % (s("x2"), s("Npad")))
+    a.e("s_mul_hi_u32 %s, %s, %s" % (s("x3"), s("x1"), s("x2")))
+    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("x1"), s("x2")))
+    for n, base in (("Qp", "q"), ("Kp", "k"), ("Vp", "vt")):
+        a.e("s_add_u32 %s, %s, %s" % (s(n), s(base), s("x2")))
+        a.e("s_addc_u32 %s, %s, %s" % (shi(n), shi(base), s("x3")))
+    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("b"), s("kas")))                         # key_add row of sample b (kas in bytes)
+    a.e("s_mul_hi_u32 %s, %s, %s" % (s("x3"), s("b"), s("kas")))
+    a.e("s_add_u32 %s, %s, %s" % (s("Ap"), s("ka"), s("x2")))
+    a.e("s_addc_u32 %s, %s, %s" % (shi("Ap"), shi("ka"), s("x3")))
+    # o + ((b * N) * H * 64 + h * 64) * 2
+    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("b"), s("N")))
+    a.e("s_lshl_b32 %s, %s, 7" % (s("x4"), s("H")))                                   # bytes of one output row
+    a.e("s_mul_hi_u32 %s, %s, %s" % (s("x3"), s("x2"), s("x4")))
+    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("x2"), s("x4")))
+    a.e("s_lshl_b32 %s, %s, 7" % (s("x5"), s("h")))
+    a.e("s_add_u32 %s, %s, %s" % (s("x2"), s("x2"), s("x5")))
+    a.e("s_addc_u32 %s, %s, 0" % (s("x3"), s("x3")))
+    a.e("s_add_u32 %s, %s, %s" % (s("Op"), s("o"), s("x2")))
+    a.e("s_addc_u32 %s, %s, %s" % (shi("Op"), shi("o"), s("x3")))
+    # q0 = (4 * qb + wave) * 64; the wave is active when q0 < N
+    a.e("s_lshl_b32 %s, %s, 2" % (s("q0"), s("qb")))
+    a.e("s_add_u32 %s, %s, %s" % (s("q0"), s("q0"), s("wave")))
+    a.e("s_lshl_b32 %s, %s, 6" % (s("q0"), s("q0")))
+    a.e("s_cmp_lt_u32 %s, %s" % (s("q0"), s("N")))
+    a.e("s_cselect_b32 %s, 1, 0" % s("active"))
+
+
+def lane_constants(a):
+    lane, m31, half, t0, t1 = T[0], T[1], T[2], T[3], T[4]
+    a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(lane))
+    a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(lane), v(lane)))
+    a.e("v_and_b32 %s, 31, %s" % (v(m31), v(lane)))
+    a.e("v_lshrrev_b32 %s, 5, %s" % (v(half), v(lane)))
+    a.e("v_lshlrev_b32 %s, 3, %s" % (v(V_HALF8), v(half)))
+    # kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1)
+    a.e("v_and_b32 %s, 0x13, %s" % (v(t0), v(m31)))
+    a.e("v_and_b32 %s, 4, %s" % (v(t1), v(m31)))
+    a.e("v_lshl_or_b32 %s, %s, 1, %s" % (v(t0), v(t1), v(t0)))
+    a.e("v_and_b32 %s, 8, %s" % (v(t1), v(m31)))
+    a.e("v_lshrrev_b32 %s, 1, %s" % (v(t1), v(t1)))
+    a.e("v_or_b32 %s, %s, %s" % (v(t0), v(t0), v(t1)))                    # kperm
+    # swz128(row, chunk) = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
+    def swz(dst, row, chunk_expr_emit):
+        a.e("v_lshrrev_b32 %s, 1, %s" % (v(T[5]), v(row)))
+        a.e("v_and_b32 %s, 7, %s" % (v(T[5]), v(T[5])))
+        chunk_expr_emit(T[6])                                             # chunk -> T[6]
+        a.e("v_xor_b32 %s, %s, %s" % (v(T[5]), v(T[5]), v(T[6])))
+        a.e("v_lshlrev_b32 %s, 4, %s" % (v(T[5]), v(T[5])))
+        a.e("v_lshl_add_u32 %s, %s, 7, %s" % (v(dst), v(row), v(T[5])))
+    for kk in range(4):
+        swz(KOFF(kk), t0, lambda r, kk=kk: a.e("v_add_u32 %s, %d, %s" % (v(r), 2 * kk, v(half))))
+        a.e("v_add_u32 %s, %s, %s" % (v(KOFF(kk)), s("lds"), v(KOFF(kk))))
+    for jb in range(2):
+        for t2 in range(2):
+            swz(VOFF(jb, t2), m31, lambda r, jb=jb, t2=t2: a.e("v_add_u32 %s, %d, %s" % (v(r), 4 * jb + 2 * t2, v(half))))
+            a.e("v_add_u32 %s, %s, %s" % (v(VOFF(jb, t2)), s("lds"), v(VOFF(jb, t2))))
+            a.e("v_add_u32 %s, 0x2000, %s" % (v(VOFF(jb, t2)), v(VOFF(jb, t2))))
+    # DMA source offsets: piece = wave + 4 i, row = 8 piece + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7)
+    a.e("s_lshl_b32 %s, %s, 3" % (s("x0"), s("wave")))
+    a.e("v_lshrrev_b32 %s, 3, %s" % (v(t0), v(lane)))
+    a.e("v_add_u32 %s, %s, %s" % (v(t0), s("x0"), v(t0)))                 # row of piece 0
+    a.e("s_lshl_b32 %s, %s, 1" % (s("x1"), s("Npad")))                    # bytes of a V^T row
+    for i in range(2):
+        if i == 1:
+            a.e("v_add_u32 %s, 32, %s" % (v(t0), v(t0)))
+        a.e("v_lshrrev_b32 %s, 1, %s" % (v(T[5]), v(t0)))
+        a.e("v_and_b32 %s, 7, %s" % (v(T[5]), v(T[5])))
+        a.e("v_and_b32 %s, 7, %s" % (v(T[6]), v(lane)))
+        a.e("v_xor_b32 %s, %s, %s" % (v(T[5]), v(T[5]), v(T[6])))
+        a.e("v_lshlrev_b32 %s, 4, %s" % (v(T[5]), v(T[5])))               # chunk * 16
+        a.e("v_lshl_add_u32 %s, %s, 7, %s" % (v(DK(i)), v(t0), v(T[5])))
+        a.e("v_mul_lo_u32 %s, %s, %s" % (v(T[6]), v(t0), s("x1")))
+        a.e("v_add_u32 %s, %s, %s" % (v(DV(i)), v(T[6]), v(T[5])))
+    a.e("v_lshlrev_b32 %s, 2, %s" % (v(V_DKA), v(lane)))
+    a.e("s_lshl_b32 %s, %s, 8" % (s("x0"), s("wave")))
+    a.e("s_add_u32 %s, %s, %s" % (s("wa"), s("lds"), s("x0")))
+    a.e("s_add_u32 %s, %s, %d" % (s("wa"), s("wa"), KADD0))               # this wave's key_add row of stage 0
+    a.e("v_add_u32 %s, %s, %s" % (v(V_KAREAD), s("wa"), v(V_DKA)))
+    a.e("v_lshlrev_b32 %s, 5, %s" % (v(t1), v(half)))
+    a.e("v_add_u32 %s, %s, %s" % (v(V_KAADDR), s("wa"), v(t1)))
+    a.e("s_lshl_b32 %s, %s, 10" % (s("x0"), s("wave")))
+    a.e("s_add_u32 %s, %s, %s" % (s("wl"), s("lds"), s("x0")))            # this wave's piece 0 of stage 0
+    a.e("v_mov_b32 %s, 0xff800000" % v(V_NEGINF))
+    for f in range(4):                                                    # "tile -1" runs P V against P = 0: its V^T fragments must be finite
+        for r in range(4):
+            a.e("v_mov_b32 %s, 0" % v(VF(1, f) + r))
+
+
+def item_prologue_active(a):
+    m31, t0 = T[1], T[3]
+    # q rows (clamped to N - 1), 16 bytes per lane and k step
+    a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(T[0]))
+    a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(T[0]), v(T[0])))
+    a.e("v_and_b32 %s, 31, %s" % (v(m31), v(T[0])))
+    a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("N")))
+    for x in range(2):
+        a.e("v_add_u32 %s, %s, %s" % (v(t0), s("q0"), v(m31)))
+        if x:
+            a.e("v_add_u32 %s, 32, %s" % (v(t0), v(t0)))
+        a.e("v_min_u32 %s, %s, %s" % (v(t0), s("x0"), v(t0)))
+        a.e("v_lshlrev_b32 %s, 7, %s" % (v(t0), v(t0)))
+        a.e("v_lshl_add_u32 %s, %s, 1, %s" % (v(QOFF(x)), v(V_HALF8), v(t0)))          # + half * 16
+        for kk in range(4):
+            a.e("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(Q(x, kk), 4), v(QOFF(x)), s2("Qp"), 32 * kk))
+
+
+def emit_rounds_012(a):
+    for r in range(3):
+        for pair in dma_round(r):
+            for t in pair:
+                a.e(t)
+        for t in advance_round():
+            a.e(t)
+
+
+def epilogue(a):
+    """normalise, range check (2^-100 < row sum < 2^100 else the item is redone exactly), 16-byte stores of rows < N"""
+    l0, l1, lane, m31, row = T[0], T[1], T[2], T[3], T[4]
+    a.e("s_mov_b32 %s, 0" % s("ibad"))
+    a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(lane))
+    a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(lane), v(lane)))
+    a.e("v_and_b32 %s, 31, %s" % (v(m31), v(lane)))
+    a.e("s_lshl_b32 %s, %s, 7" % (s("x4"), s("H")))
+    buf = 96                                                              # v96.. (scores, P, fragments: all dead) hold the packed rows
+    for x in range(2):
+        a.e("v_add_f32 %s, %s, %s" % (v(l0), v(PS(x, 0)), v(PS(x, 1))))
+        a.e("v_mov_b32 %s, %s" % (v(l1), v(l0)))
+        a.e("s_nop 1")
+        a.e("v_permlane32_swap_b32 %s, %s" % (v(l0), v(l1)))
+        a.e("s_nop 1")
+        a.e("v_add_f32 %s, %s, %s" % (v(l0), v(l0), v(l1)))
+        a.e("v_cmp_gt_f32 vcc, 0x71800000, %s" % v(l0))
+        a.e("s_mov_b64 %s, vcc" % s2("x0"))
+        a.e("v_cmp_lt_f32 vcc, 0x0d800000, %s" % v(l0))
+        a.e("s_and_b64 vcc, vcc, %s" % s2("x0"))
+        a.e("s_andn2_b64 %s, exec, vcc" % s2("x0"))
+        a.e("s_cmp_lg_u64 %s, 0" % s2("x0"))
+        a.e("s_cselect_b32 %s, 1, 0" % s("x0"))
+        a.e("s_or_b32 %s, %s, %s" % (s("ibad"), s("ibad"), s("x0")))
+        a.e("v_rcp_f32 %s, %s" % (v(l0), v(l0)))
+        a.e("v_add_u32 %s, %s, %s" % (v(row), s("q0"), v(m31)))
+        if x:
+            a.e("v_add_u32 %s, 32, %s" % (v(row), v(row)))
+        a.e("s_nop 0")
+        for db in range(2):
+            for r in range(16):
+                a.e("v_mul_f32 %s, %s, %s" % (v(O(x, db, r)), v(O(x, db, r)), v(l0)))
+        a.e("v_cmp_gt_u32 vcc, %s, %s" % (s("N"), v(row)))
+        a.e("v_mul_lo_u32 %s, %s, %s" % (v(row), v(row), s("x4")))
+        a.e("v_lshl_add_u32 %s, %s, 1, %s" % (v(row), v(V_HALF8), v(row)))            # + half * 16 bytes
+        regs = []
+        for db in range(2):
+            for gp in range(2):
+                base = buf
+                buf += 4
+                for i in range(4):
+                    a.e("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(base + i), v(O(x, db, 8 * gp + 2 * i)), v(O(x, db, 8 * gp + 2 * i + 1))))
+                regs.append((base, 64 * db + 32 * gp))
+        a.e("s_nop 1")
+        for base, off in regs:
+            a.e("v_permlane32_swap_b32 %s, %s" % (v(base), v(base + 2)))
+            a.e("v_permlane32_swap_b32 %s, %s" % (v(base + 1), v(base + 3)))
+        a.e("s_nop 1")
+        a.e("s_and_saveexec_b64 %s, vcc" % s2("x2"))
+        for base, off in regs:
+            a.e("global_store_dwordx4 %s, %s, %s offset:%d" % (v(row), vr(base, 4), s2("Op"), off))
+        a.e("s_mov_b64 exec, %s" % s2("x2"))
+
+
+def generate():
+    a = Asm()
+    # ---- operands -> fixed registers
+    for n in ("q", "k", "vt", "ka", "o"):
+        a.e("s_mov_b64 %s, %%[%s]" % (s2(n), n))
+    for n in ("N", "Npad", "H", "total", "cnt", "v", "G", "kas", "wave", "lds", "nqb", "mq", "mh"):
+        a.e("s_mov_b32 %s, %%[%s]" % (s(n), n))
+    a.e("s_lshl_b32 %s, %s, 3" % (s("vend"), s("cnt")))
+    a.e("s_add_u32 %s, %s, 63" % (s("nt"), s("N")))
+    a.e("s_lshr_b32 %s, %s, 6" % (s("nt"), s("nt")))
+    a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("nt")))
+    a.e("s_lshl_b32 %s, %s, 6" % (s("x0"), s("x0")))
+    a.e("s_sub_u32 %s, %s, %s" % (s("ntail"), s("N"), s("x0")))
+    a.e("s_and_b32 %s, %s, 63" % (s("tailf"), s("N")))
+    a.e("s_cmp_lg_u32 %s, 0" % s("tailf"))
+    a.e("s_cselect_b32 %s, 1, 0" % s("tailf"))
+    a.e("s_mov_b64 %s, 0" % s2("bad"))
+    a.e("s_mov_b32 %s, 0" % s("it"))
+    lane_constants(a)
+
+    # ================================================================ item loop
+    a.label("item")
+    item_decode(a, "done", "next")
+    # flags of the previous item (every wave wrote its own behind its epilogue), behind the barrier that also frees the ring
+    a.e("s_barrier")
+    a.e("s_cmp_eq_u32 %s, 0" % s("it"))
+    a.e("s_cbranch_scc1 %s" % a.ref("noflag"))
+    a.e("v_mov_b32 %s, %s" % (v(T[0]), s("lds")))
+    a.e("v_add_u32 %s, 0x%x, %s" % (v(T[0]), FLAG0, v(T[0])))
+    a.e("ds_read_b128 %s, %s" % (vr(T[2], 4), v(T[0])))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("v_or_b32 %s, %s, %s" % (v(T[2]), v(T[2]), v(T[3])))
+    a.e("v_or3_b32 %s, %s, %s, %s" % (v(T[2]), v(T[2]), v(T[4]), v(T[5])))
+    a.e("v_readfirstlane_b32 %s, %s" % (s("x0"), v(T[2])))
+    a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
+    a.e("s_cbranch_scc1 %s" % a.ref("noflag"))
+    a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("it")))
+    a.e("s_bitset1_b64 %s, %s" % (s2("bad"), s("x0")))
+    a.label("noflag")
+    a.e("s_barrier")                                                      # every wave has read the flags before anyone rewrites them
+    a.e("s_mov_b32 %s, 0" % s("r"))
+    a.e("s_mov_b32 %s, 0" % s("t"))
+    a.e("s_cmp_eq_u32 %s, 0" % s("active"))
+    a.e("s_cbranch_scc1 %s" % a.ref("light"))
+
+    # ---------------------------------------------------------------- active wave
+    item_prologue_active(a)
+    emit_rounds_012(a)
+    for x in range(2):
+        for db in range(2):
+            for r in range(16):
+                a.e("v_mov_b32 %s, 0" % v(O(x, db, r)))
+        for i in range(2):
+            a.e("v_mov_b32 %s, 0" % v(PS(x, i)))
+    for t2 in range(2):
+        for r in range(4):
+            a.e("v_mov_b32 %s, 0" % v(P(1, t2) + r))
+    a.e("s_waitcnt vmcnt(10)")                                            # q and round 0 have landed; rounds 1, 2 fly
+    a.e("s_barrier")
+    # what slots -3 .. -1 would have read: K block 0 (all four), K block 1 (k steps 0, 1), V^T block 0 (fragments 0, 1), key_add flag
+    for k in range(4):
+        a.e("ds_read_b128 %s, %s offset:%d" % (vr(KF(0, k), 4), v(KOFF(k)), 0))
+    for k in range(2):
+        a.e("ds_read_b128 %s, %s offset:%d" % (vr(KF(1, k), 4), v(KOFF(k)), 4096))
+    for f in range(2):
+        a.e("ds_read_b128 %s, %s offset:%d" % (vr(VF(0, f), 4), v(VOFF(0, 0)), (f & 1) * 4096))
+    a.e("ds_read_b32 %s, %s offset:0" % (v(V_KACUR), v(V_KAREAD)))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("v_cmp_neq_f32 vcc, 0, %s" % v(V_KACUR))
+    a.e("s_cmp_lg_u64 vcc, 0")
+    a.e("s_cselect_b32 %s, 1, 0" % s("masked"))
+    for k in range(4):                                                    # scores of unit 0 = (A, 0)
+        a.e(mfma(S(0, 0), KF(0, k), Q(0, k), None if k == 0 else S(0, 0)))
+    a.e("s_nop 3")                                                        # slot 0's first exponentials read these scores (12 wait states)
+    # ---- tile loop, unrolled by the ring depth (a stage is an immediate offset)
+    a.label("tile0")
+    for st in range(4):
+        if st:
+            a.label("tile%d" % st)
+        a.e("s_cmp_ge_u32 %s, %s" % (s("t"), s("nt")))
+        a.e("s_cbranch_scc1 %s" % a.ref("drain"))
+        a.e("s_cmp_lg_u32 %s, 0" % s("masked"))
+        a.e("s_cbranch_scc1 %s" % a.ref("mtile%d" % st))
+        tile_body(a, st, False)
+        if st == 3:
+            a.e("s_branch %s" % a.ref("tile0"))
+    for st in range(4):
+        a.label("mtile%d" % st)
+        tile_body(a, st, True)
+        a.e("s_branch %s" % a.ref("tile%d" % ((st + 1) & 3)))
+    # ---- drain: P V of the last unit (B, 1): its fragments are in registers
+    a.label("drain")
+    a.e("s_waitcnt lgkmcnt(0)")
+    for k in range(4):
+        db, t2 = k & 1, k >> 1
+        a.e(mfma(O(1, db, 0), VF(1, 2 * t2 + db), P(1, t2), O(1, db, 0)))
+    a.e("s_nop 15")
+    a.e("s_nop 3")
+    epilogue(a)
+    a.e("s_branch %s" % a.ref("itemend"))
+
+    # ---------------------------------------------------------------- wave without queries: DMA, tail fix and barriers only
+    a.label("light")
+    emit_rounds_012(a)
+    a.e("s_waitcnt vmcnt(10)")
+    a.e("s_barrier")
+    a.e("s_mov_b32 %s, 0" % s("ibad"))
+    a.label("ltile0")
+    for st in range(4):
+        if st:
+            a.label("ltile%d" % st)
+        a.e("s_cmp_ge_u32 %s, %s" % (s("t"), s("nt")))
+        a.e("s_cbranch_scc1 %s" % a.ref("itemend"))
+        a.e("s_waitcnt vmcnt(5)")
+        tail_fix(a, (st + 1) & 3, "%dL" % st)
+        a.e("s_barrier")
+        for pair in dma_round((st + 3) & 3):
+            for t in pair:
+                a.e(t)
+        for t in advance_round():
+            a.e(t)
+        a.e("s_add_u32 %s, %s, 1" % (s("t"), s("t")))
+        if st == 3:
+            a.e("s_branch %s" % a.ref("ltile0"))
+
+    # ---------------------------------------------------------------- item end: flag, drain the surplus rounds and the stores
+    a.label("itemend")
+    a.e("v_mov_b32 %s, %s" % (v(T[0]), s("wave")))
+    a.e("v_lshl_add_u32 %s, %s, 2, %s" % (v(T[0]), v(T[0]), s("lds")))
+    a.e("v_add_u32 %s, 0x%x, %s" % (v(T[0]), FLAG0, v(T[0])))
+    a.e("v_mov_b32 %s, %s" % (v(T[1]), s("ibad")))
+    a.e("ds_write_b32 %s, %s" % (v(T[0]), v(T[1])))
+    a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.e("s_add_u32 %s, %s, 1" % (s("it"), s("it")))
+    a.label("next")
+    a.e("s_add_u32 %s, %s, %s" % (s("v"), s("v"), s("G")))
+    a.e("s_branch %s" % a.ref("item"))
+
+    # ================================================================ after the last item: its flags
+    a.label("done")
+    a.e("s_barrier")
+    a.e("s_cmp_eq_u32 %s, 0" % s("it"))
+    a.e("s_cbranch_scc1 %s" % a.ref("out"))
+    a.e("v_mov_b32 %s, %s" % (v(T[0]), s("lds")))
+    a.e("v_add_u32 %s, 0x%x, %s" % (v(T[0]), FLAG0, v(T[0])))
+    a.e("ds_read_b128 %s, %s" % (vr(T[2], 4), v(T[0])))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("v_or_b32 %s, %s, %s" % (v(T[2]), v(T[2]), v(T[3])))
+    a.e("v_or3_b32 %s, %s, %s, %s" % (v(T[2]), v(T[2]), v(T[4]), v(T[5])))
+    a.e("v_readfirstlane_b32 %s, %s" % (s("x0"), v(T[2])))
+    a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
+    a.e("s_cbranch_scc1 %s" % a.ref("out"))
+    a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("it")))
+    a.e("s_bitset1_b64 %s, %s" % (s2("bad"), s("x0")))
+    a.label("out")
+    a.e("s_barrier")
+    a.e("s_mov_b64 %[bad], " + s2("bad"))
+    return a.lines
+
+
+def main():
+    lines = generate()
+    with open(OUT, "w") as f:
+        f.write("// GENERATED by tools/gen/attn_p64_gen.py -- do not edit.  %d instructions / labels.\n" % len(lines))
+        f.write("// LDS image: %d stages x %d B, key_add rows at %d, flags at %d, %d bytes in all.\n" % (NS, STAGE, KADD0, FLAG0, LDS_BYTES))
+        for ln in lines:
+            if ln.startswith(";"):
+                continue
+            f.write('"%s\\n\\t"\n' % ln)
+    print("wrote", OUT, len(lines), "lines")
+
+
+if __name__ == "__main__":
+    main()
+
+
+# ---------------------------------------------------------------- hazard lint (the assembler inserts no wait states)
+def _regs(tok):
+    import re
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def lint(lines):
+    """MFMA result -> any other access of those registers needs 12 wait states (measured on hipcc's own output for gfx950:
+    s_nop 11 between v_mfma_f32_32x32x16_bf16 and a VALU / memory read of its result, or a later MFMA reading it as A / B; back-to-back
+    accumulation into the same registers needs none); VALU write -> MFMA A / B read: 2.  Straight-line approximation: labels and
+    branches are ignored, which is conservative enough for this stream (every block starts and ends far from an MFMA's result use)."""
+    import re
+    recent = []          # (age in wait states, kind, written regs)
+    problems = []
+    for n, ln in enumerate(lines):
+        if ln.endswith(":") or ln.startswith(";"):
+            continue
+        op, _, rest = ln.partition(" ")
+        toks = [t.strip() for t in re.split(r",|\s+offset:\d+", rest) if t and t.strip()]
+        states = 1
+        if op == "s_nop":
+            states = int(toks[0]) + 1
+        if op.startswith("v_mfma"):
+            dst, a_, b_, c_ = _regs(toks[0]), _regs(toks[1]), _regs(toks[2]), _regs(toks[3])
+            for age, kind, wr in recent:
+                if kind == "mfma" and age < 12 and (wr & (a_ | b_)):
+                    problems.append((n, ln, "MFMA result read as A/B after %d states" % age))
+                if kind == "mfma" and age < 12 and (wr & (dst | c_)) and not (wr == dst and (c_ == dst or not c_)):
+                    problems.append((n, ln, "MFMA overlapping accumulate after %d states" % age))
+                if kind == "valu" and age < 2 and (wr & (a_ | b_ | c_)):
+                    problems.append((n, ln, "VALU result read by MFMA after %d states" % age))
+            recent = [(a + states, k, w) for a, k, w in recent if a + states < 24] + [(0, "mfma", dst)]
+            continue
+        used = set()
+        for t in toks:
+            used |= _regs(t)
+        if op.startswith(("v_", "ds_", "global_")):
+            for age, kind, wr in recent:
+                if kind == "mfma" and age < 12 and (wr & used):
+                    problems.append((n, ln, "MFMA result touched after %d states" % age))
+        wrote = set()
+        if op.startswith("v_") and toks and not op.startswith("v_cmp"):
+            wrote = _regs(toks[0])
+            if op.startswith("v_permlane32_swap"):
+                wrote |= _regs(toks[1])
+        recent = [(a + states, k, w) for a, k, w in recent if a + states < 24]
+        if wrote:
+            recent.append((0, "valu", wrote))
+    return problems
+
+
+if __name__ == "__main__":
+    import sys
+    if "--lint" in sys.argv:
+        probs = lint(generate())
+        for n, ln, why in probs[:40]:
+            print("line %d: %s  <- %s" % (n, ln, why))
+        print("%d hazard findings" % len(probs))

@@ -703,6 +703,14 @@ __device__ __forceinline__ int attn_opaque_lane() {
     return l;
 }
 
+#ifdef ATTN_WGTRACE
+// development build only (tools/attn_wgtrace.py): constant-clock (100 MHz) stamps of wave 0 of EVERY workgroup -- entry, loop start,
+// loop end, exit -- plus the hardware slot it ran on: the whole-chip timeline of a launch
+__device__ unsigned long long g_attn_wg[8192 * 6];
+#define ATTN_WGSTAMP(i) do { ATTN_SB(); wg_t[i] = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ATTN_SB(); } while (0)
+#else
+#define ATTN_WGSTAMP(i) do { } while (0)
+#endif
 #ifdef ATTN_TRACE
 // development build only (tools/attn_trace.py): shader-clock stamps of wave 0 of workgroup 0, summed per phase over the tiles
 __device__ unsigned long long g_attn_trace[16 + 8 * 32];
@@ -715,24 +723,25 @@ __device__ unsigned long long g_attn_trace[16 + 8 * 32];
 #define ATTN_STAMP(i) do { } while (0)
 #endif
 
-template <int NS>
-__global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
+// One 256-query item (query block qb of head h of sample b).  PASS1 = false: the exact pass only (attn_p64_kernel's flagged items).
+template <int NS, bool PASS1>
+__device__ __forceinline__ void attn_w64_item(const AttnParams& p, const int qb, const int h, const int b, char* smem, const int tid) {
     constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
     constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
     constexpr int FLAG0 = KADD0 + NS * 4 * 256;           // 4 x int: "this wave wants the exact pass"
     constexpr int VM = 5;                                 // VMEM operations per wave and tile: 2 K + 2 V^T pieces + the key_add row
     static_assert(NS == 4, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
-    int qb, h, b;
-    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+#ifdef ATTN_WGTRACE
+    unsigned long long wg_t[4];
+    ATTN_WGSTAMP(0);
+#endif
 #ifdef ATTN_TRACE
     unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
     const unsigned long long tr_start = tr_last;
     int tr_slot0 = 0, tr_tile = 0;
 #endif
 
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = p.N, Npad = p.Npad;
     const size_t bh = (size_t)b * p.H + h;
@@ -817,6 +826,22 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) { o[x][0][r] = 0.f; o[x][1][r] = 0.f; }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    auto load_q = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int qrow = q0 + 32 * x + (lane & 31);
+            const int qld = qrow < N ? qrow : N - 1;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) qf[x][kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
+            if (!p.q_prescaled) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[x][kk][e] = f2bf(bf2f(qf[x][kk][e]) * (0.125f * ATTN_LOG2E));
+            }
+        }
+    };
+
     // =============================== pass 1: p = exp2(s), no maximum ===============================
     // Software pipeline across tiles, four phases of 8 MFMAs, each beside ONE half of a block's softmax (16 exponentials, 16 row-sum
     // adds, 8 packs: five single-issue fillers per MFMA, the guide's budget for one wave):
@@ -826,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     //   phase 4: P V of block 0, tile t         | softmax of block 1, tile t, keys 0..31
     // Block 1 trails block 0 by half a tile, so no phase is MFMA-only or VALU-only.  Tile t-1's V^T stage is read in tile t: the
     // ring has four stages (t-1, t, and rounds t+1, t+2 in flight) and round t+2 is issued behind tile t's barrier.
-    {
+    if constexpr (PASS1) {
         static_assert(NS == 4, "the pipelined pass needs four stages");
         float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         union PF { uint32_t u[4]; bf16x8 v; };
@@ -995,26 +1020,16 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         // the first two rounds go out before anything else; q shares their flight
         issue(0, 0);
         if (1 < nt) issue(1, 1);
-    #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const int qrow = q0 + 32 * x + (lane & 31);
-            const int qld = qrow < N ? qrow : N - 1;
-    #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) qf[x][kk] = *reinterpret_cast<const bf16x8*>(Q + (size_t)qld * 64 + (2 * kk + half) * 8);
-            if (!p.q_prescaled) {
-    #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-    #pragma unroll
-                    for (int e = 0; e < 8; ++e) qf[x][kk][e] = f2bf(bf2f(qf[x][kk][e]) * (0.125f * ATTN_LOG2E));
-            }
-        }
+        load_q();
 
 
         // q has landed (and rounds 0 / 1 with it), and hipcc KNOWS it (the builtin, not inline asm): otherwise every MFMA that reads a
         // q fragment inside the loop gets a compiler-inserted s_waitcnt vmcnt(0), which drains the DMA ring once per phase
         __builtin_amdgcn_s_waitcnt(0);
         ATTN_STAMP(6);                                      // [6] = prologue (q loads, addresses)
+        ATTN_WGSTAMP(1);
         for (int t = 0; t < nt; ++t) tile(t, t & 3);
+        ATTN_WGSTAMP(2);
         // drain: block 1 of the last tile
         if (active) {
             PF pf1b[2];
@@ -1039,8 +1054,8 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
 
     // one check per item: did exp2 overflow, or flush a whole row?  Workgroup-wide decision (pass 2 needs every wave for its DMA
     // ring and barriers)
-    bool bad = false;
-    if (active) {
+    bool bad = !PASS1;
+    if (PASS1 && active) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
@@ -1048,7 +1063,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         }
         bad = __any(bad);
     }
-    {
+    if constexpr (PASS1) {
         int* flags = reinterpret_cast<int*>(smem + FLAG0);
         if (lane == 0) flags[wave] = bad ? 1 : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1061,6 +1076,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     // =============================== pass 2 (rare): online softmax with true row maxima ===============================
     if (bad) {
         __builtin_amdgcn_s_barrier();                       // every wave has read the flags; the ring may be refilled
+        if constexpr (!PASS1) { load_q(); __builtin_amdgcn_s_waitcnt(0); }
         float m_run[2] = {-INFINITY, -INFINITY};
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
@@ -1173,6 +1189,15 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
                 }
         }
     }
+#ifdef ATTN_WGTRACE
+    ATTN_WGSTAMP(3);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned long long* w = g_attn_wg + (size_t)blockIdx.x * 6;
+        w[0] = wg_t[0]; w[1] = wg_t[1]; w[2] = wg_t[2]; w[3] = wg_t[3];
+        w[4] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        w[5] = (unsigned long long)((qb << 20) | (h << 12) | b);
+    }
+#endif
 #ifdef ATTN_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ATTN_STAMP(7);                                          // [7] = epilogue (normalise + stores)
@@ -1183,6 +1208,15 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
         for (int i = 0; i < 8 * 32; ++i) g_attn_trace[16 + i] = reinterpret_cast<unsigned int*>(smem + ATTN_TRACE_OFF)[i];
     }
 #endif
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
+    int qb, h, b;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+    attn_w64_item<NS, true>(p, qb, h, b, smem, (int)threadIdx.x);
 }
 
 template <int NS>
@@ -1206,6 +1240,65 @@ static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
     p.xcd_map = total >= 400 ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// attn_p64_kernel: the hand-scheduled form of attn_w64_kernel (same item shape -- four waves x 64 queries --, same LDS image, same
+// arithmetic).  Persistent workgroups walk the items; pass 1 of the whole walk is ONE inline-asm statement generated by
+// tools/gen/attn_p64_gen.py (attn_p64_asm.inc) that owns every vector register: units of 4 score MFMAs + 40 VALU + 4 P V MFMAs in a
+// three-deep software pipeline, 32 live score registers instead of 64, every K / V^T fragment read once per tile.  Items whose row
+// sums leave [2^-100, 2^100] come back as bits of `bad` and are redone by attn_w64_item's exact pass (compiler-scheduled, rare).
+// Requires pre-scaled q and at least two key tiles (the launcher falls back to attn_w64_kernel otherwise).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int v0 = (int)blockIdx.x, G = (int)gridDim.x;
+    const int kas = p.key_add_stride * 4;
+    uint64_t bad = 0;
+#if __HIP_DEVICE_COMPILE__              // the host pass of hipcc parses kernel bodies too and knows no gfx950 register names
+    asm volatile(
+#include "attn_p64_asm.inc"
+        : [bad] "=s"(bad)
+        : [q] "s"(p.q), [k] "s"(p.k), [vt] "s"(p.vt), [ka] "s"(p.key_add), [o] "s"(p.o), [N] "s"(p.N), [Npad] "s"(p.Npad), [H] "s"(p.H),
+          [total] "s"(total), [cnt] "s"(cnt), [v] "s"(v0), [G] "s"(G), [kas] "s"(kas), [wave] "s"(wave), [lds] "s"(lds0), [nqb] "s"(nqb),
+          [mq] "s"(mq), [mh] "s"(mh)
+        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+#endif
+    if (bad == 0) return;
+    int it = 0;
+    for (int v = v0; v < 8 * cnt; v += G) {
+        int qb, h, b;
+        if (!attn_decode_block(v, total, nqb, p.H, true, qb, h, b)) continue;
+        if ((bad >> it) & 1) attn_w64_item<4, false>(p, qb, h, b, smem, wave * 64 + attn_opaque_lane());
+        ++it;
+    }
+}
+
+static hipError_t launch_attn_p64(const AttnParams& p_in, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * 16384 + (size_t)4 * 4 * 256 + 16;
+    const int nt = (p_in.N + 63) / 64;
+    if (!p_in.q_prescaled || nt < 2) return launch_attn_w64<4>(p_in, s);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_p64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    g_last_kernel = "attn_p64_kernel";
+    const int nqb = (nt + 3) / 4;
+    const int total = nqb * p_in.H * p_in.B, cnt = (total + 7) / 8;
+    int wgs = tune_get(p_in.tune, &uvl_tuning::attn_wgs, 512);          // persistent workgroups (two per CU)
+    wgs = wgs < 8 ? 8 : (wgs + 7) / 8 * 8;
+    int grid = 8 * cnt < wgs ? 8 * cnt : wgs;
+    while ((8 * cnt + grid - 1) / grid > 64) grid += 8;                   // the flagged-item mask of a workgroup has 64 bits
+    auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
+    AttnParams p = p_in;
+    p.xcd_map = 1;
+    hipLaunchKernelGGL(attn_p64_kernel, dim3(grid), dim3(256), lds, s, p, total, cnt, nqb, magic(nqb), magic(p_in.H));
     return hipGetLastError();
 }
 
@@ -1252,6 +1345,9 @@ static hipError_t launch_attn_cfg(const AttnParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef ATTN_WGTRACE
+extern "C" int uvl_debug_attn_wgtrace(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_wg), (size_t)n * 6 * sizeof(unsigned long long)); }
+#endif
 #ifdef ATTN_TRACE
 extern "C" int uvl_debug_attn_trace(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), (16 + 8 * 32) * sizeof(unsigned long long)); }
 #endif
@@ -1313,6 +1409,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 8: return launch_attn_stream<3>(p, s);        // batched: 128 queries per workgroup, speculative tiles
         case 9: return launch_attn_stream<2>(p, s);
         case 10: return launch_attn_w64<4>(p, s);          // 64 queries per wave, two workgroups per CU
+        case 11: return launch_attn_p64(p, s);             // the same item shape, hand-scheduled, persistent workgroups
     }
     return hipErrorInvalidValue;
 }
