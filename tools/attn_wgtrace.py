@@ -17,11 +17,32 @@ from uvltrack_amd import build as B  # noqa: E402
 LIB = os.path.join(ROOT, "tools", "probes", "libuvl_wgtrace.so")
 
 
+def build_variants(names):
+    """timing-only ablations of attn_pp_kernel (PP_ABL of tools/gen/attn_pp_gen.py): libuvl_wgtrace_<name>.so, attention.hip recompiled,
+    the other objects shared with the plain trace build"""
+    probes = os.path.join(ROOT, "tools", "probes")
+    for name in names:
+        d = os.path.join(probes, "abl_" + name)
+        os.makedirs(d, exist_ok=True)
+        env = dict(os.environ, PP_ABL=name.replace("+", ","))
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_pp_gen.py"), "--trace", os.path.join(d, "attn_pp_asm_trace.inc")], check=True, env=env)
+        subprocess.run(["cp", os.path.join(probes, "attn_p64_asm_trace.inc"), d], check=True)
+        obj = os.path.join(d, "attention.o")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DATTN_WGTRACE", "-I", d, "-c", os.path.join(B.CSRC, "attention.hip"), "-o", obj], check=True)
+        objs = [obj] + [os.path.join(probes, "wgtrace_" + src.replace(".hip", ".o")) for src in B.SOURCES if src != "attention.hip"]
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(probes, "libuvl_wgtrace_%s.so" % name)] + objs, check=True)
+        print("built variant", name)
+
+
 def build():
+    if "--variants" in sys.argv:
+        return build_variants(sys.argv[sys.argv.index("--variants") + 1].split(":"))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_p64_gen.py"), "--trace", os.path.join(ROOT, "tools", "probes", "attn_p64_asm_trace.inc")], check=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_pp_gen.py"), "--trace", os.path.join(ROOT, "tools", "probes", "attn_pp_asm_trace.inc")], check=True)
     objs = []
     for src in B.SOURCES:
         obj = os.path.join(ROOT, "tools", "probes", "wgtrace_" + src.replace(".hip", ".o"))
-        subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DATTN_WGTRACE", "-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
+        subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DATTN_WGTRACE", "-I", os.path.join(ROOT, "tools", "probes"), "-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
         objs.append(obj)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
     print("built", LIB)
@@ -60,6 +81,7 @@ def main():
     a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 6).astype(np.int64)
     a = a[a[:, 3] > 0]
     t = a[:, :4] * 10.0                                    # ns (100 MHz)
+    t5 = a[:, 5] * 10.0                                    # cfg 11: stores issued (the exit stamp is behind their completion)
     t0 = t[:, 0].min()
     hw = a[:, 4] & 0xffffffff
     xcc = (a[:, 4] >> 32) & 0xf
@@ -72,6 +94,25 @@ def main():
     q50 = lambda x: "%.2f / %.2f / %.2f" % tuple(np.percentile(x, [10, 50, 90]) / 1e3)
     print("  us (10 / 50 / 90 %%):  entry after first entry %s | prologue %s | tile loop %s | epilogue %s | whole item %s" %
           (q50(t[:, 0] - t0), q50(t[:, 1] - t[:, 0]), q50(t[:, 2] - t[:, 1]), q50(t[:, 3] - t[:, 2]), q50(t[:, 3] - t[:, 0])))
+    if cfg == 11:
+        G = int(os.environ.get("P64_WGS", "512"))
+        nt = (N + 63) // 64
+        nqb = (nt + 3) // 4
+        cnt = nwg8 // 8
+        vv = np.nonzero(np.frombuffer(buf, dtype=np.uint64).reshape(n, 6)[:, 3] > 0)[0]
+        L = (vv & 7) * cnt + (vv >> 3)
+        qbs = L % nqb
+        rnd = vv // G
+        loop = (t[:, 2] - t[:, 1]) / 1e3
+        for r in range(int(rnd.max()) + 1):
+            print("   round %d: tile loop us by query block: %s" % (r, "  ".join("qb%d %.1f/%.1f/%.1f (n=%d)" % ((q,) + tuple(np.percentile(loop[(rnd == r) & (qbs == q)], [10, 50, 90])) + (int(((rnd == r) & (qbs == q)).sum()),)) for q in range(nqb) if ((rnd == r) & (qbs == q)).any())))
+        first = rnd == 0
+        print("   round 0 median loop us by XCD, first / second workgroup of a CU: " + "  ".join("x%d %.1f/%.1f" % (x, np.median(loop[first & (xcc == x) & (vv < G // 2)]), np.median(loop[first & (xcc == x) & (vv >= G // 2)])) for x in range(8)))
+        pro = (t[:, 1] - t[:, 0]) / 1e3
+        print("   round 0 median prologue us by XCD: " + "  ".join("x%d %.1f/%.1f" % (x, np.median(pro[first & (xcc == x) & (vv < G // 2)]), np.median(pro[first & (xcc == x) & (vv >= G // 2)])) for x in range(8)))
+        slow = np.argsort(-loop)[:8]
+        print("   slowest loops: " + "  ".join("v%d r%d qb%d xcc%d %.1fus@%.1f" % (vv[i], rnd[i], qbs[i], xcc[i], loop[i], (t[i, 1] - t0) / 1e3) for i in slow))
+        print("  cfg 11: epilogue arithmetic + store issue %s | store / surplus-round drain %s" % (q50(t5 - t[:, 2]), q50(t[:, 3] - t5)))
     # per CU: successive workgroups
     gaps, per_cu = [], {}
     for i in range(len(a)):

@@ -1,55 +1,60 @@
-"""Generator of the hand-scheduled fused-attention item walk (attn_p64_kernel, uvltrack_amd/csrc/attention.hip).
+"""Generator of the phase-alternating ("ping-pong") fused-attention item walk: attn_pp_kernel (uvltrack_amd/csrc/attention.hip).
 
-    python tools/gen/attn_p64_gen.py          # rewrites uvltrack_amd/csrc/attn_p64_asm.inc
+    python tools/gen/attn_pp_gen.py [--lint]          # rewrites uvltrack_amd/csrc/attn_pp_asm.inc
 
-The output is ONE inline-asm statement body (a C string literal): the whole pass-1 walk of a persistent workgroup over its items --
-item decode, q loads, DMA ring, key tiles, drain, normalise + store -- with every register owned by this file.  hipcc sees only SGPR
-operands and the clobber list, so its register allocator (the 256-register wall of attn_w64_kernel) is out of the picture.
+Why.  The whole-chip timeline of attn_p64_kernel (tools/attn_wgtrace.py, profiles/r03_attention.md) shows that two co-resident waves
+that both interleave MFMAs and softmax VALU do not share a SIMD: the older one runs at ~70 cycles per MFMA, the younger at ~210, the
+matrix pipe is ~60 % busy.  At head_dim 64 a wave needs the VALU port about as long as the matrix pipe (2 exp2 + 2 adds + 1 pack per
+MFMA), so the two resources only fill when one wave of the SIMD is in an MFMA-only phase while the other is in a VALU-only phase.
 
-Same math, LDS image and MFMA operand trick as attn_w64_kernel (reference: lib/models/backbones/block.py:47-61 -- q k^T * scale,
-masked_fill, softmax, @ v): S^T = K Q^T per 32 keys x 32 queries, p = exp2(s) with NO running maximum (checked once per item, failing
-items are redone by the compiler-scheduled exact pass), P^T feeds V^T P^T as the B operand without data movement.
+Structure.  One workgroup = 8 waves = two HALVES of four waves; waves w and w + 4 share a SIMD.  Each half walks its own 256-query
+items (64 queries per wave) through its own DMA ring -- the halves share nothing but the barriers.  A wave alternates
+    M(t, jb): 16 MFMAs -- scores of key block jb of tile t for both query blocks (8) + P V of the previous key block (8)
+    V(t, jb): the softmax of those scores (80 VALU) + the fragment reads of the next M (8 ds_read_b128)
+with an s_barrier between phases; half 1 runs one barrier behind half 0, so on every SIMD one wave is in M while the other is in V.
+A wave's own stream is strictly serial (no intra-wave interleave to schedule), only 32 score + 16 P + 32 fragment registers are live.
 
-Schedule.  A wave owns 64 queries = two 32-query blocks x (A, B); a 64-key tile is four UNITS (x, jb) = (A,0) (B,0) (A,1) (B,1), each
-4 score MFMAs + 40 VALU (16 exp2, 16 row-sum adds, 8 bf16 packs) + 4 P V MFMAs.  Slot u runs  score MFMAs of unit u+1 | softmax VALU of
-unit u | P V MFMAs of unit u-1, MFMAs alternating between the two accumulator chains, the 40 VALU spread over the eight MFMA gaps
-(5 per gap).  Only 32 score registers and 16 P registers are live, K / V^T fragments are read once per tile and double-buffered
-(4 ds_read_b128 per slot), one barrier and five LDS-DMA instructions per tile, the ring runs three rounds ahead.
+Same math, LDS tile image and operand trick as attn_w64_kernel / attn_p64_kernel (reference: lib/models/backbones/block.py:47-61).
 """
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import attn_p64_gen as g1  # noqa: E402  (shared helpers: lint, swizzle conventions)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-OUT = os.path.join(ROOT, "uvltrack_amd", "csrc", "attn_p64_asm.inc")
+OUT = os.path.join(ROOT, "uvltrack_amd", "csrc", "attn_pp_asm.inc")
 
-# ---------------------------------------------------------------- LDS image (bytes from the workgroup's LDS base)
-STAGE = 16384            # K tile 8 KB + V^T tile 8 KB
+STAGE = 16384
 NS = 4
-KADD0 = NS * STAGE       # [stage][wave][64] f32 key_add rows
-FLAG0 = KADD0 + NS * 4 * 256
-LDS_BYTES = FLAG0 + 16
+KADD0 = NS * STAGE                  # per half: [stage][wave][64] f32 key_add rows
+FLAG0 = KADD0 + NS * 4 * 256        # per half: 4 x int
+HALF = FLAG0 + 64                   # bytes of LDS per half
+LDS_BYTES = 2 * HALF
 
 # ---------------------------------------------------------------- VGPR map
 def O(x, db, r): return 32 * x + 16 * db + r
 def Q(x, kk): return 64 + 16 * x + 4 * kk
-def S(par, r): return 96 + 16 * par + r
-def P(par, t2): return 128 + 8 * par + 4 * t2
-def KF(buf, k): return 144 + 16 * buf + 4 * k
-def VF(buf, f): return 176 + 16 * buf + 4 * f          # f = 2 * t2 + db
-def KA(r): return 208 + r
-def PS(x, i): return 224 + 2 * x + i
-def KOFF(kk): return 228 + kk
-def VOFF(jb, t2): return 232 + 2 * jb + t2
-def DK(i): return 236 + i
-def DV(i): return 238 + i
-V_DKA, V_KAREAD, V_KAADDR, V_LIM, V_NEGINF, V_KACUR = 240, 241, 242, 243, 244, 245
-def QOFF(x): return 246 + x
-V_HALF8 = 255
-T = [248, 249, 250, 251, 252, 253, 254]          # T[2..5] is an aligned quad
+def S(x, r): return 96 + 16 * x + r
+def P(x, t2): return 128 + 8 * x + 4 * t2
+def KF(k): return 144 + 4 * k
+def VF(f): return 160 + 4 * f                      # f = 2 * t2 + db
+def KA(r): return 176 + r
+def PS(x, i): return 192 + 2 * x + i
+def KOFF(kk): return 196 + kk
+def VOFF(jb, t2): return 200 + 2 * jb + t2
+def DK(i): return 204 + i
+def DV(i): return 206 + i
+V_DKA, V_KAREAD, V_KAADDR, V_LIM, V_NEGINF, V_KACUR, V_HALF8 = 208, 209, 210, 211, 212, 213, 214
+def QOFF(x): return 216 + x
+T = [218, 219, 220, 221, 222, 223, 224]            # T[2..5] = v220..v223, an aligned quad
+BUF = 96                                           # epilogue: packed rows in the dead score / P / fragment registers
+NV = 226                                           # registers v0..v225
 
-# ---------------------------------------------------------------- SGPR map (fixed; the operands are copied here first)
-SG = dict(q=40, k=42, vt=44, ka=46, o=48, N=50, Npad=51, H=52, total=53, cnt=54, v=55, G=56, vend=57, kas=58, wave=59, lds=60,
+SG = dict(q=40, k=42, vt=44, ka=46, o=48, N=50, Npad=51, H=52, total=53, cnt=54, idx=55, istr=56, kas=58, wave=59, lds=60,
           nqb=61, mq=62, mh=63, nt=64, ntail=65, tailf=66, qb=67, h=68, b=69, Kp=70, Vp=72, Ap=74, Qp=76, Op=78, t=80, masked=81,
-          mnext=82, active=83, r=84, it=85, bad=86, x0=88, x1=89, x2=90, x3=91, x4=92, x5=93, wl=94, wa=95, ibad=96, q0=97, vrow=98, x6=99)
+          mnext=82, active=83, r=84, it=85, bad=86, x0=88, x1=89, x2=90, x3=91, x4=92, x5=93, wl=94, wa=95, ibad=96, q0=97,
+          have=98, half=99, xcd=57, trace=39, pmask=38)
 
 
 def s(n): return "s%d" % SG[n]
@@ -59,31 +64,20 @@ def v(n): return "v%d" % n
 def vr(n, c): return "v[%d:%d]" % (n, n + c - 1)
 
 
-class Asm:
-    def __init__(self):
-        self.lines = []
-        self.nlabel = 0
-
-    def e(self, text):
-        self.lines.append(text)
-
-    def label(self, name):
-        self.lines.append(name + "_%=:")
-
-    def ref(self, name):
-        return name + "_%="
-
-    def comment(self, text):
-        self.lines.append("; " + text)
+OPT = dict(prio=1, dma_in_m=1)
+# timing-only ablations for tools/attn_pp_trace.py (WRONG results): PP_ABL=noexp,novalu,nodma,nolds,nobar,prio0,dmav
+ABL = set(x for x in os.environ.get("PP_ABL", "").split(",") if x)
+if "prio0" in ABL:
+    OPT["prio"] = 0
+if "dmav" in ABL:
+    OPT["dma_in_m"] = 0
 
 
-# ---------------------------------------------------------------- pieces
 def mfma(dst, a, b, c):
     return "v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (vr(dst, 16), vr(a, 4), vr(b, 4), "0" if c is None else vr(c, 16))
 
 
 def dma_round(stage):
-    """The five LDS-DMA instructions of one round into `stage`, as (m0 set, load) pairs; the pointer update comes last."""
     out = []
     for i in range(2):
         out.append(["s_add_u32 m0, %s, %d" % (s("wl"), stage * STAGE + i * 4096), "s_nop 0", "global_load_lds_dwordx4 %s, %s" % (v(DK(i)), s2("Kp"))])
@@ -94,8 +88,6 @@ def dma_round(stage):
 
 
 def advance_round():
-    """Round pointers walk to the next key tile; past the item's last tile they stay (the surplus rounds reload the last tile into
-    stages nobody reads: the vmcnt arithmetic stays uniform and no address leaves the allocation)."""
     return ["s_add_u32 %s, %s, 1" % (s("r"), s("r")),
             "s_cmp_lt_u32 %s, %s" % (s("r"), s("nt")),
             "s_cselect_b32 %s, 8192, 0" % s("x0"),
@@ -109,30 +101,42 @@ def advance_round():
             "s_addc_u32 %s, %s, 0" % (shi("Ap"), shi("Ap"))]
 
 
+def dma_guarded(a, pairs, tag):
+    """a half without an item (odd item count) keeps the barrier skeleton and issues nothing"""
+    if "nodma" in ABL and not tag.startswith("L"):
+        return
+    skip = "nod%s" % tag
+    a.e("s_cmp_eq_u32 %s, 0" % s("have"))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip))
+    for pair in pairs:
+        for t in pair:
+            a.e(t)
+    a.label(skip)
+
+
 def tail_fix(a, stage, tag):
-    """Zero the V^T columns of keys >= N in this wave's own two pieces of the tail tile (NaN-proof: 0 x garbage would poison P V);
-    executed once per item, behind the wave's own vmcnt wait and in front of the barrier.  The K rows need nothing: scores of keys
-    >= N are replaced, not added to."""
+    """zero the V^T columns of keys >= N in this wave's own two pieces of the tail tile (see attn_p64_gen.tail_fix)"""
     skip = "tfx%s" % tag
-    a.e("s_add_u32 %s, %s, 2" % (s("x0"), s("t")))                       # this barrier publishes tile t + 1; the tail tile is nt - 1
+    a.e("s_add_u32 %s, %s, 2" % (s("x0"), s("t")))
     a.e("s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")))
     a.e("s_cselect_b32 %s, %s, 0" % (s("x0"), s("tailf")))
+    a.e("s_and_b32 %s, %s, %s" % (s("x0"), s("x0"), s("have")))
     a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
     a.e("s_cbranch_scc1 %s" % a.ref(skip))
     t0, t1, m1, m2 = T[0], T[1], T[6], V_KACUR
-    d = T[2]                                                              # T[2..5] = v250..v253, an aligned quad
+    d = T[2]
     a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(t1))
-    a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(t1), v(t1)))                 # lane
+    a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(t1), v(t1)))
     a.e("v_and_b32 %s, 7, %s" % (v(t0), v(t1)))
     a.e("v_lshrrev_b32 %s, 4, %s" % (v(m1), v(t1)))
     a.e("s_and_b32 %s, %s, 1" % (s("x0"), s("wave")))
     a.e("s_lshl_b32 %s, %s, 2" % (s("x0"), s("x0")))
     a.e("v_add_u32 %s, %s, %s" % (v(m1), s("x0"), v(m1)))
     a.e("v_xor_b32 %s, %s, %s" % (v(t0), v(t0), v(m1)))
-    a.e("v_lshlrev_b32 %s, 3, %s" % (v(t0), v(t0)))                       # 8 * chunk
-    a.e("v_sub_u32 %s, %s, %s" % (v(t0), s("ntail"), v(t0)))              # valid keys of this lane's 8
+    a.e("v_lshlrev_b32 %s, 3, %s" % (v(t0), v(t0)))
+    a.e("v_sub_u32 %s, %s, %s" % (v(t0), s("ntail"), v(t0)))
     a.e("v_lshlrev_b32 %s, 4, %s" % (v(t1), v(t1)))
-    a.e("v_add_u32 %s, %s, %s" % (v(t1), s("wl"), v(t1)))                 # own piece 0 of stage 0's K half
+    a.e("v_add_u32 %s, %s, %s" % (v(t1), s("wl"), v(t1)))
     for i in range(2):
         off = stage * STAGE + 8192 + i * 4096
         a.e("ds_read_b128 %s, %s offset:%d" % (vr(d, 4), v(t1), off))
@@ -152,7 +156,6 @@ def tail_fix(a, stage, tag):
 
 
 def ka_load(stage, jb):
-    """masked variant: this wave's copy of the tile's key_add row, the 16 values of key block jb in score-register order"""
     out = []
     for gq in range(4):
         off = stage * 1024 + jb * 128 + (gq >> 1) * 64 + (gq & 1) * 16
@@ -161,25 +164,17 @@ def ka_load(stage, jb):
 
 
 def ka_scale():
-    return ["v_mul_f32 %s, 0x3fb8aa3b, %s" % (v(KA(r)), v(KA(r))) for r in range(16)]       # log2 domain
+    return ["v_mul_f32 %s, 0x3fb8aa3b, %s" % (v(KA(r)), v(KA(r))) for r in range(16)]
 
 
-def mask_apply(par, jb):
-    """s = key < limit ? s + key_add : -inf   (limit = valid keys of the tile - 8 * half; 64 - 8 * half unless it is the tail)"""
+def mask_apply(x, jb):
     out = []
     for r in range(16):
         key = 32 * jb + 16 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3)
-        out.append("v_add_f32 %s, %s, %s" % (v(S(par, r)), v(S(par, r)), v(KA(r))))
+        out.append("v_add_f32 %s, %s, %s" % (v(S(x, r)), v(S(x, r)), v(KA(r))))
         out.append("v_cmp_lt_i32 vcc, %d, %s" % (key, v(V_LIM)))
-        out.append("v_cndmask_b32 %s, %s, %s, vcc" % (v(S(par, r)), v(V_NEGINF), v(S(par, r))))
+        out.append("v_cndmask_b32 %s, %s, %s, vcc" % (v(S(x, r)), v(V_NEGINF), v(S(x, r))))
     return out
-
-
-OPT = dict(prio=1)
-ABL = set(x for x in os.environ.get("P64_ABL", "").split(",") if x)      # timing-only ablations (WRONG results): prio0, nobar
-if "prio0" in ABL:
-    OPT["prio"] = 0
-SG["pmask"] = 39
 
 
 def softmax_gaps(x):
@@ -194,15 +189,47 @@ def softmax_gaps(x):
         if i >= 1:
             gaps[i] += [ad(2 * i - 2), ad(2 * i - 1), cv(i - 1)]
     gaps[7] += [ad(14), ad(15), cv(7)]
+    if "novalu" in ABL:
+        return [[] for _ in range(8)]
+    if "noexp" in ABL:
+        gaps = [[t.replace("v_exp_f32", "v_mov_b32") for t in grp] for grp in gaps]
     return gaps
 
 
-def phase_M(a, st, jb, masked, qk=True, body=True):
-    """The M phase of key block jb of tile t (s_setprio 1: a wave in its matrix phase outranks the co-resident workgroup's wave in
-    its VALU phase, so the two alternate without a barrier between them): for query block A  4 score MFMAs + 4 P V MFMAs of the
-    previous key block, with the softmax of query block B's PREVIOUS scores in their gaps (five VALU per gap -- this wave waits for
-    the matrix pipe there anyway); then the same 8 MFMAs for block B, bare: pointer arithmetic and the LDS-DMA issue of round t + 2
-    ride in those gaps.  Key block 1 ends with the tile's one barrier (round t + 1 published)."""
+TRACE = False
+SG["tr"] = 100
+
+
+def stamp(a, k):
+    """trace build (tools/attn_pp_trace.py): waves 0 and 4 of workgroup 0 store the shader clock at point k of the current tile of
+    their first item: record [half][tile][k], 8 bytes each"""
+    if not TRACE:
+        return
+    skip = "st%d" % a.nlabel
+    a.nlabel += 1
+    a.e("s_cmp_eq_u32 %s, 0" % s("trace"))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip))
+    a.e("s_memtime %s" % s2("x2"))
+    a.e("s_lshl_b32 %s, %s, 9" % (s("x4"), s("half")))
+    a.e("s_lshl_b32 %s, %s, 3" % (s("x5"), s("t")))
+    a.e("s_add_u32 %s, %s, %s" % (s("x4"), s("x4"), s("x5")))
+    a.e("s_add_u32 %s, %s, %d" % (s("x4"), s("x4"), k))
+    a.e("s_lshl_b32 %s, %s, 3" % (s("x4"), s("x4")))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("s_store_dwordx2 %s, s[100:101], %s" % (s2("x2"), s("x4")))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.label(skip)
+
+
+def barrier(a):
+    a.e("s_barrier")
+
+
+def phase_M(a, st, jb, masked, qk=True, body=True, tag=""):
+    """The M phase of key block jb of tile t: for query block A  4 score MFMAs + 4 P V MFMAs (of the previous key block), with the
+    softmax of query block B's PREVIOUS scores in their gaps (five VALU per gap: this wave waits for the matrix pipe there anyway);
+    then the same 8 MFMAs for block B, bare -- pointer arithmetic and LDS-DMA issue ride in those gaps."""
+    stamp(a, 0 if jb == 0 else 4)
     if OPT["prio"]:
         a.e("s_setprio 1")
     a.e("s_waitcnt lgkmcnt(0)")
@@ -210,8 +237,8 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
     for x in range(2):
         for k in range(4):
             if qk:
-                mf.append(mfma(S(x, 0), KF(0, k), Q(x, k), None if k == 0 else S(x, 0)))
-            mf.append(mfma(O(x, k & 1, 0), VF(0, k), P(x, k >> 1), O(x, k & 1, 0)))         # fragment k = 2 t2 + db
+                mf.append(mfma(S(x, 0), KF(k), Q(x, k), None if k == 0 else S(x, 0)))
+            mf.append(mfma(O(x, k & 1, 0), VF(k), P(x, k >> 1), O(x, k & 1, 0)))            # fragment k = 2 t2 + db
     gaps = softmax_gaps(1)
     nA = 8 if qk else 4                             # drain: P V only, block B's softmax in the four gaps of block A's MFMAs
     fill = {i: [] for i in range(len(mf))}
@@ -228,15 +255,17 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
     elif body and masked:
         pre += mask_apply(1, 0)
     late = {i: [] for i in range(len(mf))}
+    rd = dma_round((st + 3) & 3)
     if body:
-        rd = dma_round((st + 2) & 3)
-        if jb == 0:
-            late[9] += rd[0]
-            late[11] += rd[1]
-            late[13] += rd[4]
-        else:
-            late[9] += rd[2]
-            late[11] += rd[3]
+        if OPT["dma_in_m"]:
+            if jb == 0:
+                late[9] += ["DMA0"]
+                late[11] += ["DMA1"]
+                late[13] += ["DMA4"]
+            else:
+                late[9] += ["DMA2"]
+                late[11] += ["DMA3"]
+        if jb == 1:
             adv = advance_round()
             late[8] += adv[0:3]
             late[10] += adv[3:5]
@@ -259,15 +288,20 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
                     a.label(t[6:])
                 else:
                     a.e(t)
-        for t in fill[i] + late[i]:
+        for t in fill[i]:
             a.e(t)
+        for t in late[i]:
+            if t.startswith("DMA"):
+                dma_guarded(a, [rd[int(t[3:])]], "%s%d%d%d%s" % (tag, st, jb, i, "m" if masked else "p"))
+            else:
+                a.e(t)
+    if body and jb == 1:
+        a.e("s_waitcnt vmcnt(10)")                     # round t + 1 has landed (own pieces); rounds t + 2, t + 3 fly
+        tail_fix(a, (st + 1) & 3, "%s%d%s" % (tag, st, "m" if masked else "p"))
     if OPT["prio"]:
         a.e("s_setprio 0")
-    if body and jb == 1:
-        a.e("s_waitcnt vmcnt(5)")                      # round t + 1 has landed (own pieces); round t + 2 flies
-        tail_fix(a, (st + 1) & 3, "%d%s" % (st, "m" if masked else "p"))
-        if "nobar" not in ABL:
-            a.e("s_barrier")
+    stamp(a, 1 if jb == 0 else 5)
+    barrier(a)
 
 
 def phase_V(a, st, jb, masked, body=True):
@@ -275,10 +309,13 @@ def phase_V(a, st, jb, masked, body=True):
     key block, V^T of this one)."""
     sn = (st + 1) & 3
     kst, kjb = (st, 1) if jb == 0 else (sn, 0)
+    stamp(a, 2 if jb == 0 else 6)
     for k in range(4):
-        a.e("ds_read_b128 %s, %s offset:%d" % (vr(KF(0, k), 4), v(KOFF(k)), kst * STAGE + kjb * 4096))
+        if "nolds" not in ABL:
+            a.e("ds_read_b128 %s, %s offset:%d" % (vr(KF(k), 4), v(KOFF(k)), kst * STAGE + kjb * 4096))
     for f in range(4):
-        a.e("ds_read_b128 %s, %s offset:%d" % (vr(VF(0, f), 4), v(VOFF(jb, f >> 1)), st * STAGE + (f & 1) * 4096))
+        if "nolds" not in ABL:
+            a.e("ds_read_b128 %s, %s offset:%d" % (vr(VF(f), 4), v(VOFF(jb, f >> 1)), st * STAGE + (f & 1) * 4096))
     if body and jb == 1:
         a.e("ds_read_b32 %s, %s offset:%d" % (v(V_KACUR), v(V_KAREAD), sn * 1024))
     if masked:
@@ -287,17 +324,25 @@ def phase_V(a, st, jb, masked, body=True):
     for grp in softmax_gaps(0):
         for t in grp:
             a.e(t)
+    if body and not OPT["dma_in_m"]:
+        rd = dma_round((st + 3) & 3)
+        dma_guarded(a, [rd[0], rd[1], rd[4]] if jb == 0 else [rd[2], rd[3]], "V%d%d%s" % (st, jb, "m" if masked else "p"))
     if body and jb == 1:
         a.e("s_waitcnt lgkmcnt(0)")
         a.e("v_cmp_neq_f32 vcc, 0, %s" % v(V_KACUR))
         a.e("s_cmp_lg_u64 vcc, 0")
         a.e("s_cselect_b32 %s, 1, 0" % s("mnext"))
+    stamp(a, 3 if jb == 0 else 7)
+    barrier(a)
 
 
 def tile_body(a, st, masked):
     for jb in range(2):
+        n0 = len(a.lines)
         phase_M(a, st, jb, masked)
         phase_V(a, st, jb, masked)
+        if "nobar" in ABL:
+            a.lines[n0:] = [t for t in a.lines[n0:] if t != "s_barrier"]
     a.e("s_mov_b32 %s, %d" % (s("pmask"), 1 if masked else 0))          # block B's scores of key block 1 are still pending
     a.e("s_add_u32 %s, %s, 1" % (s("t"), s("t")))
     a.e("s_add_u32 %s, %s, 1" % (s("x0"), s("t")))
@@ -306,40 +351,58 @@ def tile_body(a, st, masked):
     a.e("s_or_b32 %s, %s, %s" % (s("masked"), s("mnext"), s("x0")))
 
 
-def item_decode(a, done_label, skip_label):
-    """virtual block v -> (qb, h, b) with attn_decode_block's XCD map: L = (v & 7) * cnt + (v >> 3)"""
-    a.e("s_cmp_ge_u32 %s, %s" % (s("v"), s("vend")))
-    a.e("s_cbranch_scc1 %s" % a.ref(done_label))
-    a.e("s_and_b32 %s, %s, 7" % (s("x0"), s("v")))
-    a.e("s_lshr_b32 %s, %s, 3" % (s("x1"), s("v")))
-    a.e("s_mul_i32 %s, %s, %s" % (s("x0"), s("x0"), s("cnt")))
-    a.e("s_add_u32 %s, %s, %s" % (s("x0"), s("x0"), s("x1")))                         # L
+def light_tile(a, st):
+    """a wave without queries (or a half without an item): the same four barriers, its DMA pieces and its share of the tail fix"""
+    n0 = len(a.lines)
+    rd = dma_round((st + 3) & 3)
+    dma_guarded(a, [rd[0], rd[1], rd[4]], "L%da" % st)
+    barrier(a)
+    barrier(a)
+    dma_guarded(a, [rd[2], rd[3]], "L%db" % st)
+    for t in advance_round():
+        a.e(t)
+    a.e("s_waitcnt vmcnt(10)")
+    tail_fix(a, (st + 1) & 3, "L%d" % st)
+    barrier(a)
+    barrier(a)
+    a.e("s_add_u32 %s, %s, 1" % (s("t"), s("t")))
+    if "nobar" in ABL:
+        a.lines[n0:] = [t for t in a.lines[n0:] if t != "s_barrier"]
+
+
+def item_decode(a):
+    """idx -> L = xcd * cnt + idx -> (qb, h, b); have = this half has an item (idx < cnt and L < total)"""
+    a.e("s_mov_b32 %s, 1" % s("have"))
+    a.e("s_cmp_ge_u32 %s, %s" % (s("idx"), s("cnt")))
+    a.e("s_cselect_b32 %s, 0, %s" % (s("have"), s("have")))
+    a.e("s_mul_i32 %s, %s, %s" % (s("x0"), s("xcd"), s("cnt")))
+    a.e("s_add_u32 %s, %s, %s" % (s("x0"), s("x0"), s("idx")))                         # L
     a.e("s_cmp_ge_u32 %s, %s" % (s("x0"), s("total")))
-    a.e("s_cbranch_scc1 %s" % a.ref(skip_label))
-    a.e("s_mul_hi_u32 %s, %s, %s" % (s("x1"), s("x0"), s("mq")))                      # L / nqb (magic multiply; a divisor of 1 has none)
+    a.e("s_cselect_b32 %s, 0, %s" % (s("have"), s("have")))
+    a.e("s_cmp_eq_u32 %s, 0" % s("have"))
+    a.e("s_cselect_b32 %s, 0, %s" % (s("x0"), s("x0")))                                # no item: decode item 0 (addresses stay legal, nothing is issued)
+    a.e("s_mul_hi_u32 %s, %s, %s" % (s("x1"), s("x0"), s("mq")))
     a.e("s_cmp_eq_u32 %s, 1" % s("nqb"))
     a.e("s_cselect_b32 %s, %s, %s" % (s("x1"), s("x0"), s("x1")))
     a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("x1"), s("nqb")))
     a.e("s_sub_u32 %s, %s, %s" % (s("qb"), s("x0"), s("x2")))
-    a.e("s_mul_hi_u32 %s, %s, %s" % (s("b"), s("x1"), s("mh")))                       # (L / nqb) / H
+    a.e("s_mul_hi_u32 %s, %s, %s" % (s("b"), s("x1"), s("mh")))
     a.e("s_cmp_eq_u32 %s, 1" % s("H"))
     a.e("s_cselect_b32 %s, %s, %s" % (s("b"), s("x1"), s("b")))
     a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("b"), s("H")))
     a.e("s_sub_u32 %s, %s, %s" % (s("h"), s("x1"), s("x2")))
-    # byte offset of head (b, h) in q / k / v^T: bh * Npad * 128
     a.e("s_lshl_b32 %s, %s, 7" % (s("x2"), s("Npad")))
     a.e("s_mul_hi_u32 %s, %s, %s" % (s("x3"), s("x1"), s("x2")))
     a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("x1"), s("x2")))
     for n, base in (("Qp", "q"), ("Kp", "k"), ("Vp", "vt")):
         a.e("s_add_u32 %s, %s, %s" % (s(n), s(base), s("x2")))
         a.e("s_addc_u32 %s, %s, %s" % (shi(n), shi(base), s("x3")))
-    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("b"), s("kas")))                         # key_add row of sample b (kas in bytes)
+    a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("b"), s("kas")))
     a.e("s_mul_hi_u32 %s, %s, %s" % (s("x3"), s("b"), s("kas")))
     a.e("s_add_u32 %s, %s, %s" % (s("Ap"), s("ka"), s("x2")))
     a.e("s_addc_u32 %s, %s, %s" % (shi("Ap"), shi("ka"), s("x3")))
-    # o + ((b * N) * H * 64 + h * 64) * 2
     a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("b"), s("N")))
-    a.e("s_lshl_b32 %s, %s, 7" % (s("x4"), s("H")))                                   # bytes of one output row
+    a.e("s_lshl_b32 %s, %s, 7" % (s("x4"), s("H")))
     a.e("s_mul_hi_u32 %s, %s, %s" % (s("x3"), s("x2"), s("x4")))
     a.e("s_mul_i32 %s, %s, %s" % (s("x2"), s("x2"), s("x4")))
     a.e("s_lshl_b32 %s, %s, 7" % (s("x5"), s("h")))
@@ -347,12 +410,11 @@ def item_decode(a, done_label, skip_label):
     a.e("s_addc_u32 %s, %s, 0" % (s("x3"), s("x3")))
     a.e("s_add_u32 %s, %s, %s" % (s("Op"), s("o"), s("x2")))
     a.e("s_addc_u32 %s, %s, %s" % (shi("Op"), shi("o"), s("x3")))
-    # q0 = (4 * qb + wave) * 64; the wave is active when q0 < N
     a.e("s_lshl_b32 %s, %s, 2" % (s("q0"), s("qb")))
     a.e("s_add_u32 %s, %s, %s" % (s("q0"), s("q0"), s("wave")))
     a.e("s_lshl_b32 %s, %s, 6" % (s("q0"), s("q0")))
     a.e("s_cmp_lt_u32 %s, %s" % (s("q0"), s("N")))
-    a.e("s_cselect_b32 %s, 1, 0" % s("active"))
+    a.e("s_cselect_b32 %s, %s, 0" % (s("active"), s("have")))
 
 
 def lane_constants(a):
@@ -362,18 +424,17 @@ def lane_constants(a):
     a.e("v_and_b32 %s, 31, %s" % (v(m31), v(lane)))
     a.e("v_lshrrev_b32 %s, 5, %s" % (v(half), v(lane)))
     a.e("v_lshlrev_b32 %s, 3, %s" % (v(V_HALF8), v(half)))
-    # kperm = (m31 & 0x13) | ((m31 & 4) << 1) | ((m31 & 8) >> 1)
     a.e("v_and_b32 %s, 0x13, %s" % (v(t0), v(m31)))
     a.e("v_and_b32 %s, 4, %s" % (v(t1), v(m31)))
     a.e("v_lshl_or_b32 %s, %s, 1, %s" % (v(t0), v(t1), v(t0)))
     a.e("v_and_b32 %s, 8, %s" % (v(t1), v(m31)))
     a.e("v_lshrrev_b32 %s, 1, %s" % (v(t1), v(t1)))
     a.e("v_or_b32 %s, %s, %s" % (v(t0), v(t0), v(t1)))                    # kperm
-    # swz128(row, chunk) = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
-    def swz(dst, row, chunk_expr_emit):
+
+    def swz(dst, row, chunk_emit):
         a.e("v_lshrrev_b32 %s, 1, %s" % (v(T[5]), v(row)))
         a.e("v_and_b32 %s, 7, %s" % (v(T[5]), v(T[5])))
-        chunk_expr_emit(T[6])                                             # chunk -> T[6]
+        chunk_emit(T[6])
         a.e("v_xor_b32 %s, %s, %s" % (v(T[5]), v(T[5]), v(T[6])))
         a.e("v_lshlrev_b32 %s, 4, %s" % (v(T[5]), v(T[5])))
         a.e("v_lshl_add_u32 %s, %s, 7, %s" % (v(dst), v(row), v(T[5])))
@@ -385,11 +446,10 @@ def lane_constants(a):
             swz(VOFF(jb, t2), m31, lambda r, jb=jb, t2=t2: a.e("v_add_u32 %s, %d, %s" % (v(r), 4 * jb + 2 * t2, v(half))))
             a.e("v_add_u32 %s, %s, %s" % (v(VOFF(jb, t2)), s("lds"), v(VOFF(jb, t2))))
             a.e("v_add_u32 %s, 0x2000, %s" % (v(VOFF(jb, t2)), v(VOFF(jb, t2))))
-    # DMA source offsets: piece = wave + 4 i, row = 8 piece + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7)
     a.e("s_lshl_b32 %s, %s, 3" % (s("x0"), s("wave")))
     a.e("v_lshrrev_b32 %s, 3, %s" % (v(t0), v(lane)))
-    a.e("v_add_u32 %s, %s, %s" % (v(t0), s("x0"), v(t0)))                 # row of piece 0
-    a.e("s_lshl_b32 %s, %s, 1" % (s("x1"), s("Npad")))                    # bytes of a V^T row
+    a.e("v_add_u32 %s, %s, %s" % (v(t0), s("x0"), v(t0)))
+    a.e("s_lshl_b32 %s, %s, 1" % (s("x1"), s("Npad")))
     for i in range(2):
         if i == 1:
             a.e("v_add_u32 %s, 32, %s" % (v(t0), v(t0)))
@@ -397,28 +457,24 @@ def lane_constants(a):
         a.e("v_and_b32 %s, 7, %s" % (v(T[5]), v(T[5])))
         a.e("v_and_b32 %s, 7, %s" % (v(T[6]), v(lane)))
         a.e("v_xor_b32 %s, %s, %s" % (v(T[5]), v(T[5]), v(T[6])))
-        a.e("v_lshlrev_b32 %s, 4, %s" % (v(T[5]), v(T[5])))               # chunk * 16
+        a.e("v_lshlrev_b32 %s, 4, %s" % (v(T[5]), v(T[5])))
         a.e("v_lshl_add_u32 %s, %s, 7, %s" % (v(DK(i)), v(t0), v(T[5])))
         a.e("v_mul_lo_u32 %s, %s, %s" % (v(T[6]), v(t0), s("x1")))
         a.e("v_add_u32 %s, %s, %s" % (v(DV(i)), v(T[6]), v(T[5])))
     a.e("v_lshlrev_b32 %s, 2, %s" % (v(V_DKA), v(lane)))
     a.e("s_lshl_b32 %s, %s, 8" % (s("x0"), s("wave")))
     a.e("s_add_u32 %s, %s, %s" % (s("wa"), s("lds"), s("x0")))
-    a.e("s_add_u32 %s, %s, %d" % (s("wa"), s("wa"), KADD0))               # this wave's key_add row of stage 0
+    a.e("s_add_u32 %s, %s, %d" % (s("wa"), s("wa"), KADD0))
     a.e("v_add_u32 %s, %s, %s" % (v(V_KAREAD), s("wa"), v(V_DKA)))
     a.e("v_lshlrev_b32 %s, 5, %s" % (v(t1), v(half)))
     a.e("v_add_u32 %s, %s, %s" % (v(V_KAADDR), s("wa"), v(t1)))
     a.e("s_lshl_b32 %s, %s, 10" % (s("x0"), s("wave")))
-    a.e("s_add_u32 %s, %s, %s" % (s("wl"), s("lds"), s("x0")))            # this wave's piece 0 of stage 0
+    a.e("s_add_u32 %s, %s, %s" % (s("wl"), s("lds"), s("x0")))
     a.e("v_mov_b32 %s, 0xff800000" % v(V_NEGINF))
-    for f in range(4):                                                    # "tile -1" runs P V against P = 0: its V^T fragments must be finite
-        for r in range(4):
-            a.e("v_mov_b32 %s, 0" % v(VF(1, f) + r))
 
 
 def item_prologue_active(a):
     m31, t0 = T[1], T[3]
-    # q rows (clamped to N - 1), 16 bytes per lane and k step
     a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(T[0]))
     a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(T[0]), v(T[0])))
     a.e("v_and_b32 %s, 31, %s" % (v(m31), v(T[0])))
@@ -429,29 +485,52 @@ def item_prologue_active(a):
             a.e("v_add_u32 %s, 32, %s" % (v(t0), v(t0)))
         a.e("v_min_u32 %s, %s, %s" % (v(t0), s("x0"), v(t0)))
         a.e("v_lshlrev_b32 %s, 7, %s" % (v(t0), v(t0)))
-        a.e("v_lshl_add_u32 %s, %s, 1, %s" % (v(QOFF(x)), v(V_HALF8), v(t0)))          # + half * 16
+        a.e("v_lshl_add_u32 %s, %s, 1, %s" % (v(QOFF(x)), v(V_HALF8), v(t0)))
         for kk in range(4):
             a.e("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(Q(x, kk), 4), v(QOFF(x)), s2("Qp"), 32 * kk))
 
 
-def emit_rounds_01(a):
-    for r in range(2):
+def emit_rounds_012(a, tag):
+    skip = "nor%s" % tag
+    a.e("s_cmp_eq_u32 %s, 0" % s("have"))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip))
+    for r in range(3):
         for pair in dma_round(r):
             for t in pair:
                 a.e(t)
         for t in advance_round():
             a.e(t)
+    a.label(skip)
+
+
+def flags_read(a, tag):
+    """flags of this half's previous item (written behind its epilogue, at least one barrier ago)"""
+    skip = "nofl%s" % tag
+    a.e("s_cmp_eq_u32 %s, 0" % s("it"))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip))
+    a.e("v_mov_b32 %s, %s" % (v(T[0]), s("lds")))
+    a.e("v_add_u32 %s, 0x%x, %s" % (v(T[0]), FLAG0, v(T[0])))
+    a.e("ds_read_b128 %s, %s" % (vr(T[2], 4), v(T[0])))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("v_or_b32 %s, %s, %s" % (v(T[2]), v(T[2]), v(T[3])))
+    a.e("v_or3_b32 %s, %s, %s, %s" % (v(T[2]), v(T[2]), v(T[4]), v(T[5])))
+    a.e("s_nop 3")
+    a.e("v_readfirstlane_b32 %s, %s" % (s("x0"), v(T[2])))
+    a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip))
+    a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("it")))
+    a.e("s_bitset1_b64 %s, %s" % (s2("bad"), s("x0")))
+    a.label(skip)
 
 
 def epilogue(a):
-    """normalise, range check (2^-100 < row sum < 2^100 else the item is redone exactly), 16-byte stores of rows < N"""
     l0, l1, lane, m31, row = T[0], T[1], T[2], T[3], T[4]
     a.e("s_mov_b32 %s, 0" % s("ibad"))
     a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(lane))
     a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(lane), v(lane)))
     a.e("v_and_b32 %s, 31, %s" % (v(m31), v(lane)))
     a.e("s_lshl_b32 %s, %s, 7" % (s("x4"), s("H")))
-    buf = 96                                                              # v96.. (scores, P, fragments: all dead) hold the packed rows
+    buf = BUF
     for x in range(2):
         a.e("v_add_f32 %s, %s, %s" % (v(l0), v(PS(x, 0)), v(PS(x, 1))))
         a.e("v_mov_b32 %s, %s" % (v(l1), v(l0)))
@@ -477,7 +556,7 @@ def epilogue(a):
                 a.e("v_mul_f32 %s, %s, %s" % (v(O(x, db, r)), v(O(x, db, r)), v(l0)))
         a.e("v_cmp_gt_u32 vcc, %s, %s" % (s("N"), v(row)))
         a.e("v_mul_lo_u32 %s, %s, %s" % (v(row), v(row), s("x4")))
-        a.e("v_lshl_add_u32 %s, %s, 1, %s" % (v(row), v(V_HALF8), v(row)))            # + half * 16 bytes
+        a.e("v_lshl_add_u32 %s, %s, 1, %s" % (v(row), v(V_HALF8), v(row)))
         regs = []
         for db in range(2):
             for gp in range(2):
@@ -497,29 +576,8 @@ def epilogue(a):
         a.e("s_mov_b64 exec, %s" % s2("x2"))
 
 
-TRACE = False
-
-
-def stamp(a, k):
-    """trace build only (tools/attn_wgtrace.py): wave 0 stores the constant-clock time into slot k of its item's record"""
-    if not TRACE:
-        return
-    skip = "ts%d_%d" % (k, a.nlabel)
-    a.nlabel += 1
-    a.e("s_cmp_lg_u32 %s, 0" % s("wave"))
-    a.e("s_cbranch_scc1 %s" % a.ref(skip))
-    a.e("s_memrealtime s[98:99]")
-    a.e("s_mul_i32 %s, %s, 48" % (s("x5"), s("v")))
-    a.e("s_add_u32 %s, %s, %d" % (s("x5"), s("x5"), 8 * k))
-    a.e("s_waitcnt lgkmcnt(0)")
-    a.e("s_store_dwordx2 s[98:99], s[100:101], %s" % s("x5"))
-    if k == 3:
-        a.e("s_getreg_b32 s98, hwreg(HW_REG_HW_ID)")
-        a.e("s_getreg_b32 s99, hwreg(HW_REG_XCC_ID)")
-        a.e("s_add_u32 %s, %s, 8" % (s("x5"), s("x5")))
-        a.e("s_store_dwordx2 s[98:99], s[100:101], %s" % s("x5"))
-    a.e("s_waitcnt lgkmcnt(0)")
-    a.label(skip)
+class Asm(g1.Asm):
+    pass
 
 
 def generate(trace=False):
@@ -528,12 +586,20 @@ def generate(trace=False):
     a = Asm()
     if trace:
         a.e("s_mov_b64 s[100:101], %[tr]")
-    # ---- operands -> fixed registers
     for n in ("q", "k", "vt", "ka", "o"):
         a.e("s_mov_b64 %s, %%[%s]" % (s2(n), n))
-    for n in ("N", "Npad", "H", "total", "cnt", "v", "G", "kas", "wave", "lds", "nqb", "mq", "mh"):
+    for n in ("N", "Npad", "H", "total", "cnt", "kas", "nqb", "mq", "mh"):
         a.e("s_mov_b32 %s, %%[%s]" % (s(n), n))
-    a.e("s_lshl_b32 %s, %s, 3" % (s("vend"), s("cnt")))
+    # wave 0..7 -> half, wave within the half; this half's LDS; its item index walk on XCD xcd: idx = 2 (r Gx + wl) + half
+    a.e("s_lshr_b32 %s, %%[wave], 2" % s("half"))
+    a.e("s_and_b32 %s, %%[wave], 3" % s("wave"))
+    a.e("s_mul_i32 %s, %s, %d" % (s("x0"), s("half"), HALF))
+    a.e("s_add_u32 %s, %%[lds], %s" % (s("lds"), s("x0")))
+    a.e("s_and_b32 %s, %%[wg], 7" % s("xcd"))
+    a.e("s_lshr_b32 %s, %%[wg], 3" % s("x0"))
+    a.e("s_lshl_b32 %s, %s, 1" % (s("idx"), s("x0")))
+    a.e("s_add_u32 %s, %s, %s" % (s("idx"), s("idx"), s("half")))
+    a.e("s_lshr_b32 %s, %%[G], 2" % s("istr"))                            # 2 * (G / 8)
     a.e("s_add_u32 %s, %s, 63" % (s("nt"), s("N")))
     a.e("s_lshr_b32 %s, %s, 6" % (s("nt"), s("nt")))
     a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("nt")))
@@ -545,36 +611,32 @@ def generate(trace=False):
     a.e("s_mov_b64 %s, 0" % s2("bad"))
     a.e("s_mov_b32 %s, 0" % s("it"))
     lane_constants(a)
+    # half 1 runs one barrier behind half 0 from here to the end
+    a.e("s_cmp_eq_u32 %s, 0" % s("half"))
+    a.e("s_cbranch_scc1 %s" % a.ref("item"))
+    barrier(a)
 
-    # ================================================================ item loop
+    # ================================================================ item loop (both halves take the same number of turns)
     a.label("item")
-    item_decode(a, "done", "next")
-    # flags of the previous item (every wave wrote its own behind its epilogue), behind the barrier that also frees the ring
-    a.e("s_barrier")
-    a.e("s_cmp_eq_u32 %s, 0" % s("it"))
-    a.e("s_cbranch_scc1 %s" % a.ref("noflag"))
-    a.e("v_mov_b32 %s, %s" % (v(T[0]), s("lds")))
-    a.e("v_add_u32 %s, 0x%x, %s" % (v(T[0]), FLAG0, v(T[0])))
-    a.e("ds_read_b128 %s, %s" % (vr(T[2], 4), v(T[0])))
-    a.e("s_waitcnt lgkmcnt(0)")
-    a.e("v_or_b32 %s, %s, %s" % (v(T[2]), v(T[2]), v(T[3])))
-    a.e("v_or3_b32 %s, %s, %s, %s" % (v(T[2]), v(T[2]), v(T[4]), v(T[5])))
-    a.e("v_readfirstlane_b32 %s, %s" % (s("x0"), v(T[2])))
-    a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
-    a.e("s_cbranch_scc1 %s" % a.ref("noflag"))
-    a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("it")))
-    a.e("s_bitset1_b64 %s, %s" % (s2("bad"), s("x0")))
-    a.label("noflag")
-    a.e("s_barrier")                                                      # every wave has read the flags before anyone rewrites them
-    stamp(a, 0)
+    a.e("s_sub_u32 %s, %s, %s" % (s("x0"), s("idx"), s("half")))
+    a.e("s_cmp_ge_u32 %s, %s" % (s("x0"), s("cnt")))
+    a.e("s_cbranch_scc1 %s" % a.ref("done"))
+    item_decode(a)
+    # ---- phase PRO: flags of the previous item, q, rounds 0..2, zeroes
+    flags_read(a, "a")
+    if trace:
+        a.e("s_and_b32 %s, %%[wave], 3" % s("x0"))
+        a.e("s_or_b32 %s, %s, %%[wg]" % (s("x0"), s("x0")))
+        a.e("s_or_b32 %s, %s, %s" % (s("x0"), s("x0"), s("it")))
+        a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
+        a.e("s_cselect_b32 %s, 1, 0" % s("trace"))
     a.e("s_mov_b32 %s, 0" % s("r"))
     a.e("s_mov_b32 %s, 0" % s("t"))
     a.e("s_cmp_eq_u32 %s, 0" % s("active"))
     a.e("s_cbranch_scc1 %s" % a.ref("light"))
 
-    # ---------------------------------------------------------------- active wave
     item_prologue_active(a)
-    emit_rounds_01(a)
+    emit_rounds_012(a, "a")
     for x in range(2):
         for db in range(2):
             for r in range(16):
@@ -586,21 +648,22 @@ def generate(trace=False):
                 a.e("v_mov_b32 %s, 0" % v(P(x, t2) + r))
     for f in range(4):                                                    # "key block -1": P V against P = 0 needs finite V^T fragments
         for r in range(4):
-            a.e("v_mov_b32 %s, 0" % v(VF(0, f) + r))
+            a.e("v_mov_b32 %s, 0" % v(VF(f) + r))
     for r in range(16):                                                   # and block B's "pending scores" exponentiate to 0
         a.e("v_mov_b32 %s, 0xff800000" % v(S(1, r)))
     a.e("s_mov_b32 %s, 0" % s("pmask"))
-    a.e("s_waitcnt vmcnt(5)")                                             # q and round 0 have landed; round 1 flies
-    a.e("s_barrier")
-    for k in range(4):                                                    # K fragments of (tile 0, key block 0); mask flag of tile 0
-        a.e("ds_read_b128 %s, %s offset:%d" % (vr(KF(0, k), 4), v(KOFF(k)), 0))
+    a.e("s_waitcnt vmcnt(10)")
+    barrier(a)
+    # ---- phase PRE: K fragments of (tile 0, key block 0), mask flag of tile 0
+    for k in range(4):
+        a.e("ds_read_b128 %s, %s offset:%d" % (vr(KF(k), 4), v(KOFF(k)), 0))
     a.e("ds_read_b32 %s, %s offset:0" % (v(V_KACUR), v(V_KAREAD)))
     a.e("s_waitcnt lgkmcnt(0)")
     a.e("v_cmp_neq_f32 vcc, 0, %s" % v(V_KACUR))
     a.e("s_cmp_lg_u64 vcc, 0")
     a.e("s_cselect_b32 %s, 1, 0" % s("masked"))
-    stamp(a, 1)
-    # ---- tile loop, unrolled by the ring depth (a stage is an immediate offset)
+    barrier(a)
+    # ---- tile loop
     a.label("tile0")
     for st in range(4):
         if st:
@@ -616,47 +679,39 @@ def generate(trace=False):
         a.label("mtile%d" % st)
         tile_body(a, st, True)
         a.e("s_branch %s" % a.ref("tile%d" % ((st + 1) & 3)))
-    # ---- drain: block B's last scores are still pending (their mask term first), P V of the last key block
+    # ---- drain: P V of the last key block (an M phase), then the epilogue (a V-like phase)
     a.label("drain")
-    stamp(a, 2)
+    # block B's scores of the last key block are still pending: their mask term (if any) first
     a.e("s_cmp_eq_u32 %s, 0" % s("pmask"))
     a.e("s_cbranch_scc1 %s" % a.ref("dnm"))
     for t in mask_apply(1, 1):
         a.e(t)
     a.label("dnm")
-    phase_M(a, 0, 0, False, qk=False, body=False)
-    a.e("s_nop 15")
-    a.e("s_nop 3")
+    phase_M(a, 0, 0, False, qk=False, body=False, tag="D")
+    a.e("s_nop 7")
     epilogue(a)
-    stamp(a, 5)
     a.e("s_branch %s" % a.ref("itemend"))
 
-    # ---------------------------------------------------------------- wave without queries: DMA, tail fix and barriers only
+    # ---------------------------------------------------------------- wave without queries / half without an item
     a.label("light")
-    emit_rounds_01(a)
-    a.e("s_waitcnt vmcnt(5)")
-    a.e("s_barrier")
+    emit_rounds_012(a, "l")
+    a.e("s_waitcnt vmcnt(10)")
+    barrier(a)
+    barrier(a)
     a.e("s_mov_b32 %s, 0" % s("ibad"))
     a.label("ltile0")
     for st in range(4):
         if st:
             a.label("ltile%d" % st)
         a.e("s_cmp_ge_u32 %s, %s" % (s("t"), s("nt")))
-        a.e("s_cbranch_scc1 %s" % a.ref("itemend"))
-        for pair in dma_round((st + 2) & 3):
-            for t in pair:
-                a.e(t)
-        for t in advance_round():
-            a.e(t)
-        a.e("s_waitcnt vmcnt(5)")
-        tail_fix(a, (st + 1) & 3, "%dL" % st)
-        if "nobar" not in ABL:
-            a.e("s_barrier")
-        a.e("s_add_u32 %s, %s, 1" % (s("t"), s("t")))
+        a.e("s_cbranch_scc1 %s" % a.ref("ldrain"))
+        light_tile(a, st)
         if st == 3:
             a.e("s_branch %s" % a.ref("ltile0"))
+    a.label("ldrain")
+    barrier(a)
 
-    # ---------------------------------------------------------------- item end: flag, drain the surplus rounds and the stores
+    # ---------------------------------------------------------------- item end (inside the epilogue phase): flag, drain, barrier
     a.label("itemend")
     a.e("v_mov_b32 %s, %s" % (v(T[0]), s("wave")))
     a.e("v_lshl_add_u32 %s, %s, 2, %s" % (v(T[0]), v(T[0]), s("lds")))
@@ -664,111 +719,40 @@ def generate(trace=False):
     a.e("v_mov_b32 %s, %s" % (v(T[1]), s("ibad")))
     a.e("ds_write_b32 %s, %s" % (v(T[0]), v(T[1])))
     a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    stamp(a, 3)
-    a.e("s_add_u32 %s, %s, 1" % (s("it"), s("it")))
-    a.label("next")
-    a.e("s_add_u32 %s, %s, %s" % (s("v"), s("v"), s("G")))
+    barrier(a)
+    a.e("s_add_u32 %s, %s, %s" % (s("it"), s("it"), s("have")))
+    a.e("s_add_u32 %s, %s, %s" % (s("idx"), s("idx"), s("istr")))
     a.e("s_branch %s" % a.ref("item"))
 
-    # ================================================================ after the last item: its flags
+    # ================================================================ the last item's flags; half 0 pays its barrier back
     a.label("done")
-    a.e("s_barrier")
-    a.e("s_cmp_eq_u32 %s, 0" % s("it"))
+    flags_read(a, "z")
+    a.e("s_cmp_lg_u32 %s, 0" % s("half"))
     a.e("s_cbranch_scc1 %s" % a.ref("out"))
-    a.e("v_mov_b32 %s, %s" % (v(T[0]), s("lds")))
-    a.e("v_add_u32 %s, 0x%x, %s" % (v(T[0]), FLAG0, v(T[0])))
-    a.e("ds_read_b128 %s, %s" % (vr(T[2], 4), v(T[0])))
-    a.e("s_waitcnt lgkmcnt(0)")
-    a.e("v_or_b32 %s, %s, %s" % (v(T[2]), v(T[2]), v(T[3])))
-    a.e("v_or3_b32 %s, %s, %s, %s" % (v(T[2]), v(T[2]), v(T[4]), v(T[5])))
-    a.e("v_readfirstlane_b32 %s, %s" % (s("x0"), v(T[2])))
-    a.e("s_cmp_eq_u32 %s, 0" % s("x0"))
-    a.e("s_cbranch_scc1 %s" % a.ref("out"))
-    a.e("s_sub_u32 %s, %s, 1" % (s("x0"), s("it")))
-    a.e("s_bitset1_b64 %s, %s" % (s2("bad"), s("x0")))
+    barrier(a)
     a.label("out")
-    a.e("s_barrier")
     if trace:
         a.e("s_dcache_wb")
     a.e("s_mov_b64 %[bad], " + s2("bad"))
     return a.lines
 
 
-def main(out=OUT, trace=False):
+def main():
+    trace = "--trace" in sys.argv
+    out = sys.argv[sys.argv.index("--trace") + 1] if trace else OUT
     lines = generate(trace)
     with open(out, "w") as f:
-        f.write("// GENERATED by tools/gen/attn_p64_gen.py -- do not edit.  %d instructions / labels.\n" % len(lines))
-        f.write("// LDS image: %d stages x %d B, key_add rows at %d, flags at %d, %d bytes in all.\n" % (NS, STAGE, KADD0, FLAG0, LDS_BYTES))
+        f.write("// GENERATED by tools/gen/attn_pp_gen.py -- do not edit.  %d instructions / labels.\n" % len(lines))
+        f.write("// LDS per half: %d stages x %d B, key_add rows at %d, flags at %d; %d bytes per half, %d per workgroup.\n" % (NS, STAGE, KADD0, FLAG0, HALF, LDS_BYTES))
         for ln in lines:
-            if ln.startswith(";"):
-                continue
             f.write('"%s\\n\\t"\n' % ln)
     print("wrote", out, len(lines), "lines")
-
-
-# ---------------------------------------------------------------- hazard lint (the assembler inserts no wait states)
-def _regs(tok):
-    import re
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"v(\d+)", tok)
-    return {int(m.group(1))} if m else set()
-
-
-def lint(lines):
-    """MFMA result -> any other access of those registers needs 12 wait states (measured on hipcc's own output for gfx950:
-    s_nop 11 between v_mfma_f32_32x32x16_bf16 and a VALU / memory read of its result, or a later MFMA reading it as A / B; back-to-back
-    accumulation into the same registers needs none); VALU write -> MFMA A / B read: 2.  Straight-line approximation: labels and
-    branches are ignored, which is conservative enough for this stream (every block starts and ends far from an MFMA's result use)."""
-    import re
-    recent = []          # (age in wait states, kind, written regs)
-    problems = []
-    for n, ln in enumerate(lines):
-        if ln.endswith(":") or ln.startswith(";"):
-            continue
-        op, _, rest = ln.partition(" ")
-        toks = [t.strip() for t in re.split(r",|\s+offset:\d+", rest) if t and t.strip()]
-        states = 1
-        if op == "s_nop":
-            states = int(toks[0]) + 1
-        if op.startswith("v_mfma"):
-            dst, a_, b_, c_ = _regs(toks[0]), _regs(toks[1]), _regs(toks[2]), _regs(toks[3])
-            for age, kind, wr in recent:
-                if kind == "mfma" and age < 12 and (wr & (a_ | b_)):
-                    problems.append((n, ln, "MFMA result read as A/B after %d states" % age))
-                if kind == "mfma" and age < 12 and (wr & (dst | c_)) and not (wr == dst and (c_ == dst or not c_)):
-                    problems.append((n, ln, "MFMA overlapping accumulate after %d states" % age))
-                if kind == "valu" and age < 2 and (wr & (a_ | b_ | c_)):
-                    problems.append((n, ln, "VALU result read by MFMA after %d states" % age))
-            recent = [(a + states, k, w) for a, k, w in recent if a + states < 24] + [(0, "mfma", dst)]
-            continue
-        used = set()
-        for t in toks:
-            used |= _regs(t)
-        if op.startswith(("v_", "ds_", "global_")):
-            for age, kind, wr in recent:
-                if kind == "mfma" and age < 12 and (wr & used):
-                    problems.append((n, ln, "MFMA result touched after %d states" % age))
-        wrote = set()
-        if op.startswith("v_") and toks and not op.startswith("v_cmp"):
-            wrote = _regs(toks[0])
-            if op.startswith("v_permlane32_swap"):
-                wrote |= _regs(toks[1])
-        recent = [(a + states, k, w) for a, k, w in recent if a + states < 24]
-        if wrote:
-            recent.append((0, "valu", wrote))
-    return problems
-
-
-if __name__ == "__main__":
-    import sys
-    if "--trace" in sys.argv:                 # the stamped variant for tools/attn_wgtrace.py (not committed)
-        main(sys.argv[sys.argv.index("--trace") + 1], True)
-    else:
-        main()
     if "--lint" in sys.argv:
-        probs = lint(generate())
+        probs = g1.lint(lines)
         for n, ln, why in probs[:40]:
             print("line %d: %s  <- %s" % (n, ln, why))
         print("%d hazard findings" % len(probs))
+
+
+if __name__ == "__main__":
+    main()
