@@ -24,9 +24,9 @@ def build_variants(names):
     for name in names:
         d = os.path.join(probes, "abl_" + name)
         os.makedirs(d, exist_ok=True)
-        env = dict(os.environ, PP_ABL=name.replace("+", ","))
+        env = dict(os.environ, PP_ABL=name.replace("+", ","), P64_ABL=name.replace("+", ","))
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_pp_gen.py"), "--trace", os.path.join(d, "attn_pp_asm_trace.inc")], check=True, env=env)
-        subprocess.run(["cp", os.path.join(probes, "attn_p64_asm_trace.inc"), d], check=True)
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_p64_gen.py"), "--trace", os.path.join(d, "attn_p64_asm_trace.inc")], check=True, env=env)
         obj = os.path.join(d, "attention.o")
         subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DATTN_WGTRACE", "-I", d, "-c", os.path.join(B.CSRC, "attention.hip"), "-o", obj], check=True)
         objs = [obj] + [os.path.join(probes, "wgtrace_" + src.replace(".hip", ".o")) for src in B.SOURCES if src != "attention.hip"]

@@ -180,6 +180,7 @@ ABL = set(x for x in os.environ.get("P64_ABL", "").split(",") if x)      # timin
 if "prio0" in ABL:
     OPT["prio"] = 0
 SG["pmask"] = 39
+SG["ptr"] = 38
 
 
 def softmax_gaps(x):
@@ -197,12 +198,33 @@ def softmax_gaps(x):
     return gaps
 
 
+def pstamp(a, k):
+    """trace build: wave 0 of workgroups 0 and 256 stores the shader clock at phase boundary k of the current tile of its first item
+    (records behind the per-item ones: byte 300000 + [wg != 0][tile][k] * 8)"""
+    if not TRACE or ("onestamp" in ABL and k != 0):
+        return
+    skip = "ps%d" % a.nlabel
+    a.nlabel += 1
+    a.e("s_cmp_eq_u32 %s, 0" % s("ptr"))
+    a.e("s_cbranch_scc1 %s" % a.ref(skip))
+    a.e("s_memtime s[98:99]")
+    a.e("s_lshl_b32 %s, %s, 6" % (s("x5"), s("t")))
+    a.e("s_add_u32 %s, %s, %s" % (s("x5"), s("x5"), s("ptr")))
+    a.e("s_add_u32 %s, %s, %d" % (s("x5"), s("x5"), 8 * k))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("s_store_dwordx2 s[98:99], s[100:101], %s" % s("x5"))
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.label(skip)
+
+
 def phase_M(a, st, jb, masked, qk=True, body=True):
     """The M phase of key block jb of tile t (s_setprio 1: a wave in its matrix phase outranks the co-resident workgroup's wave in
     its VALU phase, so the two alternate without a barrier between them): for query block A  4 score MFMAs + 4 P V MFMAs of the
     previous key block, with the softmax of query block B's PREVIOUS scores in their gaps (five VALU per gap -- this wave waits for
     the matrix pipe there anyway); then the same 8 MFMAs for block B, bare: pointer arithmetic and the LDS-DMA issue of round t + 2
     ride in those gaps.  Key block 1 ends with the tile's one barrier (round t + 1 published)."""
+    if body:
+        pstamp(a, 0 if jb == 0 else 4)
     if OPT["prio"]:
         a.e("s_setprio 1")
     a.e("s_waitcnt lgkmcnt(0)")
@@ -263,11 +285,14 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
             a.e(t)
     if OPT["prio"]:
         a.e("s_setprio 0")
+    if body:
+        pstamp(a, 1 if jb == 0 else 5)
     if body and jb == 1:
         a.e("s_waitcnt vmcnt(5)")                      # round t + 1 has landed (own pieces); round t + 2 flies
         tail_fix(a, (st + 1) & 3, "%d%s" % (st, "m" if masked else "p"))
         if "nobar" not in ABL:
             a.e("s_barrier")
+        pstamp(a, 6)
 
 
 def phase_V(a, st, jb, masked, body=True):
@@ -275,6 +300,8 @@ def phase_V(a, st, jb, masked, body=True):
     key block, V^T of this one)."""
     sn = (st + 1) & 3
     kst, kjb = (st, 1) if jb == 0 else (sn, 0)
+    if jb == 0:
+        pstamp(a, 2)
     for k in range(4):
         a.e("ds_read_b128 %s, %s offset:%d" % (vr(KF(0, k), 4), v(KOFF(k)), kst * STAGE + kjb * 4096))
     for f in range(4):
@@ -292,6 +319,7 @@ def phase_V(a, st, jb, masked, body=True):
         a.e("v_cmp_neq_f32 vcc, 0, %s" % v(V_KACUR))
         a.e("s_cmp_lg_u64 vcc, 0")
         a.e("s_cselect_b32 %s, 1, 0" % s("mnext"))
+    pstamp(a, 3 if jb == 0 else 7)
 
 
 def tile_body(a, st, masked):
@@ -567,6 +595,16 @@ def generate(trace=False):
     a.label("noflag")
     a.e("s_barrier")                                                      # every wave has read the flags before anyone rewrites them
     stamp(a, 0)
+    if trace:
+        a.e("s_mov_b32 %s, 0" % s("ptr"))
+        a.e("s_or_b32 %s, %s, %s" % (s("x0"), s("wave"), s("it")))
+        a.e("s_cmp_lg_u32 %s, 0" % s("x0"))
+        a.e("s_cbranch_scc1 %s" % a.ref("noptr"))
+        a.e("s_cmp_eq_u32 %s, 0" % s("v"))
+        a.e("s_cselect_b32 %s, 300000, 0" % s("ptr"))
+        a.e("s_cmp_eq_u32 %s, 256" % s("v"))
+        a.e("s_cselect_b32 %s, 304096, %s" % (s("ptr"), s("ptr")))
+        a.label("noptr")
     a.e("s_mov_b32 %s, 0" % s("r"))
     a.e("s_mov_b32 %s, 0" % s("t"))
     a.e("s_cmp_eq_u32 %s, 0" % s("active"))
