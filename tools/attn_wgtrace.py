@@ -18,14 +18,15 @@ LIB = os.path.join(ROOT, "tools", "probes", "libuvl_wgtrace.so")
 
 
 def build_variants(names):
-    """timing-only ablations of attn_pp_kernel (PP_ABL of tools/gen/attn_pp_gen.py): libuvl_wgtrace_<name>.so, attention.hip recompiled,
+    """timing-only ablations / schedule options of attn_p64_kernel (P64_ABL, P64_OPT of tools/gen/attn_p64_gen.py): libuvl_wgtrace_<name>.so, attention.hip recompiled,
     the other objects shared with the plain trace build"""
     probes = os.path.join(ROOT, "tools", "probes")
     for name in names:
         d = os.path.join(probes, "abl_" + name)
         os.makedirs(d, exist_ok=True)
-        env = dict(os.environ, PP_ABL=name.replace("+", ","), P64_ABL=name.replace("+", ","))
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_pp_gen.py"), "--trace", os.path.join(d, "attn_pp_asm_trace.inc")], check=True, env=env)
+        parts = name.split("+")
+        env = dict(os.environ, P64_ABL=",".join(x for x in parts if "=" not in x),
+                   P64_OPT=",".join(x for x in parts if "=" in x))
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_p64_gen.py"), "--trace", os.path.join(d, "attn_p64_asm_trace.inc")], check=True, env=env)
         obj = os.path.join(d, "attention.o")
         subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DATTN_WGTRACE", "-I", d, "-c", os.path.join(B.CSRC, "attention.hip"), "-o", obj], check=True)
@@ -38,7 +39,6 @@ def build():
     if "--variants" in sys.argv:
         return build_variants(sys.argv[sys.argv.index("--variants") + 1].split(":"))
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_p64_gen.py"), "--trace", os.path.join(ROOT, "tools", "probes", "attn_p64_asm_trace.inc")], check=True)
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_pp_gen.py"), "--trace", os.path.join(ROOT, "tools", "probes", "attn_pp_asm_trace.inc")], check=True)
     objs = []
     for src in B.SOURCES:
         obj = os.path.join(ROOT, "tools", "probes", "wgtrace_" + src.replace(".hip", ".o"))

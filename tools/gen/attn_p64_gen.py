@@ -10,11 +10,18 @@ Same math, LDS image and MFMA operand trick as attn_w64_kernel (reference: lib/m
 masked_fill, softmax, @ v): S^T = K Q^T per 32 keys x 32 queries, p = exp2(s) with NO running maximum (checked once per item, failing
 items are redone by the compiler-scheduled exact pass), P^T feeds V^T P^T as the B operand without data movement.
 
-Schedule.  A wave owns 64 queries = two 32-query blocks x (A, B); a 64-key tile is four UNITS (x, jb) = (A,0) (B,0) (A,1) (B,1), each
-4 score MFMAs + 40 VALU (16 exp2, 16 row-sum adds, 8 bf16 packs) + 4 P V MFMAs.  Slot u runs  score MFMAs of unit u+1 | softmax VALU of
-unit u | P V MFMAs of unit u-1, MFMAs alternating between the two accumulator chains, the 40 VALU spread over the eight MFMA gaps
-(5 per gap).  Only 32 score registers and 16 P registers are live, K / V^T fragments are read once per tile and double-buffered
-(4 ds_read_b128 per slot), one barrier and five LDS-DMA instructions per tile, the ring runs three rounds ahead.
+Schedule (profiles/r03_attention.md has the measurements behind every choice).  A wave owns 64 queries = two 32-query blocks A, B;
+a 64-key tile is two key blocks jb = 0, 1.  Per key block a wave runs
+    M phase (s_setprio 1): block A's 4 score MFMAs and 4 P V MFMAs (of the previous key block) interleaved, with block B's PREVIOUS
+            softmax in their gaps (five VALU per gap: the wave waits for the matrix pipe there anyway), then block B's 8 MFMAs bare with
+            the pointer arithmetic and the LDS-DMA issue of round t + 2 in their gaps
+    V phase (priority 0): block A's softmax (40 VALU) and the 8 fragment reads of the next M phase.
+The two co-resident workgroups of a CU are NOT synchronised: a wave in its M phase simply outranks the other workgroup's wave in its V
+phase, so matrix and VALU phases of the two waves of a SIMD alternate by themselves (a first version interleaved MFMAs and VALU finely
+in both waves: the older wave then ran at ~70 cycles per MFMA and the younger at ~210; an 8-wave version with a barrier per phase was
+fair but paid for the lock-step: both in the history of this file).  One barrier per tile (the DMA round's publication), 32 live score
+registers, every K / V^T fragment read once per tile, the ring runs two rounds ahead.  Options P64_OPT / P64_ABL: measured alternatives
+(LDS-DMA or pointer arithmetic in the V phase, block B's softmax over ten gaps: all slower) and timing-only ablations for the trace tools.
 """
 import os
 
@@ -175,7 +182,10 @@ def mask_apply(par, jb):
     return out
 
 
-OPT = dict(prio=1)
+OPT = dict(prio=1, dma_v=0, spread=0, adv_v=0)
+for _kv in os.environ.get("P64_OPT", "").split(","):
+    if "=" in _kv:
+        OPT[_kv.split("=")[0]] = int(_kv.split("=")[1])
 ABL = set(x for x in os.environ.get("P64_ABL", "").split(",") if x)      # timing-only ablations (WRONG results): prio0, nobar
 if "prio0" in ABL:
     OPT["prio"] = 0
@@ -237,8 +247,24 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
     gaps = softmax_gaps(1)
     nA = 8 if qk else 4                             # drain: P V only, block B's softmax in the four gaps of block A's MFMAs
     fill = {i: [] for i in range(len(mf))}
-    for i in range(8):
-        fill[i * nA // 8] += gaps[i]
+    if qk and OPT["spread"]:
+        # block B's MFMAs reordered so that its softmax may use ten gaps: P V (t2 = 0) first, its scores (which overwrite the registers
+        # the softmax reads) behind the last VALU group
+        pvb = lambda k: mfma(O(1, k & 1, 0), VF(0, k), P(1, k >> 1), O(1, k & 1, 0))
+        qkb = lambda k: mfma(S(1, 0), KF(0, k), Q(1, k), None if k == 0 else S(1, 0))
+        mf = mf[:8] + [pvb(0), pvb(1), qkb(0), pvb(2), qkb(1), pvb(3), qkb(2), qkb(3)]
+        flat = [t for grp in gaps for t in grp]
+        # groups 0..4 (P fragment t2 = 0 complete) within gaps 0..7, the rest within gaps 8, 9
+        cvfirst = lambda grp: [t for t in grp if t.startswith("v_cvt")] + [t for t in grp if not t.startswith("v_cvt")]
+        first = [t for grp in gaps[:5] for t in cvfirst(grp)]          # a pack is never the last VALU in front of the MFMA that reads it
+        rest = [t for grp in gaps[5:7] for t in cvfirst(grp)] + cvfirst(gaps[7][:5]) + cvfirst(gaps[7][5:])
+        for n, t in enumerate(first):
+            fill[n * 8 // len(first)].append(t)
+        for n, t in enumerate(rest):
+            fill[8 + n * 2 // len(rest)].append(t)
+    else:
+        for i in range(8):
+            fill[i * nA // 8] += gaps[i]
     pre = []
     if body and jb == 0:
         # block B's pending scores belong to tile t - 1: its mask term (if that tile carried one) is still in KA / V_LIM
@@ -252,18 +278,18 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
     late = {i: [] for i in range(len(mf))}
     if body:
         rd = dma_round((st + 2) & 3)
-        if jb == 0:
-            late[9] += rd[0]
-            late[11] += rd[1]
-            late[13] += rd[4]
-        else:
-            late[9] += rd[2]
-            late[11] += rd[3]
+        if not OPT["dma_v"]:
+            if jb == 0:
+                late[11] += rd[0]
+                late[13] += rd[1]
+                late[14] += rd[4]
+            else:
+                late[11] += rd[2]
+                late[13] += rd[3]
+        if jb == 1 and not OPT["adv_v"]:
             adv = advance_round()
-            late[8] += adv[0:3]
-            late[10] += adv[3:5]
-            late[12] += adv[5:8]
-            late[14] += adv[8:11]
+            late[14] += adv[0:5]
+            late[15] += adv[5:11]
         if masked:
             # this key block's mask term for the V phase that follows (and for block B in the next M phase)
             if jb == 0:
@@ -311,8 +337,18 @@ def phase_V(a, st, jb, masked, body=True):
     if masked:
         for t in mask_apply(0, jb):
             a.e(t)
-    for grp in softmax_gaps(0):
+    extra = []
+    if body and OPT["dma_v"]:
+        rd = dma_round((st + 2) & 3)
+        extra += (rd[0] + rd[1] + rd[4]) if jb == 0 else (rd[2] + rd[3])
+    if body and jb == 1 and OPT["adv_v"]:
+        extra += advance_round()
+    grps = softmax_gaps(0)
+    for i, grp in enumerate(grps):
         for t in grp:
+            a.e(t)
+        # the scalar / DMA extras between the VALU groups
+        for t in extra[i * len(extra) // 8:(i + 1) * len(extra) // 8]:
             a.e(t)
     if body and jb == 1:
         a.e("s_waitcnt lgkmcnt(0)")

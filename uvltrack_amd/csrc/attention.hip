@@ -1252,6 +1252,14 @@ static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
 // sums leave [2^-100, 2^100] come back as bits of `bad` and are redone by attn_w64_item's exact pass (compiler-scheduled, rare).
 // Requires pre-scaled q and at least two key tiles (the launcher falls back to attn_w64_kernel otherwise).
 // ------------------------------------------------------------------------------------------------
+// every register attn_p64_asm.inc names: s38..s101 (its fixed scalar map; hipcc keeps its operands below) and all 256 VGPRs
+#define ATTN_R4(p, n) p #n "0", p #n "1", p #n "2", p #n "3"
+#define ATTN_R10(p, n) p #n "0", p #n "1", p #n "2", p #n "3", p #n "4", p #n "5", p #n "6", p #n "7", p #n "8", p #n "9"
+#define ATTN_P64_SGPRS "s38", "s39", ATTN_R10("s", 4), ATTN_R10("s", 5), ATTN_R10("s", 6), ATTN_R10("s", 7), ATTN_R10("s", 8), ATTN_R10("s", 9), "s100", "s101"
+#define ATTN_P64_VGPRS "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", ATTN_R10("v", 1), ATTN_R10("v", 2), ATTN_R10("v", 3), ATTN_R10("v", 4), \
+    ATTN_R10("v", 5), ATTN_R10("v", 6), ATTN_R10("v", 7), ATTN_R10("v", 8), ATTN_R10("v", 9), ATTN_R10("v", 10), ATTN_R10("v", 11), ATTN_R10("v", 12), \
+    ATTN_R10("v", 13), ATTN_R10("v", 14), ATTN_R10("v", 15), ATTN_R10("v", 16), ATTN_R10("v", 17), ATTN_R10("v", 18), ATTN_R10("v", 19), ATTN_R10("v", 20), \
+    ATTN_R10("v", 21), ATTN_R10("v", 22), ATTN_R10("v", 23), ATTN_R10("v", 24), "v250", "v251", "v252", "v253", "v254", "v255"
 __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -1274,7 +1282,7 @@ __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, co
           [q] "s"(p.q), [k] "s"(p.k), [vt] "s"(p.vt), [ka] "s"(p.key_add), [o] "s"(p.o), [N] "s"(p.N), [Npad] "s"(p.Npad), [H] "s"(p.H),
           [total] "s"(total), [cnt] "s"(cnt), [v] "s"(v0), [G] "s"(G), [kas] "s"(kas), [wave] "s"(wave), [lds] "s"(lds0), [nqb] "s"(nqb),
           [mq] "s"(mq), [mh] "s"(mh)
-        : "memory", "vcc", "scc", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+        : "memory", "vcc", "scc", ATTN_P64_SGPRS, ATTN_P64_VGPRS);
 #endif
     if (bad == 0) return;
     int it = 0;
@@ -1310,83 +1318,6 @@ static hipError_t launch_attn_p64(const AttnParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// attn_pp_kernel: the phase-alternating form (tools/gen/attn_pp_gen.py, attn_pp_asm.inc).  One workgroup = 8 waves = two halves of
-// four waves; each half walks its own 256-query items through its own DMA ring, and a wave alternates an MFMA-only phase (scores of
-// a key block for both of its query blocks + P V of the previous key block) with a VALU-only phase (the softmax of those scores +
-// the next fragment reads), an s_barrier between phases and half 1 one barrier behind half 0: on every SIMD one wave feeds the
-// matrix pipe while the other uses the VALU port.  Flagged items (row sums outside [2^-100, 2^100]) are redone exactly by BOTH
-// halves of a turn, so that the exact pass's workgroup-wide barriers match.
-// ------------------------------------------------------------------------------------------------
-constexpr int ATTN_PP_HALF = 4 * 16384 + 4 * 4 * 256 + 64;
-__global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int wg = (int)blockIdx.x, G = (int)gridDim.x;
-    const int kas = p.key_add_stride * 4;
-    uint64_t bad = 0;
-#if __HIP_DEVICE_COMPILE__
-    asm volatile(
-#ifdef ATTN_WGTRACE
-#include "attn_pp_asm_trace.inc"
-#else
-#include "attn_pp_asm.inc"
-#endif
-        : [bad] "=s"(bad)
-        :
-#ifdef ATTN_WGTRACE
-          [tr] "s"(g_attn_wg),
-#endif
-          [q] "s"(p.q), [k] "s"(p.k), [vt] "s"(p.vt), [ka] "s"(p.key_add), [o] "s"(p.o), [N] "s"(p.N), [Npad] "s"(p.Npad), [H] "s"(p.H),
-          [total] "s"(total), [cnt] "s"(cnt), [wg] "s"(wg), [G] "s"(G), [kas] "s"(kas), [wave] "s"(wave8), [lds] "s"(lds0), [nqb] "s"(nqb),
-          [mq] "s"(mq), [mh] "s"(mh)
-        : "memory", "vcc", "scc", "s38", "s39", "s100", "s101", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225");
-#endif
-    // the halves' flagged-item masks (bit = turn), exchanged: a flagged turn is redone by both halves
-    const int half = wave8 >> 2, lane = attn_opaque_lane();
-    unsigned long long* ex = reinterpret_cast<unsigned long long*>(smem + 2 * ATTN_PP_HALF);
-    if ((wave8 & 3) == 0 && lane == 0) ex[half] = bad;
-    __syncthreads();
-    const unsigned long long both = ex[0] | ex[1];
-    if (both == 0) return;
-    const int xcd = wg & 7;
-    int turn = 0;
-    for (int idx0 = 2 * (wg >> 3); idx0 < cnt; idx0 += G >> 2, ++turn) {
-        if (!((both >> turn) & 1)) continue;
-        int idx = idx0 + half;
-        if (!(idx < cnt && xcd * cnt + idx < total)) idx = idx0 + (half ^ 1);      // no item of its own: the partner's (same result twice)
-        const int L = xcd * cnt + idx;
-        const int qb = L % nqb, r = L / nqb;
-        attn_w64_item<4, false>(p, qb, r % p.H, r / p.H, smem + half * ATTN_PP_HALF, (wave8 & 3) * 64 + lane);
-    }
-}
-
-static hipError_t launch_attn_pp(const AttnParams& p_in, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * ATTN_PP_HALF + 16;
-    const int nt = (p_in.N + 63) / 64;
-    if (!p_in.q_prescaled || nt < 2) return launch_attn_w64<4>(p_in, s);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    g_last_kernel = "attn_pp_kernel";
-    const int nqb = (nt + 3) / 4;
-    const int total = nqb * p_in.H * p_in.B, cnt = (total + 7) / 8;
-    const int pairs = (cnt + 1) / 2;                                      // item pairs per XCD
-    int wgs = tune_get(p_in.tune, &uvl_tuning::attn_wgs, 256);          // persistent workgroups (one per CU)
-    wgs = wgs < 8 ? 8 : (wgs + 7) / 8 * 8;
-    int grid = 8 * pairs < wgs ? 8 * pairs : wgs;
-    while ((pairs + grid / 8 - 1) / (grid / 8) > 64) grid += 8;           // the flagged-turn mask has 64 bits
-    auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
-    AttnParams p = p_in;
-    p.xcd_map = 1;
-    hipLaunchKernelGGL(attn_pp_kernel, dim3(grid), dim3(512), lds, s, p, total, cnt, nqb, magic(nqb), magic(p_in.H));
-    return hipGetLastError();
-}
 
 template <int QW, int KS, int NS>
 static hipError_t launch_attn_pair_cfg(const AttnParams& a, const AttnParams& b, hipStream_t s) {
@@ -1499,7 +1430,6 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
         case 9: return launch_attn_stream<2>(p, s);
         case 10: return launch_attn_w64<4>(p, s);          // 64 queries per wave, two workgroups per CU
         case 11: return launch_attn_p64(p, s);             // the same item shape, hand-scheduled, persistent workgroups
-        case 12: return launch_attn_pp(p, s);              // hand-scheduled, 8 waves in two phase-alternating halves
     }
     return hipErrorInvalidValue;
 }
