@@ -889,6 +889,7 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
 // visual GEMM of the same kind).  1-D grid: problem A owns [0, blocks_a) = tiles_a x splitk_a, problem B the rest; tile
 // counts are multiples of 8, so the workgroup -> XCD relation of both tile maps is preserved.
