@@ -26,7 +26,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 # The kernels pin their instruction order with sched_barrier and count s_waitcnt by hand around inline-asm LDS reads / LDS-DMA
 # (attention.hip::attn_w64_kernel, gemm.hip::gemm_pipe_body): correct for THIS compiler's code generation.  Another hipcc builds too, but
-# the forced-kernel parity tests (tests/test_kernels_gpu.py: attn_cfg 8 / 10, gemm_cfg 30-32) must be re-run on it before its output is trusted.
+# the forced-kernel parity tests (tests/test_kernels_gpu.py: attn_cfg 8 / 10 / 11 -- the last one is generated assembly, tools/gen/attn_p64_gen.py --, gemm_cfg 30-32) must be re-run on it before its output is trusted.
 TESTED_HIPCC = "HIP version: 7.2.26015"
 
 
