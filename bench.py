@@ -194,7 +194,10 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     eng = HipEngine(spec, dev, max_batch=max(B, 1))
     for kv in args.tune:
         k, v = kv.split("=", 1)
-        eng.tune_set(k.strip(), int(v))
+        if k.strip().startswith("debug."):          # uvl_debug_set keys (A/B aids that are not launch heuristics), e.g. debug.aux_priority=1
+            eng.debug_set(k.strip()[6:], int(v))
+        else:
+            eng.tune_set(k.strip(), int(v))
     eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
     inp = wg.make_inputs(spec, batch=B, seed=seed + rank, flags=flags)      # every rank advances its own sequences
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

@@ -87,6 +87,7 @@ struct uvl_model {
     // streams / events
     hipStream_t aux = nullptr;                   // text-branch stream (frames of several sequences)
     int pair_text = 1;                           // uvl_debug_set("pair_text", 0): text branch on its own stream even for one sequence
+    int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_bert, ev_cont;
@@ -561,7 +562,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // costs neither launches nor a second queue; measured, the two-stream form slows each visual layer by ~11 us through
     // contention and ends level with visual layer nf-1 (profiles/r01_summary.md).  Larger batches keep the second stream.
     const bool paired = !skip && !reuse && m->nf > 0 && m->pair_text && B == 1;
-    const bool fork = !skip && !reuse && !prof && m->nf > 0 && parts == PART_ALL && !paired;
+    const bool fork = !skip && !reuse && !prof && m->nf > 0 && parts == PART_ALL && !paired && m->fork_text;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
     enum { R_GEMM = 0, R_ATTN = 1, R_LN = 2 };
     struct Rider { int kind; const char* what; double flops, bytes; GemmParams g; AttnParams a; LnParams l; int layer; };
@@ -943,6 +944,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "fork_text")) { m->fork_text = value ? 1 : 0; return UVL_OK; }   // 0: the text branch of multi-sequence frames runs on the caller's stream
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
 }
 

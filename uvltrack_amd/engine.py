@@ -73,6 +73,10 @@ class HipEngine:
         """uvl_tune_set on THIS engine's handle (there is no process-global tuning state); -1 restores the heuristic."""
         _native.check(self.lib.uvl_tune_set(self.handle, key.encode(), int(value)), "uvl_tune_set(%s)" % key)
 
+    def debug_set(self, key: str, value: int):
+        """uvl_debug_set on this engine's handle: A/B aids that are not launch heuristics (stop_layer, pair_text, fuse_contrast, aux_priority)."""
+        _native.check(self.lib.uvl_debug_set(self.handle, key.encode(), int(value)), "uvl_debug_set(%s)" % key)
+
     def tuned(self, **kw):
         """Context manager: `with eng.tuned(gemm_cfg=11): ...` -- the keys are reset to their heuristics on exit, whatever happens."""
         import contextlib
