@@ -38,23 +38,29 @@ def main():
         add = torch.zeros(B, Npad, device="cuda")
         o = torch.empty(B * N, H * 64, device="cuda", dtype=torch.bfloat16)
         fn = lambda: lib.uvl_attention(p(q), p(k), p(vt), p(add), p(o), B, H, N, Npad, 1, TUNE.ref(), st)
+        # rounds INTERLEAVED over the configurations, best round per configuration: the first thing a process times runs 5-10 % slower
+        # than the same launch a second later (clocks), so "cfg a, then cfg b" flatters b (guide section 5.4 rule 24)
+        best = {c: 1e30 for c in cfgs}
         for cfg in cfgs:
             TUNE.attn_cfg = cfg
-            for _ in range(5):
+            for _ in range(10):
                 fn()
-            torch.cuda.synchronize()
-            best = 1e30
-            for _rep in range(3):
+        torch.cuda.synchronize()
+        for _rep in range(4):
+            for cfg in cfgs:
+                TUNE.attn_cfg = cfg
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 it = 30
+                fn()
                 a.record()
                 for _ in range(it):
                     fn()
                 b.record()
                 torch.cuda.synchronize()
-                best = min(best, a.elapsed_time(b) / it * 1e3)
-            us = best
-            flops = 4.0 * N * N * H * 64 * B
+                best[cfg] = min(best[cfg], a.elapsed_time(b) / it * 1e3)
+        flops = 4.0 * N * N * H * 64 * B
+        for cfg in cfgs:
+            us = best[cfg]
             print("attention B=%3d H=%2d N=%4d cfg %2d  %8.1f us  %7.1f TFLOP/s  (%.1f %% of 2500)" % (B, H, N, cfg, us, flops / us / 1e6, flops / us / 1e6 / 25), flush=True)
     TUNE.attn_cfg = -1
 

@@ -1381,7 +1381,7 @@ static int pick_attn_cfg(const AttnParams& p) {
         const long wg64 = (long)((nt + 3) / 4) * p.H * p.B;     // 256-query workgroups of attn_w64_kernel (two per CU)
         if (wg4 >= 256 && nt >= 2 && p.q_prescaled) cfg = 11;   // the batched regime: the hand-scheduled persistent walk (attn_p64_kernel), ahead of
                                                      // both kernels below on every measured shape from 4 sequences up (profiles/r03_attention.md:
-                                                     // +7..+21 % over attn_w64_kernel, +3..+50 % over the streaming kernel; 8 x N = 553 is level)
+                                                     // +7..+23 % over attn_w64_kernel with interleaved rounds; 8 x N = 553 is 5 % behind the streaming kernel, everything else ahead)
         else if (wg64 >= 384 && nt >= 2) cfg = 10;   // 1.5+ workgroups per CU of the 64-queries-per-wave kernel: +6..+29 % over the streaming
                                                      // kernel on every measured shape from 384 workgroups up (profiles/r02_attention_w64.md),
                                                      // except 576 workgroups of N = 553 (-4 %: a second round at 75 % wave occupancy)
