@@ -1379,7 +1379,9 @@ static int pick_attn_cfg(const AttnParams& p) {
         const long wg2 = (long)((p.N + 63) / 64) * p.H * p.B;
         const int nt = (p.N + 63) / 64;
         const long wg64 = (long)((nt + 3) / 4) * p.H * p.B;     // 256-query workgroups of attn_w64_kernel (two per CU)
-        if (wg4 >= 256 && nt >= 2 && p.q_prescaled) cfg = 11;   // the batched regime: the hand-scheduled persistent walk (attn_p64_kernel), ahead of
+        if (wg64 > 256 && wg64 < 384 && wg4 <= 512 && nt >= 2) cfg = 8;   // 8 UVLTrack-B sequences (288 items of 256 queries = 0.56 of a round of cfg 11's
+                                                     // 512 slots against 480 workgroups of the streaming kernel): 17.9 vs 18.8 us, interleaved rounds
+        else if (wg4 >= 256 && nt >= 2 && p.q_prescaled) cfg = 11;   // the batched regime: the hand-scheduled persistent walk (attn_p64_kernel), ahead of
                                                      // both kernels below on every measured shape from 4 sequences up (profiles/r03_attention.md:
                                                      // +7..+23 % over attn_w64_kernel with interleaved rounds; 8 x N = 553 is 5 % behind the streaming kernel, everything else ahead)
         else if (wg64 >= 384 && nt >= 2) cfg = 10;   // 1.5+ workgroups per CU of the 64-queries-per-wave kernel: +6..+29 % over the streaming
