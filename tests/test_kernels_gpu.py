@@ -177,6 +177,38 @@ def test_attention_batched_kernels_forced(lib, cfg, B, H, N, mode):
     _attention_case(lib, B, H, N, mode, 300 + N, tune=_tune(attn_cfg=cfg))
 
 
+@pytest.mark.parametrize("wgs", [8, 64, 512])
+@pytest.mark.parametrize("B,H,N,mode", [(8, 4, 321, "fill"), (6, 3, 553, "bert"), (5, 2, 200, "bert_all"), (16, 4, 130, "none")])
+def test_attention_p64_persistent_walk(lib, wgs, B, H, N, mode):
+    """attn_p64_kernel (cfg 11, generated assembly) with few persistent workgroups: every workgroup walks several items (flags of item i
+    are read at the start of item i + 1, the ring is reused across items, waves without queries and workgroups without an item take
+    their own paths); `bert_all` flags EVERY item for the exact pass, so the flagged-item mask is exercised beyond its first bit."""
+    _attention_case(lib, B, H, N, mode, 500 + N + wgs, tune=_tune(attn_cfg=11, attn_wgs=wgs))
+
+
+def test_attention_p64_flagged_item_late_in_the_walk(lib):
+    """One key that overflows exp2 in an item that is NOT the first one its workgroup walks: pass 1 of attn_p64_kernel has no running
+    maximum, the item's row sums leave [2^-100, 2^100], its bit in the mask sends exactly that item through the exact pass."""
+    B, H, N = 6, 4, 300
+    Npad = (N + 63) // 64 * 64
+    g = torch.Generator(device="cpu").manual_seed(9)
+    q = torch.zeros((B, H, Npad, 64), dtype=torch.bfloat16, device="cuda")
+    k = torch.zeros_like(q)
+    vt = torch.zeros((B, H, 64, Npad), dtype=torch.bfloat16, device="cuda")
+    q[:, :, :N] = (torch.randn((B, H, N, 64), generator=g) * QSCALE).cuda().bfloat16()
+    k[:, :, :N] = torch.randn((B, H, N, 64), generator=g).cuda().bfloat16()
+    vt[:, :, :, :N] = torch.randn((B, H, 64, N), generator=g).cuda().bfloat16()
+    k[4, 2, 133] = q[4, 2, 17] * (60.0 / QSCALE)             # scores of ~ +-500 log2 units against query 17 of (4, 2): exp2 overflows
+    add = torch.zeros((B, Npad), device="cuda")
+    o = torch.empty((B * N, H * 64), dtype=torch.bfloat16, device="cuda")
+    _chk(lib.uvl_attention(_p(q), _p(k), _p(vt), _p(add), _p(o), B, H, N, Npad, 1, _tref(_tune(attn_cfg=11, attn_wgs=8)), _stream()), lib)
+    torch.cuda.synchronize()
+    s = (q[:, :, :N].float() @ k[:, :, :N].float().transpose(-1, -2)) * math.log(2.0)
+    ref = (s.softmax(-1) @ vt[:, :, :, :N].transpose(2, 3).float()).transpose(1, 2).reshape(B * N, H * 64)
+    assert torch.isfinite(o.float()).all()
+    assert (o.float() - ref).abs().max().item() < 3e-2
+
+
 @pytest.mark.parametrize("mode", ["none", "fill", "bert", "bert_all"])
 @pytest.mark.parametrize("B,H,N", [(1, 12, 553), (3, 12, 40), (8, 16, 681), (2, 12, 321), (32, 12, 553), (24, 16, 873)])
 def test_attention_modes(lib, B, H, N, mode):
