@@ -16,7 +16,7 @@ from uvltrack_amd import _native  # noqa: E402
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-LABEL = {6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 dma-pre", -1: "auto"}
+LABEL = {4: "64x64 ring", 7: "64x64 2st", 9: "128x64", 10: "64x128", 6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 dma-pre", -1: "auto"}
 
 
 def arg(name, default):
@@ -42,6 +42,8 @@ SETS = {
     "L32": [("L32 qkv", 21792, 3072, 1024), ("L32 fc1", 21792, 4096, 1024), ("L32 proj", 21792, 1024, 1024), ("L32 fc2", 21792, 1024, 4096)],
     # 1024 tiles of 256x256 = exactly four rounds of 256 CUs: time(K) = 4 x (fixed cost of a tile + K/64 x cost of a K step)
     "KS": [("K%d" % k, 16384, 4096, k) for k in (128, 256, 512, 1024, 2048, 4096, 8192)],
+    # one UVLTrack-L sequence (BASELINE configs[3]): 833 visual rows, 873 in the fusion layers
+    "L1": [("L1 qkv", 873, 3072, 1024), ("L1 fc1", 873, 4096, 1024), ("L1 qkv833", 833, 3072, 1024), ("L1 fc1 833", 833, 4096, 1024)],
     "B8": [("B8 qkv", 4424, 2304, 768), ("B8 fc1", 4424, 3072, 768), ("B8 proj", 4424, 768, 768), ("B8 fc2", 4424, 768, 3072)],
 }
 
