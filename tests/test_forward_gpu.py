@@ -359,6 +359,28 @@ def test_repeated_frames_are_bit_identical(name, batch):
             assert torch.equal(cur[k], ref[k]), k
 
 
+@pytest.mark.parametrize("name", ["b_z256_x256", "l_z256_x384", "tiny_mixed"])
+def test_fused_layernorm_gemm_launch_is_bit_identical(name):
+    """uvl_debug_set("fuse_ln", 1): one-sequence frames run LayerNorm + the GEMM that consumes it (LN-1 -> QKV, LN-2 -> fc1, with the
+    text branch's riders) as ONE launch -- LayerNorm rows, a hierarchical grid barrier with one L2 invalidate per XCD, then the GEMM tiles.
+    Same device functions, so every output must equal the two-launch frame bit for bit, frame after frame (the barrier's counters
+    are monotonic over launches of different grid sizes).  Off by default: it measures 3-4 % slower (profiles/r03_summary.md)."""
+    meta, spec, _ = load_case(name)
+    inp = {k: v[:1] for k, v in rebuild_inputs(meta, spec).items()}
+    eng = _engine(meta, spec)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inp.items()}
+    keys = ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "text", "pred_boxes")
+    ref = {k: v.clone() for k, v in eng.forward(t["template"], t["search"], t["ids"], t["mask"], t["prompt"], t["flag"]).items() if k in keys}
+    eng.debug_set("fuse_ln", 1)
+    try:
+        for _ in range(25):
+            out = eng.forward(t["template"], t["search"], t["ids"], t["mask"], t["prompt"], t["flag"])
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), k
+    finally:
+        eng.debug_set("fuse_ln", 0)
+
+
 @pytest.mark.parametrize("name,batch", [("b_z128_x256", 16), ("b_z256_x256", 8), ("l_z256_x384", 8)])
 def test_large_batch_matches_single_sequence_runs(name, batch):
     """The batched regime takes other kernels than the fixtures' 2-3 samples (grouped tile order, 64x128 / 128x128 tiles,

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
+#include "ln_body.h"
 
 namespace uvl {
 
@@ -176,9 +177,12 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 // PROD: 0 = every wave stages its share of a tile and computes; 2 / 4 = that many extra PRODUCER waves issue all LDS-DMA instructions (and
 // wait for them) while the WGM x WGN consumer waves only read fragments and issue MFMAs -- an LDS-DMA instruction costs the wave that
 // issues it ~55 cycles, half of what a consumer of the 128x128 tile issues per K step (profiles/r02_gemm_structure.md, probe 5).
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
+// PRE (the fused LayerNorm + GEMM launch): 1 = request the WEIGHT halves of the first NS - 1 K tiles and return (they do not depend on
+// the LayerNorm and fly under it and the grid barrier); 2 = the rest of the tile: the activation halves, then the usual loop.
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0, int PRE = 0>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk_in, const int g, char* smem) {
     int sk = sk_in;
+    static_assert(PRE == 0 || (!CONV && !PROD && NS == 4), "split prologue: plain four-stage tiles only");
     static_assert(BK == 64 || (BK == 32 && !CONV), "K extent of a stage");
     static_assert(PROD == 0 || (!CONV && !NTW), "producer waves: plain GEMMs only");
     constexpr int RB = BK * 2;                       // bytes of a stage row
@@ -273,7 +277,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
             else loff[i] = (uint32_t)(r - BM) * (uint32_t)p.ldw * 2u + (uint32_t)chunk * 16u;
         }
     }
-    auto issue = [&](int kt) __attribute__((always_inline)) {
+    auto issue = [&](int kt, bool do_a = true, bool do_w = true) __attribute__((always_inline)) {
         char* st = smem + (kt % NS) * STAGE;
         if constexpr (CONV) {
             // K index = tap * cin_g + channel; a 64-wide tile never straddles taps
@@ -306,6 +310,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
             const char* wb = pin(w_base + (size_t)kt * (BK * 2));
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
+                if ((i < LPT_A && !do_a) || (i >= LPT_A && !do_w)) continue;
                 const char* gp = (i < LPT_A ? ab : wb) + loff[i];
                 if (NTW && i >= LPT_A)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
@@ -317,6 +322,13 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         }
     };
 
+    const int nk_ = kspan / BK;
+    if constexpr (PRE == 1) {            // weight halves of the first tiles only
+#pragma unroll
+        for (int t = 0; t < NS - 1; ++t)
+            if (t < nk_) issue(t, false, true);
+        return;
+    }
     f32x4 bias_v[TN][4];
     gemm_bias_preload<TN>(p, n0 + wn * WN, lane, g, sk, bias_v);     // older than every DMA: retired by the first tile wait
 
@@ -332,7 +344,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     if (!PROD || producer) {
 #pragma unroll
         for (int t = 0; t < NS - 1; ++t)
-            if (t < nk) issue(t);
+            if (t < nk) issue(t, true, PRE != 2);          // PRE == 2: the weight halves are in LDS already (the grid barrier drained them)
     }
     if (PROD && producer) {
         // producer waves: wait for the own pieces of tile kt, meet the consumers, request tile kt + NS - 1 into the stage they left
@@ -353,7 +365,11 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         if (!PROD) {
             // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight
             const int ahead = nk - 1 - kt;
-            if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
+            // split prologue: the first tiles in flight are activation halves only (LPT_A instructions each)
+            if (PRE == 2 && kt == 0 && ahead >= NS - 2) wait_vmcnt<LPT_A * (NS - 2)>();
+            else if (PRE == 2 && kt == 1 && ahead >= NS - 2) wait_vmcnt<LPT_A * (NS - 3) + LPT>();
+            else if (PRE == 2 && kt < NS - 2) wait_vmcnt<0>();
+            else if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
             else if (NS > 5 && ahead == 3) wait_vmcnt<LPT * 3>();
             else if (NS > 4 && ahead == 2) wait_vmcnt<LPT * 2>();
             else if (NS > 3 && ahead == 1) wait_vmcnt<LPT>();
@@ -1140,6 +1156,131 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
         case EPI_QKV: return launch_epi<EPI_QKV>(p, s);
     }
     return hipErrorInvalidValue;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm + consumer GEMM of a one-sequence frame in ONE launch (ln_gemm_pair_kernel).  The frame is ~96 dependent launches of
+// 5-10 us; a LayerNorm launch is 5.6 us of which ~1 us is work.  Here the workgroups of the GEMM grid first normalise the rows (ln_body,
+// the row kernels' own code; bf16 output stored write-through), meet at a HIERARCHICAL grid barrier, and then run their GEMM tiles:
+//   * workgroup b arrives at the counter of group b % 8 (the XCD it runs on); the arrival that completes a group arrives at the global
+//     counter, waits for all eight groups, invalidates ITS XCD's L2 (one buffer_inv sc1 per XCD: the normalised rows were written by
+//     other XCDs) and releases its group; the others spin on the group's release word.  Measured (tools/probes/grid_barrier2_probe.hip):
+//     3.1-3.3 us per store + barrier + read with 360-432 workgroups, against 8.5 us for one flat counter and 20+ us with an
+//     invalidate per workgroup;
+//   * counters are monotonic: the host passes the generation of this launch and the arrivals of all earlier launches (uvl_model keeps
+//     both; grids differ from launch to launch), nothing is ever reset -- which is
+//     why graph capture keeps the two-launch form (a replay would repeat the generation);
+//   * every workgroup must be resident at once: the launcher fuses only when the grid fits two workgroups per CU (<= 512).
+// Both problems of a paired launch (visual rows + the text branch's rider) go through the same barrier.  Same arithmetic, bit for
+// bit, as layernorm(_pair) followed by gemm(_pair): the device functions are the same.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned gb_load(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// `base`: arrivals the group counters have seen in ALL earlier launches (grids differ from launch to launch, so the host keeps the sum:
+// one counter value, the same for the eight groups, because every grid is a multiple of 8 workgroups)
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, const unsigned gen, const unsigned base, const int nwg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through stores have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int grp = (int)blockIdx.x & 7;
+        const unsigned gsize = (unsigned)nwg >> 3;               // the grid is a multiple of 8 workgroups
+        unsigned* gcnt = ctr + grp * 16;                         // 64-byte spacing
+        unsigned* grel = ctr + 128 + grp * 16;
+        unsigned* glob = ctr + 256;
+        const unsigned prev = __hip_atomic_fetch_add(gcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 == base + gsize) {
+            __hip_atomic_fetch_add(glob, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((int)(gb_load(glob) - gen * 8u) < 0) __builtin_amdgcn_s_sleep(1);     // wrap-safe: the counters run for ever
+            asm volatile("buffer_inv sc1" ::: "memory");
+            asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(grel), "v"(gen) : "memory");
+        } else {
+            while ((int)(gb_load(grel) - gen) < 0) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+template <int EPI, int NS, int NV>
+__global__ __launch_bounds__(256, 2) void ln_gemm_pair_kernel(const LnParams la, const LnParams lb, const int vba, const int vbb, const GemmParams pa, const GemmParams pb,
+                                                              const int blocks_a, const int tiles_a, const int tiles_b, unsigned* bar, const unsigned gen, const unsigned base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // phase 0: the weight halves of this workgroup's first three K tiles go out (cold, from HBM): they fly under phases 1 and 2
+    if ((int)blockIdx.x < blocks_a) {
+        const int id = (int)blockIdx.x, sk = id / tiles_a;
+        gemm_glds_body<64, 64, 2, 2, EPI, NS, false, false, 64, 0, 1>(pa, id - sk * tiles_a, sk, 0, smem);
+    } else {
+        const int id = (int)blockIdx.x - blocks_a, sk = id / tiles_b;
+        gemm_glds_body<64, 64, 2, 2, EPI, NS, false, true, 64, 0, 1>(pb, id - sk * tiles_b, sk, 0, smem);
+    }
+    // phase 1: LayerNorm rows, four (one per wave) per virtual block, spread over the whole grid
+    for (int vb = (int)blockIdx.x; vb < vba + vbb; vb += (int)gridDim.x) {
+        if (vb < vba) ln_body<NV, true, true, true>(la, vb);
+        else ln_body<NV, true, true, false>(lb, vb - vba);
+    }
+    grid_barrier(bar, gen, base, (int)gridDim.x);
+    // phase 2: the GEMM tiles, as gemm_glds_pair_kernel
+    if ((int)blockIdx.x < blocks_a) {
+        const int id = (int)blockIdx.x, sk = id / tiles_a;
+        gemm_glds_body<64, 64, 2, 2, EPI, NS, false, false, 64, 0, 2>(pa, id - sk * tiles_a, sk, 0, smem);
+    } else {
+        const int id = (int)blockIdx.x - blocks_a, sk = id / tiles_b;
+        gemm_glds_body<64, 64, 2, 2, EPI, NS, false, true, 64, 0, 2>(pb, id - sk * tiles_b, sk, 0, smem);
+    }
+}
+
+template <int EPI, int NV>
+static hipError_t launch_ln_gemm_epi(const LnParams& la, const LnParams* lb, const GemmParams& a_in, const GemmParams* b_in, unsigned* bar, unsigned gen, unsigned* base, hipStream_t s) {
+    constexpr int NS = 4;
+    GemmParams a = a_in, b = b_in ? *b_in : a_in;
+    const int mta = (a.M + 63) / 64, mtb = (b.M + 63) / 64;
+    a.group_m = mta;
+    b.group_m = mtb;
+    const int ta = 8 * ((mta * (a.N / 64) + 7) / 8), tb = b_in ? 8 * ((mtb * (b.N / 64) + 7) / 8) : 0;
+    const int ba = ta, bb = tb;                                   // no split-K here (QKV / fc1)
+    constexpr size_t lds = NS * (size_t)(64 + 64) * 128;
+    auto kern = ln_gemm_pair_kernel<EPI, NS, NV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[48];
+    if (!name[0]) snprintf(name, sizeof(name), "ln_gemm_pair_kernel<%d,%d,%d>", EPI, NS, NV);
+    g_last_kernel = name;
+    LnParams l0 = la, l1 = lb ? *lb : la;
+    l0.y_wt = 1;
+    l1.y_wt = 1;
+    const int vba = (l0.M + 3) / 4, vbb = lb ? (l1.M + 3) / 4 : 0;
+    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(256), lds, s, l0, l1, vba, vbb, a, b, ba, ta, tb ? tb : 1, bar, gen, *base);
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) *base += (unsigned)(ba + bb) >> 3;      // every group counter moves by grid / 8
+    return e;
+}
+
+// Fused form where it applies, else LayerNorm(_pair) then GEMM(_pair).  `gen` is consumed (the caller increments it) only when the
+// function returns with *fused = true.
+hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const GemmParams& a, const GemmParams* b, unsigned* bar, unsigned gen, unsigned* base, bool* fused, hipStream_t s) {
+    auto plain = [](const GemmParams& p) {
+        return p.conv_F == 0 && p.groups <= 1 && p.N % 64 == 0 && p.K % 64 == 0 && p.M > 0 && p.splitk == 1 && !p.accumulate && (p.epi == EPI_BF16 || p.epi == EPI_QKV);
+    };
+    const int blocks = 8 * ((((a.M + 63) / 64) * (a.N / 64) + 7) / 8) + (b ? 8 * ((((b->M + 63) / 64) * (b->N / 64) + 7) / 8) : 0);
+    const bool ok = bar && plain(a) && (!b || (plain(*b) && b->epi == a.epi)) && pick_plain_cfg(a) == 4 && (!b || pick_plain_cfg(*b) == 4) && ring1_depth(a) == 4 &&
+                    tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0 && (a.M + 63) / 64 < 16 && (!b || (b->M + 63) / 64 < 16) && blocks <= 512 &&
+                    (la.D == 768 || la.D == 1024) && (!lb || lb->D == la.D) && la.nsplit <= LN_MAX_SLABS && (!lb || (lb->nsplit <= LN_MAX_SLABS && !lb->ct_x)) &&
+                    la.y_bf16 == a.A && (!lb || !b || lb->y_bf16 == b->A) && (lb != nullptr) == (b != nullptr);
+    *fused = ok;
+    if (!ok) {
+        hipError_t e = lb ? launch_layernorm_pair(la, *lb, s) : launch_layernorm(la, s);
+        if (e != hipSuccess) return e;
+        return b ? launch_gemm_pair(a, *b, s) : launch_gemm(a, s);
+    }
+    if (la.D == 768) return a.epi == EPI_QKV ? launch_ln_gemm_epi<EPI_QKV, 3>(la, lb, a, b, bar, gen, base, s) : launch_ln_gemm_epi<EPI_BF16, 3>(la, lb, a, b, bar, gen, base, s);
+    return a.epi == EPI_QKV ? launch_ln_gemm_epi<EPI_QKV, 4>(la, lb, a, b, bar, gen, base, s) : launch_ln_gemm_epi<EPI_BF16, 4>(la, lb, a, b, bar, gen, base, s);
 }
 
 }  // namespace uvl

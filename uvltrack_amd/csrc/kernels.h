@@ -66,6 +66,7 @@ struct LnParams {
                                                  // (text rows kept from an earlier frame); the fold is still written to x
     const float *gamma = nullptr, *beta = nullptr; float eps = 1e-6f;
     bf16_t* y_bf16 = nullptr;                    // [M,D] compact, optional
+    int y_wt = 0;                                // 1: y_bf16 is stored write-through (set by the fused LayerNorm + GEMM launch only)
     float* y_f32 = nullptr; int y_remap = 0;     // optional f32 output; y_remap: same row map as x (in-place LN) else compact
     float* y_copy = nullptr;                     // optional second f32 output, compact [M,D] (text snapshot)
     float* x_snap = nullptr;                     // optional copy of the row AFTER the slab fold and BEFORE pre_add (= the previous
@@ -79,7 +80,10 @@ struct LnParams {
     const int64_t* ct_flag = nullptr; const float* ct_logit_scale = nullptr; float* ct_logits = nullptr;
 };
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
-hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s);   // two independent problems, one launch
+hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s);
+// one-sequence frames: LayerNorm(_pair) + the GEMM(_pair) that consumes it in one launch behind a grid barrier (gemm.hip); falls back to the
+// two launches where the fused form does not apply.  bar: 4 KB of zero-initialised device memory owned by the model, gen: 1, 2, 3, ..., *base: arrivals per group so far (updated)
+hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const GemmParams& a, const GemmParams* b, unsigned* bar, unsigned gen, unsigned* base, bool* fused, hipStream_t s);   // two independent problems, one launch
 
 // set-up + BERT embedding + im2row of a single-stream frame in one launch (rowops.hip::prologue_kernel)
 struct PrologueParams {

@@ -89,6 +89,10 @@ struct uvl_model {
     int pair_text = 1;                           // uvl_debug_set("pair_text", 0): text branch on its own stream even for one sequence
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
+    int fuse_ln = 0;                             // uvl_debug_set("fuse_ln", 1): one-sequence frames launch LayerNorm + its consumer GEMM as ONE kernel behind a
+                                                 // grid barrier (96 -> 72 launches; measured 3-4 % SLOWER than the two launches, so off: profiles/r03_summary.md)
+    unsigned* gbar = nullptr;                    // 4 KB of counters for the fused launches' grid barrier (monotonic: never reset)
+    unsigned gbar_gen = 0, gbar_base = 0;        // generation of the last fused launch; arrivals per counter group so far
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_bert, ev_cont;
     // graph
@@ -139,6 +143,7 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
         delete m;
         return nullptr;
     }
+    if (hipMalloc(&m->gbar, 4096) == hipSuccess) hipMemset(m->gbar, 0, 4096); else m->gbar = nullptr;   // no barrier memory: the fused launches fall back
     m->ev_bert.resize(c->depth);
     m->ev_cont.resize(c->depth);
     for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -161,6 +166,7 @@ extern "C" void uvl_destroy(uvl_model_t* m) {
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     if (m->ev_join) hipEventDestroy(m->ev_join);
     if (m->aux) hipStreamDestroy(m->aux);
+    if (m->gbar) hipFree(m->gbar);
     delete m;
 }
 
@@ -573,6 +579,24 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     struct AttnPair { AttnParams a, b; };
     struct LnPair { LnParams a, b; };
     // launch a visual kernel; if the next waiting text kernel is of the same kind (and, for GEMMs, the same epilogue), take it along
+    // One-sequence frames: a visual LayerNorm (with its text rider) is not launched but held, and the GEMM that consumes it -- always
+    // the next visual launch: LN-1 -> QKV, LN-2 -> fc1 -- takes it along (launch_ln_gemm_pair: LayerNorm rows, grid barrier, GEMM tiles
+    // in one launch).  Graph capture keeps the two-launch form: the barrier's generation is a launch argument.
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cap_status);
+    const bool fuse_ln = B == 1 && m->fuse_ln && m->gbar && cap_status == hipStreamCaptureStatusNone && (paired || skip || reuse);
+    struct PendLn { bool on = false, has_b = false; LnParams a, b; double bytes = 0; } pend_ln;
+    struct LnGemm { LnParams la, lb; GemmParams ga, gb; bool has_lb, has_gb; unsigned* bar; unsigned gen; unsigned* base; bool fused; };
+    auto flush_ln = [&](hipStream_t st) {            // safety: a held LayerNorm whose consumer did not come next
+        if (!pend_ln.on) return;
+        pend_ln.on = false;
+        if (pend_ln.has_b) {
+            struct LnPair2 { LnParams a, b; } lp{pend_ln.a, pend_ln.b};
+            L.run(st, "layernorm", 0, pend_ln.bytes, [](void* c, hipStream_t q) { auto* x = (LnPair2*)c; return launch_layernorm_pair(x->a, x->b, q); }, &lp);
+        } else {
+            L.run(st, "layernorm", 0, pend_ln.bytes, tramp<LnParams, launch_layernorm>, &pend_ln.a);
+        }
+    };
     auto run_gemm = [&](hipStream_t st, GemmParams& p, const char* what, bool is_text) {
         p.tune = &m->tune;
         if (is_text && !paired && m->tune.text_cfg >= 0) { m->tune_text = m->tune; m->tune_text.gemm_cfg = m->tune.text_cfg; p.tune = &m->tune_text; }
@@ -581,6 +605,22 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (is_text && p.M <= 192) p.w_stream = 1;
         const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K);
         if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.g = p; r.layer = rider_layer; riders.push_back(r); return; }
+        if (pend_ln.on && !is_text) {
+            LnGemm c{};
+            c.la = pend_ln.a; c.lb = pend_ln.b; c.has_lb = pend_ln.has_b; c.ga = p; c.has_gb = false; c.bar = m->gbar; c.gen = m->gbar_gen + 1; c.base = &m->gbar_base; c.fused = false;
+            double fl2 = fl, by2 = by + pend_ln.bytes;
+            if (paired && rider_at < riders.size() && riders[rider_at].kind == R_GEMM && riders[rider_at].g.epi == p.epi) {
+                const Rider& r = riders[rider_at++];
+                c.gb = r.g; c.has_gb = true; fl2 += r.flops; by2 += r.bytes;
+            }
+            pend_ln.on = false;
+            L.run(st, what, fl2, by2, [](void* cc, hipStream_t q) {
+                auto* x = (LnGemm*)cc;
+                return launch_ln_gemm_pair(x->la, x->has_lb ? &x->lb : nullptr, x->ga, x->has_gb ? &x->gb : nullptr, x->bar, x->gen, x->base, &x->fused, q);
+            }, &c);
+            if (c.fused) m->gbar_gen = c.gen;
+            return;
+        }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_GEMM && riders[rider_at].g.epi == p.epi) {
             GemmPair gp{p, riders[rider_at].g};
             const Rider& r = riders[rider_at++];
@@ -591,6 +631,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     };
     auto run_attn = [&](hipStream_t st, AttnParams& p, const char* what, double fl, double by, bool is_text) {
         p.tune = &m->tune;
+        if (!is_text) flush_ln(st);
         if (paired && is_text) { Rider r{}; r.kind = R_ATTN; r.what = what; r.flops = fl; r.bytes = by; r.a = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_ATTN) {
             AttnPair ap{p, riders[rider_at].a};
@@ -602,6 +643,15 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     };
     auto run_ln = [&](hipStream_t st, LnParams& p, double by, bool is_text) {
         if (paired && is_text) { Rider r{}; r.kind = R_LN; r.what = "layernorm"; r.flops = 0; r.bytes = by; r.l = p; r.layer = rider_layer; riders.push_back(r); return; }
+        flush_ln(st);
+        if (fuse_ln && !is_text && p.y_bf16 && (L.parts & L.cur)) {      // held for the GEMM that reads p.y_bf16
+            pend_ln.on = true; pend_ln.a = p; pend_ln.has_b = false; pend_ln.bytes = by;
+            if (paired && rider_at < riders.size() && riders[rider_at].kind == R_LN && riders[rider_at].l.D == p.D) {
+                const Rider& r = riders[rider_at++];
+                pend_ln.b = r.l; pend_ln.has_b = true; pend_ln.bytes += r.bytes;
+            }
+            return;
+        }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_LN && riders[rider_at].l.D == p.D) {
             LnPair lp{p, riders[rider_at].l};
             const Rider& r = riders[rider_at++];
@@ -838,6 +888,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     if (m->nf >= m->depth && fork && m->debug_stop_layer < 0) {   // no fusion layer at all: still join the text branch
         if (hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) return fail(UVL_EHIP, "join failed");
     }
+    flush_ln(s);
     if (paired) flush_riders(s);
     if (pend_v.nsplit || pend_t.nsplit) return fail(UVL_ESTATE, "internal: split-K slabs left unconsumed");
     if (fused_ct >= 0) return fail(UVL_ESTATE, "internal: fused contrast job left unlaunched");
@@ -944,6 +995,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fork_text")) { m->fork_text = value ? 1 : 0; return UVL_OK; }   // 0: the text branch of multi-sequence frames runs on the caller's stream
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
 }
