@@ -235,6 +235,7 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   attn_cfg   index into the attention configuration table (attention.hip::launch_attention)
  *   sk_k1 / sk_k4  split-K factor of the frame's residual GEMMs with K = D / K = 4 D
  *   gemm_pipe  0 = never pick the phase-pipelined 256-wide GEMM (default: batched frames, see gemm.hip::pick_plain_cfg)
+ *   gemm_w4    0 = never pick the four-wave 256 x 256 GEMM with the generated K loop (cfg 34, gemm_w4.hip) where cfg 30 would do
  *   ring1      ring depth (3..5 stages of 16 KB) of the 64x64 tile that one-sequence frames use (default 4)
  *   res_store  cache policy of the in-place f32 residual stores (x += ...) of the GEMM epilogue: 0 plain, 1 non-temporal, 2 write-through (default)
  *   slab_store the same for the split-K f32 slabs of one-sequence frames (default 2)
@@ -242,8 +243,8 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   attn_wgs   persistent workgroups of the hand-scheduled attention kernel (attention.hip::launch_attn_p64; default 512 = two per CU)
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
-    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs;
-    int32_t reserved[2];
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_w4;
+    int32_t reserved[1];
 } uvl_tuning;
 void uvl_tuning_init(uvl_tuning* t);
 int uvl_tune_set(uvl_model_t* m, const char* key, int value);

@@ -48,3 +48,48 @@ def test_register_map_stays_inside_the_clobber_list():
         used_s.update(int(x) for x in re.findall(r"\bs(\d+)\b", ln))
     assert max(used_v) <= 255
     assert min(used_s) >= 38 and max(used_s) <= 101          # attention.hip: ATTN_P64_SGPRS = s38..s101
+
+
+# ---- the K loop of gemm_w4_kernel (uvltrack_amd/csrc/gemm_w4_asm.inc, tools/gen/gemm_w4_gen.py)
+def _gen_w4():
+    spec = importlib.util.spec_from_file_location("gemm_w4_gen", os.path.join(ROOT, "tools", "gen", "gemm_w4_gen.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_committed_gemm_loop_is_the_generators_output():
+    g = _gen_w4()
+    assert open(os.path.join(ROOT, "uvltrack_amd", "csrc", "gemm_w4_asm.inc")).read() == g.render()
+
+
+def test_gemm_loop_register_map_and_counts():
+    """Every register the block names is in gemm_w4.hip's clobber list (v0..v161, s40..s59) or an accumulator operand (a0..a255, each
+    written by exactly the MFMAs of its block); per K tile and wave: 128 MFMAs, 32 fragment reads, 16 LDS-DMA instructions, one barrier;
+    the wave index is NOT read back from a VALU-written SGPR (the hazard that cost a morning)."""
+    import re
+    g = _gen_w4()
+    lines = g.Gen().generate()
+    used_v, used_s, used_a = set(), set(), set()
+    for ln in lines:
+        for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", ln):
+            used_v.update(range(int(a), int(b) + 1))
+        used_v.update(int(x) for x in re.findall(r"\bv(\d+)\b", ln))
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", ln):
+            used_s.update(range(int(a), int(b) + 1))
+        used_s.update(int(x) for x in re.findall(r"\bs(\d+)\b", ln))
+        for a, b in re.findall(r"\ba\[(\d+):(\d+)\]", ln):
+            used_a.update(range(int(a), int(b) + 1))
+    assert max(used_v) < g.NV == 162
+    assert min(used_s) >= 40 and max(used_s) <= 59
+    assert used_a == set(range(256))
+    top = lines.index("top_%=:")
+    loop = lines[top:]
+    assert sum("v_mfma_f32_16x16x32_bf16" in ln for ln in loop) == 2 * 128
+    assert sum(ln.startswith("ds_read_b128") for ln in loop) == 2 * 32
+    assert sum(ln.startswith("global_load_lds_dwordx4") for ln in loop) == 2 * 16
+    assert sum(ln == "s_barrier" for ln in loop) == 2
+    assert not any("v_readfirstlane" in ln for ln in lines)
+    # an M0 write and the LDS-DMA that uses it are never adjacent without an instruction in between
+    for a, b in zip(lines, lines[1:]):
+        assert not (a.startswith("s_add_u32 m0") and b.startswith("global_load_lds")), (a, b)

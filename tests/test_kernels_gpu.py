@@ -145,20 +145,23 @@ def test_attention_token_counts(lib, N):
     _attention_case(lib, 1, 2, N, "fill", 10 + N)
 
 
-@pytest.mark.parametrize("cfg", [6, 11, 16, 17, 20, 21, 30, 31, 32])
-@pytest.mark.parametrize("M,N,K,act", [(777, 512, 192, 0), (300, 256, 64, 1), (6200, 3072, 768, 1), (1000, 256, 128, 0)])
+@pytest.mark.parametrize("cfg", [6, 11, 16, 17, 20, 21, 30, 31, 32, 34])
+@pytest.mark.parametrize("M,N,K,act", [(777, 512, 192, 0), (300, 256, 64, 1), (6200, 3072, 768, 1), (1000, 256, 128, 0), (513, 768, 448, 2)])
 def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
     """The tile / ring / wave-role forms of the batched GEMM on shapes the heuristic would not give them: 128x128 and 256x256 tiles,
     32-wide K stages with 4 / 5 ring stages (cfg 16 / 17), the producer-wave form (cfg 20 / 21: 2 / 4 extra waves issue every
     LDS-DMA instruction, the four consumer waves only read fragments and issue MFMAs) and the phase-pipelined 256-wide tiles (cfg 30 /
-    31: gemm_pipe_body, two wave groups half a phase apart; K = 64 falls back to the plain loop) -- ragged M, one / two / three K
-    steps, a long K loop."""
+    31: gemm_pipe_body, two wave groups half a phase apart; K = 64 falls back to the plain loop) and the four-wave 256x256 tile whose K
+    loop is generated assembly (cfg 34: gemm_w4_kernel, 16x16x32 MFMAs, an odd and an even number of K tiles) -- ragged M, one / two /
+    three / seven K steps, a long K loop, GELU / ReLU / no activation."""
     x = _rand((M, K), 1).bfloat16()
     w = (_rand((N, K), 2, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
     b = _rand((N,), 3, 0.5)
     ref = x.float() @ w.float().t() + b
-    if act:
+    if act == 1:
         ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
     y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
     _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, _tune(gemm_cfg=cfg).ref(), _stream()), lib)
     torch.cuda.synchronize()

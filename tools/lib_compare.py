@@ -13,7 +13,7 @@ from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
 TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
-CFGS = (4, 7, 9, 10, 6, 11, 30, 31)
+CFGS = (4, 7, 9, 10, 6, 11, 30, 31, 34)
 GMS = (0, 8)
 
 
@@ -48,7 +48,7 @@ def gemms(B, D, ntok):
         best = (mine, "auto")
         allc = []
         for cfg in CFGS:
-            if (cfg in (2, 3, 6, 10, 12, 13, 15) and N % 128) or (cfg in (11, 14, 30, 31) and N % 256):
+            if (cfg in (2, 3, 6, 10, 12, 13, 15) and N % 128) or (cfg in (11, 14, 30, 31, 34) and N % 256):
                 continue
             TUNE.gemm_cfg = cfg
             for gm in GMS:

@@ -55,19 +55,19 @@ class UvlCropGeometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("crop_sz", "x1", "y1", "x1_pad", "x2_pad", "y1_pad", "y2_pad")] + [("resize_factor", C.c_float)]
 
 
-TUNING_FIELDS = ("gemm_cfg", "gemm_gm", "gemm_prod", "gemm_big", "gemm_kxcd", "attn_cfg", "sk_k1", "sk_k4", "gemm_pipe", "ring1", "text_cfg", "res_store", "slab_store", "attn_wgs")
+TUNING_FIELDS = ("gemm_cfg", "gemm_gm", "gemm_prod", "gemm_big", "gemm_kxcd", "attn_cfg", "sk_k1", "sk_k4", "gemm_pipe", "ring1", "text_cfg", "res_store", "slab_store", "attn_wgs", "gemm_w4")
 
 
 class UvlTuning(C.Structure):
     """include/uvltrack_hip.h: uvl_tuning -- overrides of the launch heuristics for tools and tests, every field -1 = heuristic.
     `UvlTuning(gemm_cfg=11)` forces one choice; pass `tuning.ref()` (or None) to the per-kernel entry points."""
-    _fields_ = [(n, C.c_int32) for n in TUNING_FIELDS] + [("reserved", C.c_int32 * 2)]
+    _fields_ = [(n, C.c_int32) for n in TUNING_FIELDS] + [("reserved", C.c_int32 * 1)]
 
     def __init__(self, **kw):
         super().__init__()
         for n in TUNING_FIELDS:
             setattr(self, n, -1)
-        for i in range(2):
+        for i in range(len(self.reserved)):
             self.reserved[i] = -1
         for k, v in kw.items():
             if k not in TUNING_FIELDS:

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libuvltrack_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "prompter.hip", "preprocess.hip", "uvl_api.hip"]
+SOURCES = ["gemm.hip", "gemm_w4.hip", "attention.hip", "rowops.hip", "prompter.hip", "preprocess.hip", "uvl_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1",      # accumulators stay in VGPRs (unified file on gfx950): no v_accvgpr moves around the softmax
          # a*b+c fuses where the SOURCE expression says so, not wherever the optimiser finds a multiply next to an add: the same
@@ -23,6 +23,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-ffp-contract=on",
          "-I", INCLUDE, "-I", CSRC]
 
+# translation units whose kernels keep their MFMA accumulators in AGPRs (gemm_w4.hip: 256 accumulator registers per wave)
+AGPR_FORM = {"gemm_w4.hip"}
+AGPR_FORM_DROP = {"-mllvm", "-amdgpu-mfma-vgpr-form=1"}
 
 # The kernels pin their instruction order with sched_barrier and count s_waitcnt by hand around inline-asm LDS reads / LDS-DMA
 # (attention.hip::attn_w64_kernel, gemm.hip::gemm_pipe_body): correct for THIS compiler's code generation.  Another hipcc builds too, but
@@ -64,7 +67,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        flags = [f for f in FLAGS if f not in AGPR_FORM_DROP] if src in AGPR_FORM else FLAGS
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -16,147 +16,9 @@
 #include "common.h"
 #include "kernels.h"
 #include "ln_body.h"
+#include "gemm_epi.h"
 
 namespace uvl {
-
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_QKV = 2 };
-
-// Epilogue of the pipelined kernel, which computes the tile TRANSPOSED (W fragments feed the MFMA row operand, A
-// fragments the column operand): lane l holds output row m = l & 31 and, per register quad q = r >> 2, the four
-// consecutive columns n = 8 q + 4 (l >> 5) + (r & 3).  Bias / activation are applied in registers, then each wave
-// transposes 32 rows at a time through its own slice of the (now idle) LDS ring and writes them back row-major, 16 bytes
-// per lane: every store instruction covers whole 128-byte lines (measured on the fc1 shape at M = 17.7k,
-// tools/probes/gemm_probe.hip: 112 us, against 124 us for element-per-lane stores and 141 us for 8 bytes per lane on
-// 32 different rows).  V^T of the QKV projection is token-contiguous and is stored straight from registers.
-//
-// The bias of the lane's columns is fetched by gemm_bias_preload at kernel start (it does not depend on the product): as
-// conditional loads inside the epilogue they were four dependent L2 round trips per launch, each behind its own s_waitcnt.
-__device__ uint32_t g_zero_page[256];     // 1 KB of zeros: DMA source of out-of-image conv taps (zero padding), absent bias
-
-template <int TN>
-__device__ __forceinline__ void gemm_bias_preload(const GemmParams& p, int colw, int lane, int g, int sk, f32x4 (&bv)[TN][4]) {
-    const float* bp = (p.bias && sk == 0) ? p.bias + (size_t)g * p.N + colw : reinterpret_cast<const float*>(g_zero_page);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(bp + j * 32 + 8 * q + 4 * (lane >> 5));
-}
-
-template <int TM, int TN, int WM, int WN, int EPI, int NW>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
-                                                  int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4]) {
-    const bool has_bias = p.bias && sk == 0;
-    constexpr int ES = (EPI == EPI_F32) ? 4 : 2;               // output element size
-    constexpr int RS = WN * ES + 16;                            // padded LDS row stride
-    constexpr int LPR = WN * ES / 16;                           // lanes per row on the way out
-    constexpr int RPI = 64 / LPR;                               // rows per store instruction
-    const int colw = n0 + wn * WN;                              // first column of this wave's sub-tile
-    const bool vpart = EPI == EPI_QKV && colw >= 2 * p.D;       // wave-uniform: D % 64 == 0 and WN divides 64
-    const float qs = (EPI == EPI_QKV && colw < p.D) ? p.q_scale : 1.0f;   // q columns carry the attention's log2(e)/8 (wave-uniform)
-    __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
-    char* cw = smem + wave * (32 * RS);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int rowl = m0 + wm * WM + i * 32 + (lane & 31);
-        if (vpart) {
-            if (rowl < p.M) {
-                const int b = rowl / p.rpb, rem = rowl - b * p.rpb;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = colw + j * 32 + 8 * q + 4 * (lane >> 5);
-                        const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][4 * q + e] + (has_bias ? bv[j][q][e] : 0.f));
-                    }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = j * 32 + 8 * q + 4 * (lane >> 5);
-                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (has_bias) v += bv[j][q];
-                if (EPI == EPI_QKV) v *= qs;
-                if (EPI == EPI_F32) {
-                    *reinterpret_cast<f32x4*>(cw + (lane & 31) * RS + cl * 4) = v;
-                } else {
-                    if (EPI == EPI_BF16 && p.act == 1) {
-                        const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
-                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
-                    } else if (EPI == EPI_BF16 && p.act == 2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    uint2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<uint2*>(cw + (lane & 31) * RS + cl * 2) = o;
-                }
-            }
-        if constexpr (EPI == EPI_F32) {
-            // the table / residual operands of a chunk of row groups are requested together (one wait), then added in the same order;
-            // the chunk is all 32 rows except where the accumulators already fill half the register file (128 x 64 per wave)
-            constexpr int NIT = 32 / RPI;
-            constexpr int CH = (TM * TN >= 8 && NIT > 4) ? 4 : NIT;
-            const int c16 = lane % LPR, col = colw + c16 * (16 / ES);
-#pragma unroll
-            for (int h0 = 0; h0 < NIT; h0 += CH) {
-                f32x4 v[CH], tv[CH], ov[CH];
-                float* dst[CH];
-                bool inb[CH];
-#pragma unroll
-                for (int it = 0; it < CH; ++it) {
-                    const int r = (h0 + it) * RPI + lane / LPR;
-                    const int row = m0 + wm * WM + i * 32 + r;
-                    inb[it] = row < p.M;
-                    const int rc = inb[it] ? row : p.M - 1;
-                    const int b = rc / p.rpb, rem = rc - b * p.rpb;
-                    v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
-                    dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
-                    if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
-                }
-                if (p.accumulate) {
-#pragma unroll
-                    for (int it = 0; it < CH; ++it) ov[it] = *reinterpret_cast<const f32x4*>(dst[it]);
-                }
-#pragma unroll
-                for (int it = 0; it < CH; ++it) {
-                    if (p.addtab) v[it] += tv[it];
-                    if (p.accumulate) v[it] += ov[it];
-                    if (inb[it]) {
-                        if (p.c_store == 1) __builtin_nontemporal_store(v[it], reinterpret_cast<f32x4*>(dst[it]));
-                        else if (p.c_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst[it]), "v"(v[it]) : "memory");
-                        else *reinterpret_cast<f32x4*>(dst[it]) = v[it];
-                    }
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int r = it * RPI + lane / LPR, c16 = lane % LPR;
-            const int row = m0 + wm * WM + i * 32 + r;
-            const int col = colw + c16 * (16 / ES);
-            if (EPI == EPI_F32) {
-            } else {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(cw + r * RS + c16 * 16);
-                if (row < p.M) {
-                    if (EPI == EPI_BF16) {
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + (size_t)g * p.N + col) = v;
-                    } else {
-                        const int b = row / p.rpb, rem = row - b * p.rpb;
-                        const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
-                        const int hh = cc >> 6, dd = cc & 63;
-                        *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;
-                    }
-                }
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // The kernel: tiles go HBM -> LDS directly (global_load_lds,
@@ -1017,6 +879,7 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 30: return launch_pipe<256, EPI, 1>(p, s);      // 256 x 256, product form: LDS-DMA issued between the MFMAs
         case 31: return launch_pipe128<EPI>(p, s);           // 128 x 256: two phases of 8 MFMAs per K tile, three buffers
         case 32: return launch_pipe<256, EPI, 0>(p, s);      // 256 x 256 with the LDS-DMA issued in front of the barrier (A/B: -2..-5 %)
+        case 34: return launch_gemm_w4(p, EPI, s);                // 256 x 256 on four waves (128 x 128 each), register-staged K tiles
     }
     return hipErrorInvalidValue;
 }
@@ -1045,9 +908,15 @@ static int pick_plain_cfg(const GemmParams& p) {
         auto fill = [](long t) { const long rounds = (t + 255) / 256; return (double)t / (double)(rounds * 256); };
         const long nt256 = p.N / 256;
         const double f256 = fill((long)((p.M + 255) / 256) * nt256), f128 = fill((long)((p.M + 127) / 128) * nt256);
-        if (f256 >= 0.8) return 30;
+        // 256 x 256 with bf16-type outputs (bias / GELU / QKV epilogues) at >= 8192 rows: the four-wave form whose K loop is generated
+        // assembly (cfg 34, gemm_w4.hip: 16x16x32 MFMAs, LDS-DMA, one wave per SIMD) -- in isolation +3..15 % over cfg 30 from K = 768 up
+        // and level with hipBLASLt at 32 sequences; in the frames (interleaved A/B, same box) +2.2 % at 32 UVLTrack-L sequences, +0.5 %
+        // at 32 UVLTrack-B, level at 8 UVLTrack-L, -1.3 % at 8 UVLTrack-B (M = 4424), hence the row bound (profiles/r03_gemm_w4.md).
+        // Its one wave per SIMD leaves the f32 read-modify-write epilogue exposed, so the residual GEMMs stay with cfg 30 / 31.
+        const int c256 = (p.epi != EPI_F32 && p.K >= 512 && p.M >= 8192 && !(p.epi == EPI_QKV && p.D % 128 != 0) && tune_get(p.tune, &uvl_tuning::gemm_w4, 1)) ? 34 : 30;
+        if (f256 >= 0.8) return c256;
         if (f128 >= 0.8) return 31;
-        if (f256 >= 0.6 || f128 >= 0.6) return f256 >= f128 ? 30 : 31;
+        if (f256 >= 0.6 || f128 >= 0.6) return f256 >= f128 ? c256 : 31;
     }
     if (p.M < 6144) return n128 ? 10 : 9;           // 64x128 (128x64), 2 stages
     if (tune_get(p.tune, &uvl_tuning::gemm_prod, 1) && p.epi != EPI_F32 && p.N >= 3072 && n128 && p.splitk <= 1) return 21;   // 4 consumers + 4 producers (probe 5)
@@ -1071,7 +940,7 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
     int cfg = pick_plain_cfg(p);
     if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 21)) && p.N % 128 != 0) cfg = 0;
     if (cfg >= 16 && cfg <= 21 && p.splitk > 1) cfg = 6;
-    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 32)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
+    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 34)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
 

@@ -83,6 +83,7 @@ hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
 hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s);
 // one-sequence frames: LayerNorm(_pair) + the GEMM(_pair) that consumes it in one launch behind a grid barrier (gemm.hip); falls back to the
 // two launches where the fused form does not apply.  bar: 4 KB of zero-initialised device memory owned by the model, gen: 1, 2, 3, ..., *base: arrivals per group so far (updated)
+hipError_t launch_gemm_w4(const GemmParams& p, int epi, hipStream_t s);      // gemm_w4.hip: 256 x 256 on four waves (cfg 34)
 hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const GemmParams& a, const GemmParams* b, unsigned* bar, unsigned gen, unsigned* base, bool* fused, hipStream_t s);   // two independent problems, one launch
 
 // set-up + BERT embedding + im2row of a single-stream frame in one launch (rowops.hip::prologue_kernel)
