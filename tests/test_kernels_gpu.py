@@ -145,7 +145,7 @@ def test_attention_token_counts(lib, N):
     _attention_case(lib, 1, 2, N, "fill", 10 + N)
 
 
-@pytest.mark.parametrize("cfg", [6, 11, 16, 17, 20, 21, 30, 31, 32, 34])
+@pytest.mark.parametrize("cfg", [6, 11, 16, 17, 20, 21, 30, 31, 32, 33, 34])
 @pytest.mark.parametrize("M,N,K,act", [(777, 512, 192, 0), (300, 256, 64, 1), (6200, 3072, 768, 1), (1000, 256, 128, 0), (513, 768, 448, 2)])
 def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
     """The tile / ring / wave-role forms of the batched GEMM on shapes the heuristic would not give them: 128x128 and 256x256 tiles,

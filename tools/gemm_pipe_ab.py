@@ -16,7 +16,7 @@ from uvltrack_amd import _native  # noqa: E402
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-LABEL = {4: "64x64 ring", 7: "64x64 2st", 9: "128x64", 10: "64x128", 6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 dma-pre", 34: "w4 256x256", -1: "auto"}
+LABEL = {4: "64x64 ring", 7: "64x64 2st", 9: "128x64", 10: "64x128", 6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 mi32", 33: "pipe128 mi32", 34: "w4 256x256", -1: "auto"}
 
 
 def arg(name, default):

@@ -28,6 +28,33 @@ namespace uvl {
 // extra fetch) and again on the fragment read.  At batch 1 a workgroup streams its weight panel with
 // exposed HBM latency per K-step; the ring hides it.
 // ------------------------------------------------------------------------------------------------
+// One k step (16 wide) of a 32 x 32 output block in the pipelined kernels.  MI16 = false: one v_mfma_f32_32x32x16_bf16 on fragment ks of
+// both operands.  MI16 = true (the product form): the same flops as two v_mfma_f32_16x16x32_bf16 -- the fragments of a block are then
+// indexed t = 2 * (16-row half) + (32-wide k step), "k step" ks stands for (k step ks >> 1, row half ks & 1) of the A operand and both
+// column halves of the W operand, and registers 4 (2 hi + hj) .. + 3 of the block are its 16 x 16 sub-block (hi, hj) (gemm_epilogue_lds,
+// L16).  Half the accumulator traffic per flop: the loop runs at a higher clock at the same pipe occupancy (profiles/r03_gemm_w4.md,
+// sections 2-3 and 8: +2.5..7 % on the pipelined kernels).
+template <bool MI16>
+__device__ __forceinline__ void pipe_mfma(f32x16& c, const bf16x8 (&wq)[4], const bf16x8 (&aq)[4], const int ks) {
+    if constexpr (!MI16) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks], aq[ks], c, 0, 0, 0);
+    } else {
+        const int s = ks >> 1, hi = ks & 1;
+#pragma unroll
+        for (int hj = 0; hj < 2; ++hj) {
+            const int r0 = 4 * (2 * hi + hj);
+            f32x4 sub = {c[r0], c[r0 + 1], c[r0 + 2], c[r0 + 3]};
+            sub = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[2 * hj + s], aq[2 * hi + s], sub, 0, 0, 0);
+            c[r0] = sub[0]; c[r0 + 1] = sub[1]; c[r0 + 2] = sub[2]; c[r0 + 3] = sub[3];
+        }
+    }
+}
+// fragment t of a 32-row block whose first row is `row0` (lane-independent part): LDS byte offset of this lane's 16 bytes
+template <bool MI16>
+__device__ __forceinline__ int pipe_frag_off(int row0, int t, int lane) {
+    if constexpr (!MI16) return swz128(row0 + (lane & 31), t * 2 + (lane >> 5));
+    else return swz128(row0 + 16 * (t >> 1) + (lane & 15), 4 * (t & 1) + (lane >> 4));
+}
 template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 
@@ -301,7 +328,7 @@ __device__ unsigned int g_gemm_trace[2 * 64 * 4 * 4 + 16];
 // in front of the barrier -- an LDS-DMA instruction costs the issuing wave 60-120 cycles, which the other wave group's 256-cycle MFMA
 // block cannot hide together with up to 12 fragment reads; between MFMAs it rides on the matrix pipe's own latency (+2..5 % at
 // 256 x 256, +5..9 % at 128 x 256; VAR 0 is kept as cfg 32 / 33 for the A/B).
-template <int BM, int EPI, int VAR = 0>
+template <int BM, int EPI, int VAR = 0, bool MI16 = true>
 __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx, char* smem) {
     constexpr int BN = 256, NW = 8, WGN = 4, WM = BM / 2, WN = 64, TM = WM / 32, TN = 2, HB = TM / 2;   // HB: A blocks of a half (lo / hi)
     constexpr int STAGE = (BM + BN) * 128;                   // one K tile: A rows then W rows, 128 bytes each
@@ -375,8 +402,8 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
     int a_off[4], b_off[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        a_off[ks] = swz128(wm * WM + (lane & 31), ks * 2 + (lane >> 5));
-        b_off[ks] = BM * 128 + swz128(wn * WN + (lane & 31), ks * 2 + (lane >> 5));
+        a_off[ks] = pipe_frag_off<MI16>(wm * WM, ks, lane);
+        b_off[ks] = BM * 128 + pipe_frag_off<MI16>(wn * WN, ks, lane);
     }
 
     f32x16 acc[TM][TN];
@@ -469,7 +496,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < HB; ++i) {
-                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(j ? bh[ks] : bl[ks], af[i][ks], acc[i0 + i][j], 0, 0, 0);
+                pipe_mfma<MI16>(acc[i0 + i][j], j ? bh : bl, af[i], ks);
                 if constexpr (VAR == 1 && iss) {
                     constexpr int NM = 4 * HB;               // MFMAs of the phase
                     const int mi = ks * HB + i;
@@ -517,9 +544,9 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5));
+        for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + (MI16 ? 16 * (q & 1) + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5)));
     static_assert(32 * (WN * 4 + 16) * NW <= 2 * STAGE, "epilogue staging fits in the two buffers");
-    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW, MI16>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,7 +561,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
 // may stay outstanding in every steady-state phase (derived as in gemm_pipe_body: wait in p, read in p + 1, wait placed before the
 // phase's own issue).  Epilogue, tile order, bias row in LDS: as gemm_pipe_body.
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool MI16 = true>
 __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int bx, char* smem) {
     constexpr int BM = 128, BN = 256, NW = 8, WM = 64, WN = 64, TM = 2, TN = 2, NBUF = 3;
     constexpr int STAGE = (BM + BN) * 128;                   // 48 KB: A rows then W rows
@@ -597,8 +624,8 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
     int a_off[4], b_off[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        a_off[ks] = swz128(wm * WM + (lane & 31), ks * 2 + (lane >> 5));
-        b_off[ks] = BM * 128 + swz128(wn * WN + (lane & 31), ks * 2 + (lane >> 5));
+        a_off[ks] = pipe_frag_off<MI16>(wm * WM, ks, lane);
+        b_off[ks] = BM * 128 + pipe_frag_off<MI16>(wn * WN, ks, lane);
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -655,7 +682,7 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? bh[ks] : bl[ks], af[i][ks], acc[i][h], 0, 0, 0);
+                pipe_mfma<MI16>(acc[i][h], h ? bh : bl, af[i], ks);
                 if constexpr (iss) {
                     const int mi = ks * 2 + i;
                     __builtin_amdgcn_sched_barrier(0);
@@ -698,18 +725,18 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5));
+        for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + (MI16 ? 16 * (q & 1) + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5)));
     static_assert(32 * (WN * 4 + 16) * NW <= NBUF * STAGE, "epilogue staging fits in the buffers");
-    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW, MI16>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
 }
 
-template <int EPI>
+template <int EPI, bool MI16>
 __global__ __launch_bounds__(512) void gemm_pipe128_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_pipe128_body<EPI>(p, blockIdx.x, smem);
+    gemm_pipe128_body<EPI, MI16>(p, blockIdx.x, smem);
 }
 
-template <int EPI>
+template <int EPI, bool MI16 = true>
 static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (p.N % 256 != 0 || p.K < 128 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return hipErrorInvalidValue;
@@ -719,7 +746,7 @@ static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
     if (forced_gm > 0) p.group_m = forced_gm;
     const int nblk = 8 * ((MT * NT + 7) / 8);
     constexpr size_t lds = 3 * (size_t)(128 + 256) * 128 + 1024;      // three K-tile buffers + the tile's bias row
-    auto kern = gemm_pipe128_kernel<EPI>;
+    auto kern = gemm_pipe128_kernel<EPI, MI16>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -727,19 +754,19 @@ static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[48];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe128_kernel<%d>", EPI);
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe128_kernel<%d,%s>", EPI, MI16 ? "true" : "false");
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, p);
     return hipGetLastError();
 }
 
-template <int BM, int EPI, int VAR>
+template <int BM, int EPI, int VAR, bool MI16>
 __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_pipe_body<BM, EPI, VAR>(p, blockIdx.x, smem);
+    gemm_pipe_body<BM, EPI, VAR, MI16>(p, blockIdx.x, smem);
 }
 
-template <int BM, int EPI, int VAR = 0>
+template <int BM, int EPI, int VAR = 1, bool MI16 = true>
 static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (p.N % 256 != 0 || p.K < 128 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return hipErrorInvalidValue;
@@ -753,7 +780,7 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
 #else
     constexpr size_t lds = 2 * (size_t)(BM + 256) * 128 + 1024;      // two K-tile buffers + the tile's bias row
 #endif
-    auto kern = gemm_pipe_kernel<BM, EPI, VAR>;
+    auto kern = gemm_pipe_kernel<BM, EPI, VAR, MI16>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -761,7 +788,7 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[48];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_kernel<%d,%d,%d>", BM, EPI, VAR);
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_kernel<%d,%d,%d,%s>", BM, EPI, VAR, MI16 ? "true" : "false");
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, p);
     return hipGetLastError();
@@ -876,9 +903,10 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 20: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 2>(p, s);  // 4 consumers + 2 producers, 2 workgroups per CU (3 waves / SIMD)
         case 21: return launch_glds<128, 128, 2, 2, EPI, 2, false, false, 64, 4>(p, s);  // 4 + 4, 2 per CU (4 waves / SIMD: 128 registers)
         // phase-pipelined 256-wide tiles (gemm_pipe_body)
-        case 30: return launch_pipe<256, EPI, 1>(p, s);      // 256 x 256, product form: LDS-DMA issued between the MFMAs
-        case 31: return launch_pipe128<EPI>(p, s);           // 128 x 256: two phases of 8 MFMAs per K tile, three buffers
-        case 32: return launch_pipe<256, EPI, 0>(p, s);      // 256 x 256 with the LDS-DMA issued in front of the barrier (A/B: -2..-5 %)
+        case 30: return launch_pipe<256, EPI, 1, true>(p, s);    // 256 x 256, product form: LDS-DMA issued between the MFMAs, 16x16x32 MFMAs
+        case 31: return launch_pipe128<EPI, true>(p, s);         // 128 x 256: two phases per K tile, three buffers, 16x16x32 MFMAs
+        case 32: return launch_pipe<256, EPI, 1, false>(p, s);   // cfg 30 with 32x32x16 MFMAs (the form of the first half of round 3; A/B)
+        case 33: return launch_pipe128<EPI, false>(p, s);        // cfg 31 with 32x32x16 MFMAs
         case 34: return launch_gemm_w4(p, EPI, s);                // 256 x 256 on four waves (128 x 128 each), register-staged K tiles
     }
     return hipErrorInvalidValue;

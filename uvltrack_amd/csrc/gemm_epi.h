@@ -29,7 +29,10 @@ __device__ __forceinline__ void gemm_bias_preload(const GemmParams& p, int colw,
         for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(bp + j * 32 + 8 * q + 4 * (lane >> 5));
 }
 
-template <int TM, int TN, int WM, int WN, int EPI, int NW>
+// L16: the accumulators of a 32 x 32 block were produced by 16x16x32 MFMAs -- registers 4 (2 hi + hj) .. + 3 of the block hold its 16 x 16
+// sub-block (hi, hj): lane l has row 16 hi + (l & 15) and the four consecutive columns 16 hj + 4 (l >> 4) + r; bv[j][hj] is the bias of those
+// columns.  Everything behind the staging store (row write-out, residual / table operands, V^T) is the same.
+template <int TM, int TN, int WM, int WN, int EPI, int NW, bool L16 = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
                                                   int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4]) {
     const bool has_bias = p.bias && sk == 0;
@@ -44,23 +47,24 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
     char* cw = smem + wave * (32 * RS);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        // 128 x 128 per wave (gemm_w4_kernel: accumulators in AGPRs): keep the row blocks apart, or hipcc moves all 256 accumulators into
-        // VGPRs at once and spills
-        if constexpr (TM * TN == 16) __builtin_amdgcn_sched_barrier(0);
-        const int rowl = m0 + wm * WM + i * 32 + (lane & 31);
         if (vpart) {
-            if (rowl < p.M) {
-                const int b = rowl / p.rpb, rem = rowl - b * p.rpb;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int hi = 0; hi < (L16 ? 2 : 1); ++hi) {
+                const int rowl = m0 + wm * WM + i * 32 + (L16 ? 16 * hi + (lane & 15) : (lane & 31));
+                if (rowl < p.M) {
+                    const int b = rowl / p.rpb, rem = rowl - b * p.rpb;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = colw + j * 32 + 8 * q + 4 * (lane >> 5);
-                        const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
+                    for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][4 * q + e] + (has_bias ? bv[j][q][e] : 0.f));
-                    }
+                        for (int q = 0; q < (L16 ? 2 : 4); ++q) {
+                            const int col = colw + j * 32 + (L16 ? 16 * q + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5));
+                            const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
+                            const int r0 = L16 ? 4 * (2 * hi + q) : 4 * q;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][r0 + e] + (has_bias ? bv[j][q][e] : 0.f));
+                        }
+                }
             }
             continue;
         }
@@ -68,12 +72,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cl = j * 32 + 8 * q + 4 * (lane >> 5);
+                // 32x32x16 blocks: register quad q = columns 8 q + 4 (l >> 5) of row l & 31; 16x16x32: q = (hi, hj)
+                const int hi = q >> 1, hj = q & 1;
+                const int rl = L16 ? 16 * hi + (lane & 15) : (lane & 31);
+                const int cl = j * 32 + (L16 ? 16 * hj + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5));
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (has_bias) v += bv[j][q];
+                if (has_bias) v += bv[j][L16 ? hj : q];
                 if (EPI == EPI_QKV) v *= qs;
                 if (EPI == EPI_F32) {
-                    *reinterpret_cast<f32x4*>(cw + (lane & 31) * RS + cl * 4) = v;
+                    *reinterpret_cast<f32x4*>(cw + rl * RS + cl * 4) = v;
                 } else {
                     if (EPI == EPI_BF16 && p.act == 1) {
                         const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
@@ -83,7 +90,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     uint2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<uint2*>(cw + (lane & 31) * RS + cl * 2) = o;
+                    *reinterpret_cast<uint2*>(cw + rl * RS + cl * 2) = o;
                 }
             }
         if constexpr (EPI == EPI_F32) {
