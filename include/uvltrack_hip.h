@@ -235,7 +235,8 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   attn_cfg   index into the attention configuration table (attention.hip::launch_attention)
  *   sk_k1 / sk_k4  split-K factor of the frame's residual GEMMs with K = D / K = 4 D
  *   gemm_pipe  0 = never pick the phase-pipelined 256-wide GEMM (default: batched frames, see gemm.hip::pick_plain_cfg)
- *   gemm_w4    0 = never pick the four-wave 256 x 256 GEMM with the generated K loop (cfg 34, gemm_w4.hip) where cfg 30 would do
+ *   gemm_w4    1 = pick the four-wave 256 x 256 GEMM with the generated K loop (cfg 34, gemm_w4.hip) where cfg 30 would do, for bf16-type
+ *              epilogues from 8192 rows (default 0: cfg 30 with the same MFMA is faster in the frames)
  *   ring1      ring depth (3..5 stages of 16 KB) of the 64x64 tile that one-sequence frames use (default 4)
  *   res_store  cache policy of the in-place f32 residual stores (x += ...) of the GEMM epilogue: 0 plain, 1 non-temporal, 2 write-through (default)
  *   slab_store the same for the split-K f32 slabs of one-sequence frames (default 2)

@@ -926,22 +926,24 @@ static int pick_plain_cfg(const GemmParams& p) {
         return n128 ? 10 : 9;
     }
     if (t64 < 768) return 4;
-    if (p.M >= 2048 && tune_get(p.tune, &uvl_tuning::gemm_pipe, 1) && p.N % 256 == 0 && p.K >= 128 && p.splitk <= 1 && !(p.epi == EPI_F32 && p.K < 2048)) {
+    if (p.M >= 2048 && tune_get(p.tune, &uvl_tuning::gemm_pipe, 1) && p.N % 256 == 0 && p.K >= 128 && p.splitk <= 1 && !(p.epi == EPI_F32 && p.K < 512)) {
         // phase-pipelined 256-wide tiles (gemm_pipe_body / gemm_pipe128_body), one workgroup per CU: 256 x 256 (7.8 bytes of LDS fill
         // per KFLOP, 0.75 fragment reads per MFMA) where its tiles fill >= 80 % of whole rounds of the 256 CUs, else 128 x 256 under
-        // the same rule, else the better-filling of the two from 60 % on.  One workgroup per CU exposes the epilogue, so the
-        // read-modify-write f32 epilogue only takes them behind a long K loop (fc2).  Measured against the round-2 kernels in
+        // the same rule, else the better-filling of the two from 60 % on.  One workgroup per CU exposes the epilogue; the
+        // read-modify-write f32 epilogue took them only behind K >= 2048 until the loops moved to 16x16x32 MFMAs -- since then from
+        // K = 512 (same box, new / old rule: 32 UVLTrack-B sequences 5601-5610 / 5517-5519 frames/s, 16: 4854-4858 / 4817-4820,
+        // UVLTrack-L x 8 1124-1125 / 1118-1119, x 32 1352-1355 / 1340-1343).  Measured against the round-2 kernels in
         // isolation (tools/gemm_pipe_ab.py, tools/lib_compare.py, profiles/r03_gemm_pipe.md): +5..+35 % from 8 UVLTrack-B sequences
         // (M = 4424: fc1 605 -> 811 TFLOP/s) to 32 UVLTrack-L sequences.
         auto fill = [](long t) { const long rounds = (t + 255) / 256; return (double)t / (double)(rounds * 256); };
         const long nt256 = p.N / 256;
         const double f256 = fill((long)((p.M + 255) / 256) * nt256), f128 = fill((long)((p.M + 127) / 128) * nt256);
-        // 256 x 256 with bf16-type outputs (bias / GELU / QKV epilogues) at >= 8192 rows: the four-wave form whose K loop is generated
-        // assembly (cfg 34, gemm_w4.hip: 16x16x32 MFMAs, LDS-DMA, one wave per SIMD) -- in isolation +3..15 % over cfg 30 from K = 768 up
-        // and level with hipBLASLt at 32 sequences; in the frames (interleaved A/B, same box) +2.2 % at 32 UVLTrack-L sequences, +0.5 %
-        // at 32 UVLTrack-B, level at 8 UVLTrack-L, -1.3 % at 8 UVLTrack-B (M = 4424), hence the row bound (profiles/r03_gemm_w4.md).
-        // Its one wave per SIMD leaves the f32 read-modify-write epilogue exposed, so the residual GEMMs stay with cfg 30 / 31.
-        const int c256 = (p.epi != EPI_F32 && p.K >= 512 && p.M >= 8192 && !(p.epi == EPI_QKV && p.D % 128 != 0) && tune_get(p.tune, &uvl_tuning::gemm_w4, 1)) ? 34 : 30;
+        // The four-wave 256 x 256 form whose K loop is generated assembly (cfg 34, gemm_w4.hip: 16x16x32 MFMAs, LDS-DMA, one wave per
+        // SIMD) is where the 16x16x32 / clock finding came from; against the 32x32x16 cfg 30 it was +3..15 % in isolation and +2.2 % on
+        // 32 UVLTrack-L sequences.  Against TODAY's cfg 30 (same MFMA, two waves per SIMD hiding the epilogue) it loses in the frames
+        // (interleaved A/B: 32 UVLTrack-B sequences 5751-5784 against 5925-5929 frames/s, 32 UVLTrack-L 1352-1357 against 1362-1364), so it
+        // is opt-in: uvl_tuning.gemm_w4 = 1 puts it on bf16-type epilogues from 8192 rows (profiles/r03_gemm_w4.md).
+        const int c256 = (p.epi != EPI_F32 && p.K >= 512 && p.M >= 8192 && !(p.epi == EPI_QKV && p.D % 128 != 0) && tune_get(p.tune, &uvl_tuning::gemm_w4, 0)) ? 34 : 30;
         if (f256 >= 0.8) return c256;
         if (f128 >= 0.8) return 31;
         if (f256 >= 0.6 || f128 >= 0.6) return f256 >= f128 ? c256 : 31;
