@@ -754,7 +754,7 @@ static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[48];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe128_kernel<%d,%s>", EPI, MI16 ? "true" : "false");
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe128_kernel<%d,%d>", EPI, (int)MI16);     // bools as 0 / 1, the way tools/make_profiles.py writes rocprofv3's names
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, p);
     return hipGetLastError();
@@ -788,7 +788,7 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[48];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_kernel<%d,%d,%d,%s>", BM, EPI, VAR, MI16 ? "true" : "false");
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_kernel<%d,%d,%d,%d>", BM, EPI, VAR, (int)MI16);
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, p);
     return hipGetLastError();
