@@ -1,6 +1,6 @@
 """A/B of the batched GEMM forms on the frames' own shapes, beside hipBLASLt (through torch, a yardstick only): the 128x128 product
-loop (cfg 6), its producer-wave form (21), the plain 256x256 tile (11) and the phase-pipelined 256-wide tiles (30: 256x256,
-31: 128x256; gemm.hip::gemm_pipe_body).  Every configuration is bit-checked against torch before it is timed; rounds are
+loop (cfg 6), its producer-wave form (21), the plain 256x256 tile (11), the phase-pipelined 256-wide tiles (30: 256x256,
+31: 128x256; gemm.hip::gemm_pipe_body; 32 / 33: the same with 32x32x16 MFMAs) and the four-wave tile with the generated K loop (34).  Every configuration is bit-checked against torch before it is timed; rounds are
 interleaved in one process and the best of them is reported (guide section 5.4 rule 24).
 Usage (GPU box): python tools/gemm_pipe_ab.py [--epi bf16|gelu|f32acc|qkv] [--cfgs 6,11,30] [--shapes L8,B32,...]"""
 import ctypes as C

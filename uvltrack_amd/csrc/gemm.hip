@@ -327,7 +327,7 @@ __device__ unsigned int g_gemm_trace[2 * 64 * 4 * 4 + 16];
 // VAR 1 (the product form): the phase's two LDS-DMA instructions are issued BETWEEN its MFMAs (behind the 2nd and the 5th) instead of
 // in front of the barrier -- an LDS-DMA instruction costs the issuing wave 60-120 cycles, which the other wave group's 256-cycle MFMA
 // block cannot hide together with up to 12 fragment reads; between MFMAs it rides on the matrix pipe's own latency (+2..5 % at
-// 256 x 256, +5..9 % at 128 x 256; VAR 0 is kept as cfg 32 / 33 for the A/B).
+// 256 x 256, +5..9 % at 128 x 256; VAR 0 is still instantiable but has no cfg number any more: 32 / 33 are now the 32x32x16 forms).
 template <int BM, int EPI, int VAR = 0, bool MI16 = true>
 __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx, char* smem) {
     constexpr int BN = 256, NW = 8, WGN = 4, WM = BM / 2, WN = 64, TM = WM / 32, TN = 2, HB = TM / 2;   // HB: A blocks of a half (lo / hi)
