@@ -169,6 +169,22 @@ def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
     assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "cfg %d max err %g" % (cfg, float(err.max()))
 
 
+@pytest.mark.parametrize("w4", [0, 1])
+def test_linear_heuristic_with_and_without_the_four_wave_form(lib, w4):
+    """The un-forced choice at >= 8192 rows: cfg 30 by default, cfg 34 with uvl_tuning.gemm_w4 = 1 (bf16-type epilogues) -- same
+    function, both against torch; a ragged last tile, K = 576 (nine K tiles)."""
+    M, N, K = 8200, 512, 576
+    x = _rand((M, K), 11).bfloat16()
+    w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()
+    b = _rand((N,), 13, 0.5)
+    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + b)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, 1, 0, 0, _tune(gemm_w4=w4).ref(), _stream()), lib)
+    torch.cuda.synchronize()
+    err = (y.float() - ref).abs()
+    assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "gemm_w4 %d max err %g" % (w4, float(err.max()))
+
+
 @pytest.mark.parametrize("cfg", [8, 10, 11])
 @pytest.mark.parametrize("B,H,N,mode", [(1, 2, 1, "fill"), (1, 2, 33, "fill"), (2, 3, 64, "none"), (2, 3, 65, "bert"), (1, 2, 257, "fill"),
                                          (3, 2, 321, "bert_all"), (2, 4, 553, "fill"), (1, 2, 1100, "fill")])
