@@ -29,7 +29,8 @@ def build_variants(names):
                    P64_OPT=",".join(x for x in parts if "=" in x))
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "attn_p64_gen.py"), "--trace", os.path.join(d, "attn_p64_asm_trace.inc")], check=True, env=env)
         obj = os.path.join(d, "attention.o")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DATTN_WGTRACE", "-I", d, "-c", os.path.join(B.CSRC, "attention.hip"), "-o", obj], check=True)
+        extra = ["-DATTN_P64_NOFALLBACK"] if ("nofallback" in parts or "mfma16" in parts) else []
+        subprocess.run(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DATTN_WGTRACE"] + extra + ["-I", d, "-c", os.path.join(B.CSRC, "attention.hip"), "-o", obj], check=True)
         objs = [obj] + [os.path.join(probes, "wgtrace_" + src.replace(".hip", ".o")) for src in B.SOURCES if src != "attention.hip"]
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(probes, "libuvl_wgtrace_%s.so" % name)] + objs, check=True)
         print("built variant", name)

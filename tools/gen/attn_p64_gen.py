@@ -86,6 +86,9 @@ class Asm:
 
 # ---------------------------------------------------------------- pieces
 def mfma(dst, a, b, c):
+    if "mfma16" in ABL:        # timing probe (results wrong; build attention.hip with -DATTN_P64_NOFALLBACK): the same flops as two 16x16x32 MFMAs
+        return "\\n\\t".join("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (vr(dst + 4 * h, 4), vr(a, 4), vr(b, 4), "0" if c is None else vr(c + 4 * h, 4))
+                              for h in range(2))
     return "v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (vr(dst, 16), vr(a, 4), vr(b, 4), "0" if c is None else vr(c, 16))
 
 

@@ -1284,6 +1284,9 @@ __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, co
           [mq] "s"(mq), [mh] "s"(mh)
         : "memory", "vcc", "scc", ATTN_P64_SGPRS, ATTN_P64_VGPRS);
 #endif
+#ifdef ATTN_P64_NOFALLBACK      // timing probes whose pass 1 is wrong by construction: never take the exact pass
+    return;
+#endif
     if (bad == 0) return;
     int it = 0;
     for (int v = v0; v < 8 * cnt; v += G) {
