@@ -242,10 +242,11 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   slab_store the same for the split-K f32 slabs of one-sequence frames (default 2)
  *   text_cfg   tile configuration (as gemm_cfg) of the text-branch GEMMs of multi-sequence frames, which run on the second stream
  *   attn_wgs   persistent workgroups of the hand-scheduled attention kernel (attention.hip::launch_attn_p64; default 512 = two per CU)
+ *   gemm_sk    1 = split-tile ("stream-K") schedule of the 256 x 256 pipelined GEMM (gemm.hip::gemm_sk_kernel) wherever it applies (needs the
+ *              scratch of uvl_linear_ws); 2 = also whole rounds on persistent workgroups (a timing aid).  Default 0: measured slower than the tile grids
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
-    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_w4;
-    int32_t reserved[1];
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_w4, gemm_sk;
 } uvl_tuning;
 void uvl_tuning_init(uvl_tuning* t);
 int uvl_tune_set(uvl_model_t* m, const char* key, int value);
@@ -261,6 +262,15 @@ int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, flo
  * (the residual add of block.py:30-31); otherwise d_y is bf16 [M,N].  K % 64 == 0, N % 64 == 0. */
 int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
                int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune, void* stream);
+
+/* The same with the scratch of the split-tile GEMM schedule: frames of several thousand rows cut the output tiles that do not fill a
+ * whole round of the CUs along K, and the pieces of a tile meet through f32 slabs in this scratch (fixed summation order, no atomics).
+ * uvl_gemm_scratch_bytes() bytes of device memory, 256-byte aligned, ZERO-FILLED ONCE by the caller (the kernels leave its flags
+ * zero again); one GEMM at a time per scratch.  A model handle owns its own; NULL = tile grids only (what uvl_linear passes). */
+size_t uvl_gemm_scratch_bytes(void);
+int uvl_linear_ws(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
+                  int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune,
+                  void* d_scratch, size_t scratch_bytes, void* stream);
 
 /* Fused multi-head self-attention core of Attention.forward (block.py:50-58) and BertSelfAttention
  * (bert_backbone.py:311-324): softmax(q k^T / sqrt(64) + key_add) v.
@@ -278,6 +288,9 @@ int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const floa
  * q_scale before it is rounded (1.0f = the plain projection). */
 int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
                     int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune, void* stream);
+int uvl_qkv_project_ws(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
+                       int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune,
+                       void* d_scratch, size_t scratch_bytes, void* stream);     /* scratch: see uvl_linear_ws */
 
 /* One layer of the box head's four 3x3 conv towers, conv(3x3, pad 1) + BatchNorm2d(eval) + ReLU (heads/utils.py:126-131;
  * towers of modality_adaptive_box_head.py:28-50), as the frame runs it: BatchNorm folded into bf16 weights, the four towers as

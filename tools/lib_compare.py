@@ -1,6 +1,6 @@
 """Batched-regime yardstick: this library's GEMM / attention kernels beside the vendor libraries reached through
 torch (hipBLASLt matmul, SDPA) on the frame's shapes.  Measurement aid only -- the product never calls torch math.
-Usage (GPU box): python tools/lib_compare.py [batch ...]"""
+Usage (GPU box): python tools/lib_compare.py [batch ...] | cfg4"""
 import ctypes as C
 import os
 import sys
@@ -83,6 +83,14 @@ def attn(B, H, N):
 
 
 def main():
+    if sys.argv[1:2] == ["cfg4"]:
+        # the per-GPU shard of BASELINE configs[4] at the shapes its GEMMs run: 8 UVLTrack-L sequences at z256/x384 = 8 x 833 rows
+        # in the visual layers (M = 6664) and 8 x 873 rows in the fusion layers (M = 6984); M = 5448 = 8 x 681 (z128) beside them
+        for ntok in (833, 873, 681):
+            gemms(8, 1024, ntok)
+        attn(8, 16, 833)
+        attn(8, 16, 873)
+        return
     batches = [int(a) for a in sys.argv[1:]] or [8, 32]
     for B in batches:
         gemms(B, 768, 553)

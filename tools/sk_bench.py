@@ -1,0 +1,66 @@
+"""Split-tile (stream-K) GEMM schedule beside the tile-grid kernels and hipBLASLt on the shapes of 8 UVLTrack-L sequences.
+Usage (GPU box): python tools/sk_bench.py [M ...]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uvltrack_amd import _native  # noqa: E402
+
+if "--lib" in sys.argv:                      # a variant build of the library (development A/B)
+    i = sys.argv.index("--lib")
+    _native.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
+lib = _native.load()
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def timeit(fn, iters=40):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def main():
+    Ms = [int(a) for a in sys.argv[1:]] or [6664, 6984, 5448]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nb = lib.uvl_gemm_scratch_bytes()
+    scratch = torch.zeros((nb,), dtype=torch.uint8, device="cuda")
+    D = 1024
+    for M in Ms:
+        for name, N, K, act, f32 in (("qkv", 3 * D, D, 0, 0), ("fc1", 4 * D, D, 1, 0), ("proj", D, D, 0, 1), ("fc2", D, 4 * D, 0, 1)):
+            x = torch.randn(M, K, device="cuda").bfloat16()
+            w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+            bias = torch.randn(N, device="cuda")
+            y = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+            flops = 2.0 * M * N * K
+            row = []
+            forms = (("auto", {}), ("nosk", dict(gemm_sk=0)), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("sk", dict(gemm_cfg=35, gemm_sk=1)))
+            if os.environ.get("SK_ONLY"):
+                forms = forms[-1:]
+            for label, kw in forms:
+                t = _native.UvlTuning(**kw)
+                for ep_label, a_, f_, acc_ in (("bias", 0, 0, 0), ("frame", act, f32, f32)):
+                    yy = y if f_ == f32 else torch.zeros(M, N, device="cuda", dtype=torch.float32 if f_ else torch.bfloat16)
+                    us = timeit(lambda: lib.uvl_linear_ws(p(x), p(w), p(bias), p(yy), M, N, K, a_, f_, acc_, t.ref(), p(scratch), nb, st))
+                    row.append("%s/%s %.1f" % (label, ep_label, us))
+            bb = bias.bfloat16()
+            ven = timeit(lambda: F.linear(x, w, bb))
+            print("%-4s M=%5d N=%4d K=%4d | %s | hipBLASLt(bias) %.1f us %.0f TF" % (name, M, N, K, "  ".join(row), ven, flops / ven / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,8 @@ struct GemmParams {
                                                  // Infinity Cache (text branch): non-temporal weight-tile loads where instantiated
     const uvl_tuning* tune = nullptr;            // host side only: overrides of the launch heuristics (null = heuristics)
     int c_store = 0;                             // EPI_F32 stores: 0 plain, 1 non-temporal, 2 write-through (sc1); A/B knob uvl_tuning.res_store
+    float* sk_slab = nullptr; unsigned* sk_flags = nullptr; int sk_slots = 0;   // scratch of the split-tile schedule (gemm.hip::gemm_sk_kernel):
+                                                 // sk_slots slabs of 256 KB + as many flags (zero between launches); null = tile grids only
     int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
 };
