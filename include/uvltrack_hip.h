@@ -244,9 +244,11 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   attn_wgs   persistent workgroups of the hand-scheduled attention kernel (attention.hip::launch_attn_p64; default 512 = two per CU)
  *   gemm_sk    1 = split-tile ("stream-K") schedule of the 256 x 256 pipelined GEMM (gemm.hip::gemm_sk_kernel) wherever it applies (needs the
  *              scratch of uvl_linear_ws); 2 = also whole rounds on persistent workgroups (a timing aid).  Default 0: measured slower than the tile grids
+ *   gemm_dr    the direct-to-register GEMM (cfg 36, gemm_dr.hip; needs the packed weight image): 0 = never, 1 = wherever it applies,
+ *              default = frames of >= 2048 rows except the f32 read-modify-write epilogue behind a short K loop
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
-    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_w4, gemm_sk;
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_w4, gemm_sk, gemm_dr;
 } uvl_tuning;
 void uvl_tuning_init(uvl_tuning* t);
 int uvl_tune_set(uvl_model_t* m, const char* key, int value);
@@ -263,12 +265,18 @@ int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, flo
 int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
                int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune, void* stream);
 
-/* The same with the scratch of the split-tile GEMM schedule: frames of several thousand rows cut the output tiles that do not fill a
- * whole round of the CUs along K, and the pieces of a tile meet through f32 slabs in this scratch (fixed summation order, no atomics).
- * uvl_gemm_scratch_bytes() bytes of device memory, 256-byte aligned, ZERO-FILLED ONCE by the caller (the kernels leave its flags
- * zero again); one GEMM at a time per scratch.  A model handle owns its own; NULL = tile grids only (what uvl_linear passes). */
+/* The same with the two optional resources of the many-sequence GEMM kernels (`_ws`: with scratch / packed weights):
+ *   d_w_packed  the weight once more in the fragment-native layout of gemm_dr_kernel (cfg 36: 128 x 256 tiles, two workgroups per CU, the
+ *               weight fragments loaded straight into registers), made by uvl_pack_weight (N % 16 == 0, K % 64 == 0; same size as d_w).
+ *               NULL = that kernel is not available for this call.  A model handle packs its ViT weights at uvl_finalize_weights when
+ *               max_batch allows frames of >= 2048 rows.
+ *   d_scratch   scratch of the split-tile ("stream-K") schedule (cfg 35): the output tiles that do not fill a whole round of the CUs are
+ *               cut along K and the pieces of a tile meet through f32 slabs here (fixed summation order, no atomics).
+ *               uvl_gemm_scratch_bytes() bytes, 256-byte aligned, ZERO-FILLED ONCE by the caller (the kernels leave its flags zero
+ *               again); one GEMM at a time per scratch.  NULL = tile grids only. */
 size_t uvl_gemm_scratch_bytes(void);
-int uvl_linear_ws(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
+int uvl_pack_weight(const void* d_w, void* d_w_packed, int N, int K, void* stream);
+int uvl_linear_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y,
                   int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune,
                   void* d_scratch, size_t scratch_bytes, void* stream);
 
@@ -288,9 +296,9 @@ int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const floa
  * q_scale before it is rounded (1.0f = the plain projection). */
 int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
                     int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune, void* stream);
-int uvl_qkv_project_ws(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
+int uvl_qkv_project_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_q, void* d_k, void* d_vt,
                        int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune,
-                       void* d_scratch, size_t scratch_bytes, void* stream);     /* scratch: see uvl_linear_ws */
+                       void* d_scratch, size_t scratch_bytes, void* stream);     /* d_w_packed, scratch: see uvl_linear_ws */
 
 /* One layer of the box head's four 3x3 conv towers, conv(3x3, pad 1) + BatchNorm2d(eval) + ReLU (heads/utils.py:126-131;
  * towers of modality_adaptive_box_head.py:28-50), as the frame runs it: BatchNorm folded into bf16 weights, the four towers as

@@ -32,16 +32,17 @@ def test_config_struct_layout_matches_header(lib):
 
 
 def test_tuning_struct_and_no_global_tuning_state(lib):
-    """uvl_tuning is a plain 64-byte struct of int32 (-1 = heuristic) owned by a handle or passed per call; the library holds no
+    """uvl_tuning is a plain struct of int32 (-1 = heuristic) owned by a handle or passed per call; the library holds no
     process-global tuning variable (no global mutable state besides the error string)."""
     import subprocess
     from uvltrack_amd import _native
-    assert ctypes.sizeof(_native.UvlTuning) == 64
+    assert ctypes.sizeof(_native.UvlTuning) == 4 * len(_native.TUNING_FIELDS)
     t = _native.UvlTuning(gemm_cfg=11)
     assert t.gemm_cfg == 11 and t.attn_cfg == -1
-    raw = (ctypes.c_int32 * 16)(*range(16))
+    nf = len(_native.TUNING_FIELDS)
+    raw = (ctypes.c_int32 * (nf + 1))(*range(nf + 1))
     lib.uvl_tuning_init(ctypes.cast(raw, ctypes.POINTER(_native.UvlTuning)))
-    assert list(raw) == [-1] * 16
+    assert list(raw) == [-1] * nf + [nf]                       # exactly the struct, not a byte more
     hdr = open(os.path.join(ROOT, "include", "uvltrack_hip.h")).read()
     fields = re.search(r"typedef struct uvl_tuning \{\s*int32_t ([^;]+);", hdr).group(1).replace(" ", "").split(",")
     assert tuple(fields) == _native.TUNING_FIELDS

@@ -169,6 +169,37 @@ def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
     assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "cfg %d max err %g" % (cfg, float(err.max()))
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(777, 512, 192, "bf16"), (300, 256, 64, "gelu"), (6200, 3072, 768, "gelu"), (1000, 256, 128, "relu"),
+                                         (513, 768, 448, "f32"), (6984, 1024, 4096, "f32_acc"), (130, 256, 1024, "f32_acc"), (6664, 4096, 1024, "bf16")])
+def test_linear_direct_to_register_form(lib, M, N, K, mode):
+    """gemm_dr_kernel (cfg 36): 128 x 256 tiles on four waves, two workgroups per CU, A through a four-stage LDS ring, W fragments loaded
+    straight into registers from the fragment-native weight image of uvl_pack_weight, K loop in generated assembly.  Ragged M, 1 / 2 / 3 /
+    7 / 12 / 16 / 64 K tiles (the loop is unrolled four times with clamped tile indices), every epilogue."""
+    x = _rand((M, K), 1).bfloat16()
+    w = (_rand((N, K), 2, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
+    b = _rand((N,), 3, 0.5)
+    wp = torch.empty_like(w)
+    _chk(lib.uvl_pack_weight(_p(w), _p(wp), N, K, _stream()), lib)
+    ref = x.float() @ w.float().t() + b
+    t = _tune(gemm_cfg=36)
+    if mode in ("bf16", "gelu", "relu"):
+        act = {"bf16": 0, "gelu": 1, "relu": 2}[mode]
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _chk(lib.uvl_linear_ws(_p(x), _p(w), _p(wp), _p(b), _p(y), M, N, K, act, 0, 0, t.ref(), None, 0, _stream()), lib)
+        r = torch.nn.functional.gelu(ref) if act == 1 else torch.relu(ref) if act == 2 else ref
+        torch.cuda.synchronize()
+        err = (y.float() - r).abs()
+        assert bool((err <= 1e-2 * r.abs() + 2e-2).all()), "max err %g" % float(err.max())
+    else:
+        acc = mode == "f32_acc"
+        y0 = _rand((M, N), 4) if acc else torch.full((M, N), float("nan"), device="cuda")
+        y = y0.clone()
+        _chk(lib.uvl_linear_ws(_p(x), _p(w), _p(wp), _p(b), _p(y), M, N, K, 0, 1, int(acc), t.ref(), None, 0, _stream()), lib)
+        torch.cuda.synchronize()
+        err = (y - (ref + y0 if acc else ref)).abs().max().item()
+        assert err < 3e-3, err
+
+
 def _gemm_scratch(lib):
     """zero-filled scratch of the split-tile GEMM schedule (include/uvltrack_hip.h: uvl_linear_ws)"""
     n = lib.uvl_gemm_scratch_bytes()
@@ -198,7 +229,7 @@ def test_linear_split_tile_schedule(lib, M, N, K, mode):
         if mode in ("bf16", "gelu", "relu"):
             act = {"bf16": 0, "gelu": 1, "relu": 2}[mode]
             y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-            _chk(lib.uvl_linear_ws(_p(x), _p(w), _p(b), _p(y), M, N, K, act, 0, 0, t.ref(), _p(scratch), nbytes, _stream()), lib)
+            _chk(lib.uvl_linear_ws(_p(x), _p(w), None, _p(b), _p(y), M, N, K, act, 0, 0, t.ref(), _p(scratch), nbytes, _stream()), lib)
             r = torch.nn.functional.gelu(ref) if act == 1 else torch.relu(ref) if act == 2 else ref
             torch.cuda.synchronize()
             err = (y.float() - r).abs()
@@ -207,7 +238,7 @@ def test_linear_split_tile_schedule(lib, M, N, K, mode):
             acc = mode == "f32_acc"
             y0 = _rand((M, N), 4) if acc else torch.full((M, N), float("nan"), device="cuda")
             y = y0.clone()
-            _chk(lib.uvl_linear_ws(_p(x), _p(w), _p(b), _p(y), M, N, K, 0, 1, int(acc), t.ref(), _p(scratch), nbytes, _stream()), lib)
+            _chk(lib.uvl_linear_ws(_p(x), _p(w), None, _p(b), _p(y), M, N, K, 0, 1, int(acc), t.ref(), _p(scratch), nbytes, _stream()), lib)
             torch.cuda.synchronize()
             err = (y - (ref + y0 if acc else ref)).abs().max().item()
             assert err < 3e-3, err
@@ -231,7 +262,7 @@ def test_qkv_project_split_tile_schedule(lib):
         k = torch.zeros_like(q)
         vt = torch.zeros((B, D // 64, 64, Npad), dtype=torch.bfloat16, device="cuda")
         t = _tune(gemm_sk=sk, gemm_cfg=35 if sk else 30)
-        _chk(lib.uvl_qkv_project_ws(_p(x), _p(w), _p(b), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(QSCALE), t.ref(), _p(scratch), nbytes, _stream()), lib)
+        _chk(lib.uvl_qkv_project_ws(_p(x), _p(w), None, _p(b), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(QSCALE), t.ref(), _p(scratch), nbytes, _stream()), lib)
         torch.cuda.synchronize()
         res.append((q, k, vt))
     ref = (x.float() @ w.float().t() + b).reshape(B, N, 3, D // 64, 64)

@@ -45,17 +45,19 @@ def main():
             x = torch.randn(M, K, device="cuda").bfloat16()
             w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
             bias = torch.randn(N, device="cuda")
+            wp = torch.empty_like(w)
+            lib.uvl_pack_weight(p(w), p(wp), N, K, st)
             y = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
             flops = 2.0 * M * N * K
             row = []
-            forms = (("auto", {}), ("nosk", dict(gemm_sk=0)), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("sk", dict(gemm_cfg=35, gemm_sk=1)))
+            forms = (("auto", {}), ("nosk", dict(gemm_sk=0)), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("sk", dict(gemm_cfg=35, gemm_sk=1)), ("dr", dict(gemm_cfg=36)))
             if os.environ.get("SK_ONLY"):
-                forms = forms[-1:]
+                forms = [f for f in forms if f[0] in os.environ["SK_ONLY"].split(",")]
             for label, kw in forms:
                 t = _native.UvlTuning(**kw)
                 for ep_label, a_, f_, acc_ in (("bias", 0, 0, 0), ("frame", act, f32, f32)):
                     yy = y if f_ == f32 else torch.zeros(M, N, device="cuda", dtype=torch.float32 if f_ else torch.bfloat16)
-                    us = timeit(lambda: lib.uvl_linear_ws(p(x), p(w), p(bias), p(yy), M, N, K, a_, f_, acc_, t.ref(), p(scratch), nb, st))
+                    us = timeit(lambda: lib.uvl_linear_ws(p(x), p(w), p(wp), p(bias), p(yy), M, N, K, a_, f_, acc_, t.ref(), p(scratch), nb, st))
                     row.append("%s/%s %.1f" % (label, ep_label, us))
             bb = bias.bfloat16()
             ven = timeit(lambda: F.linear(x, w, bb))

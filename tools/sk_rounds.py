@@ -45,7 +45,7 @@ def main():
                 y = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
                 for label, kw in (("grid", dict(gemm_cfg=30, gemm_sk=0)), ("persist", dict(gemm_cfg=35, gemm_sk=2))):
                     t = _native.UvlTuning(**kw)
-                    us = timeit(lambda: lib.uvl_linear_ws(p(x), p(w), p(bias), p(y), M, N, K, act, f32, f32, t.ref(), p(scratch), nb, st))
+                    us = timeit(lambda: lib.uvl_linear_ws(p(x), p(w), None, p(bias), p(y), M, N, K, act, f32, f32, t.ref(), p(scratch), nb, st))
                     out.append("%s %.1f" % (label, us))
             print("rounds %d M=%5d N=%4d K=%4d | bias: %s %s | gelu: %s %s | f32acc: %s %s" % ((rounds, M, N, K) + tuple(out)), flush=True)
 

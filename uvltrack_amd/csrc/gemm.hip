@@ -1098,6 +1098,7 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 32: return launch_pipe<256, EPI, 1, false>(p, s);   // cfg 30 with 32x32x16 MFMAs (the form of the first half of round 3; A/B)
         case 33: return launch_pipe128<EPI, false>(p, s);        // cfg 31 with 32x32x16 MFMAs
         case 34: return launch_gemm_w4(p, EPI, s);                // 256 x 256 on four waves (128 x 128 each), register-staged K tiles
+        case 36: return launch_gemm_dr(p, EPI, s);                // 128 x 256 on four waves, two workgroups per CU, W fragments straight from global memory
         case 35: {                                                // cfg 30's loop under the split-tile schedule (gemm_sk_kernel); cfg 30 where it does not apply
             const hipError_t e = launch_pipe_sk<EPI>(p, s);
             return e == hipErrorNotSupported ? launch_pipe<256, EPI, 1, true>(p, s) : e;
@@ -1137,6 +1138,15 @@ static int pick_plain_cfg(const GemmParams& p) {
         // 32 UVLTrack-L sequences.  Against TODAY's cfg 30 (same MFMA, two waves per SIMD hiding the epilogue) it loses in the frames
         // (interleaved A/B: 32 UVLTrack-B sequences 5751-5784 against 5925-5929 frames/s, 32 UVLTrack-L 1352-1357 against 1362-1364), so it
         // is opt-in: uvl_tuning.gemm_w4 = 1 puts it on bf16-type epilogues from 8192 rows (profiles/r03_gemm_w4.md).
+        // The direct-to-register form (cfg 36, gemm_dr.hip: 128 x 256 tiles on four waves, TWO workgroups per CU, W fragments loaded straight
+        // into registers from the fragment-native weight image): what a tile pays outside its K loop runs under the other workgroup's loop.
+        // Measured beside cfg 30 / 31 and hipBLASLt (profiles/r04_gemm_dr.md): ahead of both with the bias / GELU / QKV epilogues on every
+        // shape of 8 sequences; with the f32 read-modify-write epilogue only behind a long K loop (a 220-tile launch is ONE round: its
+        // 57 MB burst overlaps nothing, and the eight-wave 128 x 256 kernel hides more of it).  uvl_tuning.gemm_dr: 0 = never, 1 = wherever it applies.
+        {
+            const int want = tune_get(p.tune, &uvl_tuning::gemm_dr, -1);
+            if (want != 0 && p.Wp && p.K % 64 == 0 && (want == 1 || p.epi != EPI_F32 || p.K >= 2048)) return 36;
+        }
         // Split-tile schedule (cfg 35, gemm_sk_kernel): the 256 x 256 loop without tile quantisation.  Measured (profiles/r04_gemm_streamk.md):
         // every piece of a cut tile pays the ~8 us a whole tile pays outside its K loop, and three pieces per workgroup cost more than the
         // half-empty round they replace -- slower than the tile grids on every shape of the frames, so it is opt-in (uvl_tuning.gemm_sk = 1).
@@ -1168,7 +1178,7 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
     int cfg = pick_plain_cfg(p);
     if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 21)) && p.N % 128 != 0) cfg = 0;
     if (cfg >= 16 && cfg <= 21 && p.splitk > 1) cfg = 6;
-    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 35)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
+    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 36)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
 

@@ -1,0 +1,283 @@
+// bf16 MFMA GEMM, 128 x 256 tile on four waves, TWO workgroups per CU, the weight operand loaded straight into registers (cfg 36 of
+// gemm.hip's table).  Own translation unit: the other kernels are compiled with -amdgpu-mfma-vgpr-form=1 (accumulators in VGPRs); this
+// one keeps the 128 accumulators of a wave in AGPRs so that the K loop can own the 128 architectural VGPRs.
+#include <cstdio>
+#include <type_traits>
+#include "common.h"
+#include "kernels.h"
+#include "gemm_epi.h"
+
+namespace uvl {
+
+// ------------------------------------------------------------------------------------------------
+// What a batched GEMM of the frame pays OUTSIDE its K loop is a third of its time at K = 1024 (profiles/r04_gemm_streamk.md: ~10 us per
+// round of 256 x 256 tiles for the cold prologue, the LDS staging and the output burst; 15-30 us with the GELU / read-modify-write
+// epilogues), and the one-workgroup-per-CU kernels (cfg 30 / 31) run nothing under it.  Here two workgroups share a CU -- they drift
+// apart, and one's prologue / epilogue runs under the other's K loop -- without giving up the 128 x 64 wave tile:
+//   * 128 x 256 tile, wave w owns all 128 rows x columns [64 w, + 64): 8 x 4 blocks of v_mfma_f32_16x16x32_bf16, 128 AGPRs;
+//   * only A (shared by the four waves) goes through LDS: LDS-DMA, four stages of 16 KB; W fragments are loaded from global memory
+//     straight into the lane that feeds them to the MFMA, one K tile ahead (tools/gen/gemm_dr_gen.py: schedule, LDS image, register map);
+//   * 73 KB of LDS and 256 registers per wave: two workgroups per CU.
+// The K loop is ONE generated inline-asm statement (gemm_dr_asm.inc).  Transposed accumulation (W fragment = MFMA row operand) and the
+// epilogue arithmetic are those of gemm_pipe_tile / gemm_epilogue_lds.
+// ------------------------------------------------------------------------------------------------
+#define DR_R10(p, n) p #n "0", p #n "1", p #n "2", p #n "3", p #n "4", p #n "5", p #n "6", p #n "7", p #n "8", p #n "9"
+#define GEMM_DR_SGPRS DR_R10("s", 4), DR_R10("s", 5)        // (m0 is written too; hipcc refuses it in a clobber list and sets it again before its own uses)
+#define GEMM_DR_VGPRS "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", DR_R10("v", 1), DR_R10("v", 2), DR_R10("v", 3), DR_R10("v", 4), \
+    DR_R10("v", 5), DR_R10("v", 6), DR_R10("v", 7), DR_R10("v", 8), DR_R10("v", 9), DR_R10("v", 10), "v110", "v111", "v112", "v113"
+
+// Epilogue for the accumulator layout of the 16x16x32 MFMA: block (ib, jb) of the wave's 128 x 64 = accv[ib], registers 4 jb .. + 3: lane l
+// holds output row 16 ib + (l & 15), the four consecutive columns 16 jb + 4 (l >> 4) + r.  Same arithmetic, in the same order, as
+// gemm_epilogue_lds (bias, q scale, activation, rounding) and the same row-major write-out through LDS, 32 rows at a time, so that every
+// store instruction covers whole 128-byte lines; block i + 1 is converted and written to LDS before the rows of block i are read back.
+template <int EPI, int ACT>
+__device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&accv)[8], char* smem, const float* sbias, int m0, int n0,
+                                                 int lane, int wave) {
+    constexpr int WN = 64;
+    constexpr int ES = (EPI == EPI_F32) ? 4 : 2;               // output element size
+    constexpr int RS = WN * ES + 16;                            // padded LDS row stride
+    constexpr int LPR = WN * ES / 16;                           // lanes per row on the way out
+    constexpr int RPI = 64 / LPR;                               // rows per store instruction
+    constexpr int NSL = (EPI == EPI_F32) ? 2 : 4;               // 32-row slices per wave (4 waves x NSL x 32 rows x RS <= 72 KB)
+    const bool has_bias = p.bias != nullptr;
+    const int colw = n0 + wave * WN;                            // first column of this wave's sub-tile
+    const bool vpart = EPI == EPI_QKV && colw >= 2 * p.D;       // wave-uniform: D % 64 == 0
+    const float qs = (EPI == EPI_QKV && colw < p.D) ? p.q_scale : 1.0f;
+    const int l15 = lane & 15, g = lane >> 4;
+    f32x4 bv[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) bv[jb] = *reinterpret_cast<const f32x4*>(sbias + wave * WN + 16 * jb + 4 * g);
+    __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
+    if (vpart) {                                                // V^T is token-contiguous: stored straight from registers
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int rowl = m0 + ib * 16 + l15;
+            if (rowl < p.M) {
+                const int b = rowl / p.rpb, rem = rowl - b * p.rpb;
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int col = colw + 16 * jb + 4 * g;
+                    const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(accv[ib][4 * jb + e] + (has_bias ? bv[jb][e] : 0.f));
+                }
+            }
+        }
+        return;
+    }
+    char* cw0 = smem + wave * (NSL * 32 * RS);
+    auto to_lds = [&](int i) __attribute__((always_inline)) {       // rows [32 i, 32 i + 32) of the wave's block: registers -> slice i % NSL
+        char* cw = cw0 + (i % NSL) * (32 * RS);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ib = 2 * i + h;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int cl = 16 * jb + 4 * g;
+                const f32x16& a = accv[ib];
+                f32x4 v = {a[4 * jb], a[4 * jb + 1], a[4 * jb + 2], a[4 * jb + 3]};
+                if (has_bias) v += bv[jb];
+                if (EPI == EPI_QKV) v *= qs;
+                if (EPI == EPI_F32) {
+                    *reinterpret_cast<f32x4*>(cw + (16 * h + l15) * RS + cl * 4) = v;
+                } else {
+                    if (EPI == EPI_BF16 && ACT == 1) {
+                        const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                    } else if (EPI == EPI_BF16 && ACT == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    uint2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<uint2*>(cw + (16 * h + l15) * RS + cl * 2) = o;
+                }
+            }
+        }
+    };
+    // f32 outputs that accumulate (the residual stream) or add a table: the operands of a 32-row block are requested before the NEXT
+    // block is converted and staged, so their round trip runs under that work (one buffer: 128 architectural VGPRs per wave)
+    constexpr int NIT = 32 / RPI;
+    f32x4 ov[1][EPI == EPI_F32 ? NIT : 1], tv[1][EPI == EPI_F32 ? NIT : 1];
+    auto res_dst = [&](int i, int it, bool& inb) __attribute__((always_inline)) -> float* {
+        const int r = it * RPI + lane / LPR;
+        const int row = m0 + i * 32 + r;
+        inb = row < p.M;
+        const int rc = inb ? row : p.M - 1;
+        const int b = rc / p.rpb, rem = rc - b * p.rpb;
+        return reinterpret_cast<float*>(p.C) + ((size_t)b * p.obs + p.oro + rem) * p.ldc + colw + (lane % LPR) * 4;
+    };
+    auto load_res = [&](int i) __attribute__((always_inline)) {
+        if constexpr (EPI == EPI_F32) {
+            if (p.accumulate) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    bool inb;
+                    ov[0][it] = *reinterpret_cast<const f32x4*>(res_dst(i, it, inb));
+                }
+            }
+            if (p.addtab) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int r = it * RPI + lane / LPR, row = m0 + i * 32 + r;
+                    const int rc = row < p.M ? row : p.M - 1, rem = rc - (rc / p.rpb) * p.rpb;
+                    tv[0][it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + colw + (lane % LPR) * 4);
+                }
+            }
+        }
+    };
+    auto store_rows = [&](int i) __attribute__((always_inline)) {   // slice i % NSL -> global, row-major
+        const char* cw = cw0 + (i % NSL) * (32 * RS);
+        if constexpr (EPI == EPI_F32) {
+            const int c16 = lane % LPR;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                bool inb;
+                float* dst = res_dst(i, it, inb);
+                f32x4 v = *reinterpret_cast<const f32x4*>(cw + (it * RPI + lane / LPR) * RS + c16 * 16);
+                if (p.addtab) v += tv[0][it];
+                if (p.accumulate) v += ov[0][it];
+                if (inb) {
+                    if (p.c_store == 1) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                    else if (p.c_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                    else *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int r = it * RPI + lane / LPR, c16 = lane % LPR;
+                const int row = m0 + i * 32 + r;
+                const int col = colw + c16 * (16 / ES);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(cw + r * RS + c16 * 16);
+                if (row < p.M) {
+                    if (EPI == EPI_BF16) {
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col) = v;
+                    } else {
+                        const int b = row / p.rpb, rem = row - b * p.rpb;
+                        const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
+                        const int hh = cc >> 6, dd = cc & 63;
+                        *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;
+                    }
+                }
+            }
+        }
+    };
+    to_lds(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_res(i);
+        if (i < 3) to_lds(i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_rows(i);
+    }
+}
+
+// nn.Linear weight [N, K] bf16 -> the image the K loop loads from: for (16-row block nb, K tile kt, k step s) the 64 lanes' 16-byte fragments
+// in lane order; lane l = 16 g + r holds row 16 nb + r, bytes [128 kt + 16 (2 g + s), + 16) of that row (tools/gen/gemm_dr_gen.py)
+__global__ __launch_bounds__(256) void pack_w_dr_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ Wp, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // one 16-byte chunk of the source per thread
+    const int cpr = K / 8;                                          // chunks per row
+    if (i >= (size_t)N * cpr) return;
+    const int n = (int)(i / cpr), cc = (int)(i - (size_t)n * cpr);
+    const int kt = cc >> 3, c = cc & 7, g = c >> 1, s = c & 1, nb = n >> 4, r = n & 15, nk = K / 64;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(W + (size_t)n * K + (size_t)cc * 8);
+    *reinterpret_cast<u32x4*>(Wp + ((((size_t)nb * nk + kt) * 2 + s) * 64 + 16 * g + r) * 8) = v;
+}
+hipError_t launch_pack_w_dr(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s) {
+    if (N % 16 != 0 || K % 64 != 0) return hipErrorInvalidValue;
+    const size_t chunks = (size_t)N * (K / 8);
+    hipLaunchKernelGGL(pack_w_dr_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, W, Wp, N, K);
+    return hipGetLastError();
+}
+
+constexpr int DR_LDS_BIAS = 73728, DR_LDS_BYTES = DR_LDS_BIAS + 1024;       // A ring (4 x 16 KB) / epilogue slices (<= 72 KB), then the tile's bias row
+
+template <int EPI>
+__device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, char* smem) {
+    constexpr int BM = 128, BN = 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
+    int nt, mt;
+    {   // grouped tile order cut into 8 contiguous runs, one per XCD (see gemm_glds_body)
+        const int xcd = bx & 7, idx = bx >> 3;
+        const int T = MT * NT, base = T >> 3, rem = T & 7;
+        const int cnt = base + (xcd < rem ? 1 : 0);
+        if (idx >= cnt) return;
+        const int L = xcd * base + (xcd < rem ? xcd : rem) + idx;
+        const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
+        const int gm = min(p.group_m, MT - gi * p.group_m);
+        nt = within / gm;
+        mt = gi * p.group_m + (within - nt * gm);
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const int nk = p.K / 64;
+    const char* w_base = reinterpret_cast<const char*>(p.Wp + (size_t)(n0 >> 4) * nk * 1024);     // fragment-native image: 2 KB per (16-row block, K tile)
+
+    f32x16 accv[8];                                          // pinned to a[0:15] ... a[112:127] by the asm statement's constraints
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[t][r] = 0.f;
+
+    float* sbias = reinterpret_cast<float*>(smem + DR_LDS_BIAS);
+    if (wave == 0) *reinterpret_cast<f32x4*>(sbias + lane * 4) = *reinterpret_cast<const f32x4*>((p.bias ? p.bias + n0 : reinterpret_cast<const float*>(g_zero_page)) + lane * 4);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int lda2 = p.lda * 2, ldw2 = nk * 2048, rmax = min(BM, p.M - m0) - 1;      // rows past M re-read the last valid one (never stored)
+#if __HIP_DEVICE_COMPILE__              // the host pass of hipcc parses kernel bodies too and knows no gfx950 register names
+    asm volatile(
+#include "gemm_dr_asm.inc"
+        : "+{a[0:15]}"(accv[0]), "+{a[16:31]}"(accv[1]), "+{a[32:47]}"(accv[2]), "+{a[48:63]}"(accv[3]),
+          "+{a[64:79]}"(accv[4]), "+{a[80:95]}"(accv[5]), "+{a[96:111]}"(accv[6]), "+{a[112:127]}"(accv[7])
+        : [tid] "v"(tid), [ab] "s"(a_base), [wb] "s"(w_base), [lda2] "s"(lda2), [ldw2] "s"(ldw2), [rmax] "s"(rmax), [nk] "s"(nk), [lds] "s"(lds0), [wave] "s"(wave)
+        : "memory", "scc", GEMM_DR_SGPRS, GEMM_DR_VGPRS);
+#endif
+    if (EPI == EPI_BF16 && p.act == 1) gemm_epilogue_dr<EPI, 1>(p, accv, smem, sbias, m0, n0, lane, wave);
+    else if (EPI == EPI_BF16 && p.act == 2) gemm_epilogue_dr<EPI, 2>(p, accv, smem, sbias, m0, n0, lane, wave);
+    else gemm_epilogue_dr<EPI, 0>(p, accv, smem, sbias, m0, n0, lane, wave);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_dr_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_dr_body<EPI>(p, blockIdx.x, smem);
+}
+
+template <int EPI>
+static hipError_t launch_dr(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (!p.Wp || p.N % 256 != 0 || p.K < 64 || p.K % 64 != 0 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return hipErrorInvalidValue;
+    const int MT = (p.M + 127) / 128, NT = p.N / 256;
+    p.group_m = MT >= 16 ? 8 : MT;
+    const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
+    if (forced_gm > 0) p.group_m = forced_gm;
+    const int nblk = 8 * ((MT * NT + 7) / 8);
+    constexpr size_t lds = DR_LDS_BYTES;
+    auto kern = gemm_dr_kernel<EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[48];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_dr_kernel<%d>", EPI);
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_dr(const GemmParams& p, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BF16: return launch_dr<EPI_BF16>(p, s);
+        case EPI_F32: return launch_dr<EPI_F32>(p, s);
+        case EPI_QKV: return launch_dr<EPI_QKV>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace uvl

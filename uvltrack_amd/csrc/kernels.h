@@ -16,6 +16,7 @@ inline int tune_get(const uvl_tuning* t, int32_t uvl_tuning::*field, int dflt) {
 struct GemmParams {
     const bf16_t* A = nullptr; int lda = 0;      // [M,K] bf16 (plain) or NHWC activations (conv)
     const bf16_t* W = nullptr; int ldw = 0;      // [groups*N, K] bf16, K-contiguous
+    const bf16_t* Wp = nullptr;                  // optional: the same weight in the fragment-native layout of gemm_dr_kernel (launch_pack_w_dr)
     const float* bias = nullptr;                 // [groups*N] or null
     int M = 0, N = 0, K = 0;                     // per group
     int epi = 0;                                 // EPI_BF16 / EPI_F32 / EPI_QKV
@@ -86,6 +87,8 @@ hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream
 // one-sequence frames: LayerNorm(_pair) + the GEMM(_pair) that consumes it in one launch behind a grid barrier (gemm.hip); falls back to the
 // two launches where the fused form does not apply.  bar: 4 KB of zero-initialised device memory owned by the model, gen: 1, 2, 3, ..., *base: arrivals per group so far (updated)
 hipError_t launch_gemm_w4(const GemmParams& p, int epi, hipStream_t s);      // gemm_w4.hip: 256 x 256 on four waves (cfg 34)
+hipError_t launch_pack_w_dr(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);   // [N, K] -> fragment-native image (same size)
+hipError_t launch_gemm_dr(const GemmParams& p, int epi, hipStream_t s);      // gemm_dr.hip: 128 x 256 on four waves, two workgroups per CU, W straight into registers (cfg 36)
 hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const GemmParams& a, const GemmParams* b, unsigned* bar, unsigned gen, unsigned* base, bool* fused, hipStream_t s);   // two independent problems, one launch
 
 // set-up + BERT embedding + im2row of a single-stream frame in one launch (rowops.hip::prologue_kernel)

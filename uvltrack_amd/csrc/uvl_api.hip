@@ -44,6 +44,7 @@ struct RawTensor {
 struct VitBlockW {
     const float *ln1g, *ln1b, *ln2g, *ln2b, *bqkv, *bproj, *bfc1, *bfc2;
     bf16_t *wqkv, *wproj, *wfc1, *wfc2;
+    bf16_t *pqkv, *pproj, *pfc1, *pfc2;          // the same weights in the fragment-native layout of gemm_dr_kernel (null: frames of this handle never reach 2048 rows)
 };
 struct BertLayerW {
     const float *bao, *bi, *bo, *ln1g, *ln1b, *ln2g, *ln2b;
@@ -299,6 +300,15 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
         w.wproj = P.bf16(b + "attn.proj.weight", D * D); w.bproj = P.f32(b + "attn.proj.bias", D);
         w.wfc1 = P.bf16(b + "mlp.fc1.weight", Fn * D); w.bfc1 = P.f32(b + "mlp.fc1.bias", Fn);
         w.wfc2 = P.bf16(b + "mlp.fc2.weight", D * Fn); w.bfc2 = P.f32(b + "mlp.fc2.bias", D);
+        if ((long)m->cfg.max_batch * m->nj >= 2048) {          // many-sequence frames: second image of the weights for the direct-to-register GEMM
+            auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
+                bf16_t* dst = src ? P.alloc<bf16_t>((size_t)N_ * K_) : nullptr;
+                if (dst && launch_pack_w_dr(src, dst, N_, K_, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "weight packing launch failed");
+                return dst;
+            };
+            w.pqkv = pack(w.wqkv, 3 * (int)D, (int)D); w.pproj = pack(w.wproj, (int)D, (int)D);
+            w.pfc1 = pack(w.wfc1, (int)Fn, (int)D); w.pfc2 = pack(w.wfc2, (int)D, (int)Fn);
+        }
         m->vit.push_back(w);
     }
     const std::string e = "backbone.bert.embeddings.";
@@ -717,9 +727,9 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     auto consume = [](LnParams& p, Pending& pd) { p.part = pd.part; p.nsplit = pd.nsplit; p.part_rows = pd.rows; p.part_stride = pd.stride; pd = Pending(); };
     auto is_cont_layer = [&](int i) { bool c = false; for (int k = 0; k < m->cfg.n_cont; ++k) c |= (m->cfg.cont_layers[k] == i); return c; };
     auto residual_gemm = [&](hipStream_t st, const char* what, const bf16_t* A, int lda, const bf16_t* Wt, const float* bias, int Mr, int K,
-                             int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false) {
+                             int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false, const bf16_t* Wpk = nullptr) {
         GemmParams p;
-        p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
+        p.A = A; p.lda = lda; p.W = Wt; p.Wp = Wpk; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
         const int sk = allow_split ? choose_splitk(Mr, D, K, &m->tune) : 1;
         if (sk > 1) {             // slabs [sk][Mr, D], folded in by the next LayerNorm / contrast kernel
             p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D; p.c_store = tune_get(&m->tune, &uvl_tuning::slab_store, 2);   // write-through slabs: +1 % at one sequence (both A/B orders)
@@ -834,7 +844,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         }
         {
             GemmParams p;
-            p.A = w.Xn; p.lda = D; p.W = vw.wqkv; p.ldw = D; p.bias = vw.bqkv; p.M = M; p.N = 3 * D; p.K = D;
+            p.A = w.Xn; p.lda = D; p.W = vw.wqkv; p.Wp = vw.pqkv; p.ldw = D; p.bias = vw.bqkv; p.M = M; p.N = 3 * D; p.K = D;
             p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D; p.q_scale = UVL_QSCALE;
             run_gemm(s, p, "gemm.qkv", false);
         }
@@ -843,7 +853,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad; p.q_prescaled = 1;
             run_attn(s, p, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, false);
         }
-        residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true);
+        residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true, false, vw.pproj);
         {
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
@@ -864,11 +874,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         }
         {
             GemmParams p;
-            p.A = w.Xn; p.lda = D; p.W = vw.wfc1; p.ldw = D; p.bias = vw.bfc1; p.M = M; p.N = Fn; p.K = D;
+            p.A = w.Xn; p.lda = D; p.W = vw.wfc1; p.Wp = vw.pfc1; p.ldw = D; p.bias = vw.bfc1; p.M = M; p.N = Fn; p.K = D;
             p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
             run_gemm(s, p, "gemm.fc1", false);
         }
-        residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last);
+        residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last, false, vw.pfc2);
         if (i <= last_bert && !paired) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
         if (is_cont_layer(i)) {
@@ -1000,7 +1010,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
     static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
         {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
-        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_w4", &uvl_tuning::gemm_w4}, {"gemm_sk", &uvl_tuning::gemm_sk}};
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_w4", &uvl_tuning::gemm_w4}, {"gemm_sk", &uvl_tuning::gemm_sk}, {"gemm_dr", &uvl_tuning::gemm_dr}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) { m->tune.*(k.field) = value < 0 ? -1 : value; return UVL_OK; }
     if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
@@ -1224,7 +1234,12 @@ extern "C" int uvl_normalize_u8(const uint8_t* d_patch_hwc, int height, int widt
 }
 
 // ---- per-kernel entry points -----------------------------------------------------------------------
-extern "C" int uvl_linear_ws(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
+extern "C" int uvl_pack_weight(const void* d_w, void* d_w_packed, int N, int K, void* stream) {
+    if (!d_w || !d_w_packed || N <= 0 || N % 16 != 0 || K <= 0 || K % 64 != 0) return fail(UVL_EINVAL, "uvl_pack_weight: need N %% 16 == 0 and K %% 64 == 0");
+    HIPCHK(launch_pack_w_dr((const bf16_t*)d_w, (bf16_t*)d_w_packed, N, K, (hipStream_t)stream));
+    return UVL_OK;
+}
+extern "C" int uvl_linear_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
                              int accumulate, const uvl_tuning* tune, void* d_scratch, size_t scratch_bytes, void* stream) {
     if (!d_x || !d_w || !d_y || M <= 0 || N % 32 != 0 || K % 64 != 0) return fail(UVL_EINVAL, "uvl_linear: need N %% 32 == 0 and K %% 64 == 0");
     if (d_scratch && (scratch_bytes < uvl_gemm_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
@@ -1232,13 +1247,14 @@ extern "C" int uvl_linear_ws(const void* d_x, const void* d_w, const float* d_bi
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
     p.epi = out_f32 ? 1 : 0; p.C = d_y; p.ldc = N; p.act = act; p.accumulate = accumulate; p.tune = tune;
+    p.Wp = (const bf16_t*)d_w_packed;
     set_gemm_scratch(p, d_scratch, scratch_bytes);
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
 extern "C" int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
                           int accumulate, const uvl_tuning* tune, void* stream) {
-    return uvl_linear_ws(d_x, d_w, d_bias, d_y, M, N, K, act, out_f32, accumulate, tune, nullptr, 0, stream);
+    return uvl_linear_ws(d_x, d_w, nullptr, d_bias, d_y, M, N, K, act, out_f32, accumulate, tune, nullptr, 0, stream);
 }
 
 /* tuning entry: y[sk] (f32 slabs [splitk][M,N]) = partial sums over K-range sk (bias in slab 0) */
@@ -1282,7 +1298,7 @@ extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt,
     return UVL_OK;
 }
 
-extern "C" int uvl_qkv_project_ws(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
+extern "C" int uvl_qkv_project_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
                                   const uvl_tuning* tune, void* d_scratch, size_t scratch_bytes, void* stream) {
     if (!d_x || !d_w || !d_q || !d_k || !d_vt || D % 64 != 0) return fail(UVL_EINVAL, "uvl_qkv_project: bad argument");
     if (d_scratch && (scratch_bytes < uvl_gemm_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
@@ -1290,13 +1306,14 @@ extern "C" int uvl_qkv_project_ws(const void* d_x, const void* d_w, const float*
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = D; p.W = (const bf16_t*)d_w; p.ldw = D; p.bias = d_bias; p.M = B * N; p.N = 3 * D; p.K = D;
     p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale; p.tune = tune;
+    p.Wp = (const bf16_t*)d_w_packed;
     set_gemm_scratch(p, d_scratch, scratch_bytes);
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
 extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
                                const uvl_tuning* tune, void* stream) {
-    return uvl_qkv_project_ws(d_x, d_w, d_bias, d_q, d_k, d_vt, B, N, Npad, D, q_scale, tune, nullptr, 0, stream);
+    return uvl_qkv_project_ws(d_x, d_w, nullptr, d_bias, d_q, d_k, d_vt, B, N, Npad, D, q_scale, tune, nullptr, 0, stream);
 }
 
 extern "C" int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps, void* d_y_bf16, float* d_y_f32, int M, int D, void* stream) {
