@@ -162,8 +162,11 @@ class Gen:
             self.need_lds(("a", 0, ib))
             for jb in range(4):
                 self.mfma(p, 0, ib, jb)
-                if jb == 1 and ib % 2 == 0:                                # W(t + 1), block ib // 2: both k steps back to back -- they are the
-                    self.w_load(1 - p, 0, ib // 2, "w")                    # two halves of the same sixteen 128-byte lines
+                if "wearly" in self.abl:                                   # variant: the eight W loads behind the first eight MFMAs
+                    if ib < 2:
+                        self.w_load(1 - p, (4 * ib + jb) // 4, (4 * ib + jb) % 4, "w")
+                elif jb == 1 and ib % 2 == 0:                              # W(t + 1), block ib // 2, both k steps (2 x 1 KB of consecutive addresses)
+                    self.w_load(1 - p, 0, ib // 2, "w")
                     self.w_load(1 - p, 1, ib // 2, "w")
                 if jb == 3:
                     self.a_read(ib, 1, st, ("a", 1, ib))                   # A(t, k step 1, ib) into the slot the four MFMAs above have read
@@ -256,6 +259,8 @@ class Gen:
     def generate(self):
         self.prologue()
         self.in_loop = True
+        if "prio" in self.abl:
+            self.e("s_setprio 1")
         self.e("top_%=:")
         start, vstart = list(self.ldsq), list(self.vmq)
         for u in range(NSTG):
@@ -265,6 +270,8 @@ class Gen:
             self.e("s_cbranch_scc1 done_%=" if u < NSTG - 1 else "s_cbranch_scc0 top_%=")
             assert self.abl or (start == self.ldsq and vstart == self.vmq), (u, start, self.ldsq, vstart, self.vmq)
         self.e("done_%=:")
+        if "prio" in self.abl:
+            self.e("s_setprio 0")
         # nothing of the block may be in flight when the compiler's code resumes: LDS-DMA, fragment reads, MFMAs
         self.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         self.e("s_nop 15")

@@ -49,16 +49,21 @@ def main():
             lib.uvl_pack_weight(p(w), p(wp), N, K, st)
             y = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
             flops = 2.0 * M * N * K
-            row = []
             forms = (("auto", {}), ("nosk", dict(gemm_sk=0)), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("sk", dict(gemm_cfg=35, gemm_sk=1)), ("dr", dict(gemm_cfg=36)))
             if os.environ.get("SK_ONLY"):
                 forms = [f for f in forms if f[0] in os.environ["SK_ONLY"].split(",")]
+            cases = []
             for label, kw in forms:
                 t = _native.UvlTuning(**kw)
                 for ep_label, a_, f_, acc_ in (("bias", 0, 0, 0), ("frame", act, f32, f32)):
                     yy = y if f_ == f32 else torch.zeros(M, N, device="cuda", dtype=torch.float32 if f_ else torch.bfloat16)
-                    us = timeit(lambda: lib.uvl_linear_ws(p(x), p(w), p(wp), p(bias), p(yy), M, N, K, a_, f_, acc_, t.ref(), p(scratch), nb, st))
-                    row.append("%s/%s %.1f" % (label, ep_label, us))
+                    cases.append(("%s/%s" % (label, ep_label), (lambda t=t, yy=yy, a_=a_, f_=f_, acc_=acc_: lib.uvl_linear_ws(p(x), p(w), p(wp), p(bias), p(yy), M, N, K, a_, f_, acc_, t.ref(), p(scratch), nb, st))))
+            # three interleaved rounds, median: the order of the cases and the clock the part grants do not favour one of them
+            res = {c[0]: [] for c in cases}
+            for _ in range(3):
+                for name_, fn in cases:
+                    res[name_].append(timeit(fn, 25))
+            row = ["%s %.1f" % (k, sorted(v)[1]) for k, v in res.items()]
             bb = bias.bfloat16()
             ven = timeit(lambda: F.linear(x, w, bb))
             print("%-4s M=%5d N=%4d K=%4d | %s | hipBLASLt(bias) %.1f us %.0f TF" % (name, M, N, K, "  ".join(row), ven, flops / ven / 1e6), flush=True)

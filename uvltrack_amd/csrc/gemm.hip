@@ -1141,11 +1141,15 @@ static int pick_plain_cfg(const GemmParams& p) {
         // The direct-to-register form (cfg 36, gemm_dr.hip: 128 x 256 tiles on four waves, TWO workgroups per CU, W fragments loaded straight
         // into registers from the fragment-native weight image): what a tile pays outside its K loop runs under the other workgroup's loop.
         // Measured beside cfg 30 / 31 and hipBLASLt (profiles/r04_gemm_dr.md): ahead of both with the bias / GELU / QKV epilogues on every
-        // shape of 8 sequences; with the f32 read-modify-write epilogue only behind a long K loop (a 220-tile launch is ONE round: its
-        // 57 MB burst overlaps nothing, and the eight-wave 128 x 256 kernel hides more of it).  uvl_tuning.gemm_dr: 0 = never, 1 = wherever it applies.
+        // shape of 8 sequences; with the f32 read-modify-write epilogue where the launch has several rounds or a long K loop.
+        // uvl_tuning.gemm_dr: 0 = never, 1 = wherever it applies.
         {
             const int want = tune_get(p.tune, &uvl_tuning::gemm_dr, -1);
-            if (want != 0 && p.Wp && p.K % 64 == 0 && (want == 1 || p.epi != EPI_F32 || p.K >= 2048)) return 36;
+            // f32 read-modify-write epilogue: a launch of fewer than ~400 tiles is a single round (two slots per CU): its 2 x 28 MB burst runs
+            // under nothing, and the eight-wave kernel hides more of it (tools/dr_sweep.py shapes: proj of 8 UVLTrack-L sequences 28.3 against
+            // 25.0 us, of 16 sequences 41.6 against 44.9, of 32 64.2 against 71.0)
+            const long t128 = (long)((p.M + 127) / 128) * (p.N / 256);
+            if (want != 0 && p.Wp && p.K % 64 == 0 && (want == 1 || p.epi != EPI_F32 || t128 >= 400 || (p.K >= 2048 && t128 >= 200))) return 36;
         }
         // Split-tile schedule (cfg 35, gemm_sk_kernel): the 256 x 256 loop without tile quantisation.  Measured (profiles/r04_gemm_streamk.md):
         // every piece of a cut tile pays the ~8 us a whole tile pays outside its K loop, and three pieces per workgroup cost more than the

@@ -83,7 +83,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     *reinterpret_cast<f32x4*>(cw + rl * RS + cl * 4) = v;
                 } else {
                     if (EPI == EPI_BF16 && p.act == 1) {
-                        const f32x2 g0 = gelu_erf_fast2(f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(f32x2{v[2], v[3]});
+                        const f32x2 g0 = gelu_erf_poly2(f32x2{v[0], v[1]}), g1 = gelu_erf_poly2(f32x2{v[2], v[3]});
                         v = f32x4{g0[0], g0[1], g1[0], g1[1]};
                     } else if (EPI == EPI_BF16 && p.act == 2) {
 #pragma unroll
