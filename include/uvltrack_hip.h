@@ -245,7 +245,7 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   gemm_sk    1 = split-tile ("stream-K") schedule of the 256 x 256 pipelined GEMM (gemm.hip::gemm_sk_kernel) wherever it applies (needs the
  *              scratch of uvl_linear_ws); 2 = also whole rounds on persistent workgroups (a timing aid).  Default 0: measured slower than the tile grids
  *   gemm_dr    the direct-to-register GEMM (cfg 36, gemm_dr.hip; needs the packed weight image): 0 = never, 1 = wherever it applies,
- *              default = frames of >= 2048 rows except the f32 read-modify-write epilogue behind a short K loop
+ *              default = frames of >= 2048 rows, bf16-type epilogues (bias / GELU / QKV scatter); the f32 read-modify-write epilogue stays with cfg 30 / 31
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
     int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_w4, gemm_sk, gemm_dr;

@@ -1141,15 +1141,14 @@ static int pick_plain_cfg(const GemmParams& p) {
         // The direct-to-register form (cfg 36, gemm_dr.hip: 128 x 256 tiles on four waves, TWO workgroups per CU, W fragments loaded straight
         // into registers from the fragment-native weight image): what a tile pays outside its K loop runs under the other workgroup's loop.
         // Measured beside cfg 30 / 31 and hipBLASLt (profiles/r04_gemm_dr.md): ahead of both with the bias / GELU / QKV epilogues on every
-        // shape of 8 sequences; with the f32 read-modify-write epilogue where the launch has several rounds or a long K loop.
-        // uvl_tuning.gemm_dr: 0 = never, 1 = wherever it applies.
+        // shape of 8 sequences.  uvl_tuning.gemm_dr: 0 = never, 1 = wherever it applies (the f32 epilogue too).
         {
             const int want = tune_get(p.tune, &uvl_tuning::gemm_dr, -1);
-            // f32 read-modify-write epilogue: a launch of fewer than ~400 tiles is a single round (two slots per CU): its 2 x 28 MB burst runs
-            // under nothing, and the eight-wave kernel hides more of it (tools/dr_sweep.py shapes: proj of 8 UVLTrack-L sequences 28.3 against
-            // 25.0 us, of 16 sequences 41.6 against 44.9, of 32 64.2 against 71.0)
-            const long t128 = (long)((p.M + 127) / 128) * (p.N / 256);
-            if (want != 0 && p.Wp && p.K % 64 == 0 && (want == 1 || p.epi != EPI_F32 || t128 >= 400 || (p.K >= 2048 && t128 >= 200))) return 36;
+            // The f32 read-modify-write epilogue stays with the eight-wave kernels: in isolation cfg 36 wins it from ~400 tiles on (proj of 16 /
+            // 32 UVLTrack-L sequences 41.6 / 64.2 against 44.9 / 71.0 us; 8 sequences = 220 tiles = a single round: 28.3 against 25.0), but in
+            // the frames it loses (interleaved tools/ab_tune.py gemm_dr 2 -1: UVLTrack-L x 8 1156-1157 against 1136-1138 frames/s, UVLTrack-B x 32
+            // 6150-6172 against 6111-6131): 2 x 28 MB of residual traffic per launch, and two workgroups per CU issue it at the same moment.
+            if (want != 0 && p.Wp && p.K % 64 == 0 && (want == 1 || p.epi != EPI_F32)) return 36;
         }
         // Split-tile schedule (cfg 35, gemm_sk_kernel): the 256 x 256 loop without tile quantisation.  Measured (profiles/r04_gemm_streamk.md):
         // every piece of a cut tile pays the ~8 us a whole tile pays outside its K loop, and three pieces per workgroup cost more than the
