@@ -5,6 +5,8 @@ import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uvltrack_amd import _native
+if "--lib" in sys.argv:
+    i = sys.argv.index("--lib"); _native.LIB_PATH = os.path.abspath(sys.argv[i + 1]); del sys.argv[i:i + 2]
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
