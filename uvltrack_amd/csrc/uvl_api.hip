@@ -50,6 +50,7 @@ struct BertLayerW {
     const float *bao, *bi, *bo, *ln1g, *ln1b, *ln2g, *ln2b;
     float* bqkv;
     bf16_t *wqkv, *wao, *wi, *wo;
+    bf16_t *pqkv, *pao, *pi, *po;                // fragment-native images for gemm_dr_kernel (null: see VitBlockW)
 };
 struct ConvLayerW {
     bf16_t* w;      // [4][Cout][9*Cin]
@@ -332,6 +333,15 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
         w.wi = P.bf16(b + "intermediate.dense.weight", Fn * D); w.bi = P.f32(b + "intermediate.dense.bias", Fn);
         w.wo = P.bf16(b + "output.dense.weight", D * Fn); w.bo = P.f32(b + "output.dense.bias", D);
         w.ln2g = P.f32(b + "output.LayerNorm.weight", D); w.ln2b = P.f32(b + "output.LayerNorm.bias", D);
+        if ((long)m->cfg.max_batch * m->nj >= 2048) {          // the text branch of many-sequence frames runs on gemm_dr_kernel too (see run_gemm)
+            auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
+                bf16_t* dst = src ? P.alloc<bf16_t>((size_t)N_ * K_) : nullptr;
+                if (dst && launch_pack_w_dr(src, dst, N_, K_, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "weight packing launch failed");
+                return dst;
+            };
+            w.pqkv = pack(w.wqkv, 3 * (int)D, (int)D); w.pao = pack(w.wao, (int)D, (int)D);
+            w.pi = pack(w.wi, (int)Fn, (int)D); w.po = pack(w.wo, (int)D, (int)Fn);
+        }
         m->bert.push_back(w);
     }
     // head: fold BN into the conv towers, tower-major packing
@@ -594,6 +604,14 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // costs neither launches nor a second queue; measured, the two-stream form slows each visual layer by ~11 us through
     // contention and ends level with visual layer nf-1 (profiles/r01_summary.md).  Larger batches keep the second stream.
     const bool paired = !skip && !reuse && m->nf > 0 && m->pair_text && B == 1;
+    // The text branch of a many-sequence frame (B x T rows: 320 at 8 sequences) overlaps the visual layers on the second stream, and what it
+    // costs the frame is the CU time of its workgroups: as 64 x 64 tiles (240 workgroups of ~6 us per GEMM at ~15 % MFMA efficiency) that was
+    // 8 % of the UVLTrack-L x 8 frame (1241 against 1351 frames/s without the branch).  On gemm_dr_kernel's 128 x 256 tiles the same GEMM is
+    // 36 workgroups of ~10 us: a seventh of the CU time -- worth +0.7 % on that frame and +1.9 % on 32 UVLTrack-B sequences, and it LOSES where
+    // the longer text kernels reach the critical path (8 UVLTrack-B sequences -3.4 %, 4: -17 %), so only frames of >= 6000 visual rows take it.
+    // The rest of the branch's cost is not CU time (profiles/r04_text_branch.md).  In-place residual epilogue (no split-K slabs).
+    // uvl_tuning.text_cfg >= 0 overrides the tile configuration as before; gemm_dr = 0 switches this off.
+    const bool text_dr = !paired && (long)B * m->nv >= 6000 && m->tune.text_cfg < 0 && tune_get(&m->tune, &uvl_tuning::gemm_dr, -1) != 0 && !m->bert.empty() && m->bert[0].pqkv;
     const bool fork = !skip && !reuse && !prof && m->nf > 0 && parts == PART_ALL && !paired && m->fork_text;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
     enum { R_GEMM = 0, R_ATTN = 1, R_LN = 2 };
@@ -626,6 +644,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     auto run_gemm = [&](hipStream_t st, GemmParams& p, const char* what, bool is_text) {
         p.tune = &m->tune;
         if (is_text && !paired && m->tune.text_cfg >= 0) { m->tune_text = m->tune; m->tune_text.gemm_cfg = m->tune.text_cfg; p.tune = &m->tune_text; }
+        else if (is_text && text_dr && p.Wp) { m->tune_text = m->tune; m->tune_text.gemm_cfg = 36; p.tune = &m->tune_text; }
         // BERT weights are read once per frame: up to four sequences (<= 3 M tiles share a weight tile through L2) they are loaded
         // non-temporal so that they do not displace the ViT weights from the Infinity Cache (+2-3 % at 2-4 sequences, -0.5 % from 8 on)
         if (is_text && p.M <= 192) p.w_stream = 1;
@@ -762,7 +781,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             const int Mt = B * T;
             {
                 GemmParams p;
-                p.A = w.Tn; p.lda = D; p.W = bw.wqkv; p.ldw = D; p.bias = bw.bqkv; p.M = Mt; p.N = 3 * D; p.K = D;
+                p.A = w.Tn; p.lda = D; p.W = bw.wqkv; p.Wp = bw.pqkv; p.ldw = D; p.bias = bw.bqkv; p.M = Mt; p.N = 3 * D; p.K = D;
                 p.epi = 2; p.rpb = T; p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.H = H; p.Npad = 64; p.D = D; p.q_scale = UVL_QSCALE;
                 run_gemm(sa, p, "gemm.bert_qkv", true);
             }
@@ -771,7 +790,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64; p.q_prescaled = 1;
                 run_attn(sa, p, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, true);
             }
-            residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, true, true);
+            residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, !text_dr, true, bw.pao);
             {
                 LnParams p;        // post-LN in place on the text rows
                 p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
@@ -781,11 +800,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             }
             {
                 GemmParams p;
-                p.A = w.Tn; p.lda = D; p.W = bw.wi; p.ldw = D; p.bias = bw.bi; p.M = Mt; p.N = Fn; p.K = D;
+                p.A = w.Tn; p.lda = D; p.W = bw.wi; p.Wp = bw.pi; p.ldw = D; p.bias = bw.bi; p.M = Mt; p.N = Fn; p.K = D;
                 p.epi = 0; p.C = w.Th; p.ldc = Fn; p.act = 1;
                 run_gemm(sa, p, "gemm.bert_i", true);
             }
-            residual_gemm(sa, "gemm.bert_o", w.Th, Fn, bw.wo, bw.bo, Mt, Fn, T, nv, w.PartT, pend_t, true, true);
+            residual_gemm(sa, "gemm.bert_o", w.Th, Fn, bw.wo, bw.bo, Mt, Fn, T, nv, w.PartT, pend_t, !text_dr, true, bw.po);
             {
                 LnParams p;
                 p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
