@@ -235,20 +235,16 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   attn_cfg   index into the attention configuration table (attention.hip::launch_attention)
  *   sk_k1 / sk_k4  split-K factor of the frame's residual GEMMs with K = D / K = 4 D
  *   gemm_pipe  0 = never pick the phase-pipelined 256-wide GEMM (default: batched frames, see gemm.hip::pick_plain_cfg)
- *   gemm_w4    1 = pick the four-wave 256 x 256 GEMM with the generated K loop (cfg 34, gemm_w4.hip) where cfg 30 would do, for bf16-type
- *              epilogues from 8192 rows (default 0: cfg 30 with the same MFMA is faster in the frames)
  *   ring1      ring depth (3..5 stages of 16 KB) of the 64x64 tile that one-sequence frames use (default 4)
  *   res_store  cache policy of the in-place f32 residual stores (x += ...) of the GEMM epilogue: 0 plain, 1 non-temporal, 2 write-through (default)
  *   slab_store the same for the split-K f32 slabs of one-sequence frames (default 2)
  *   text_cfg   tile configuration (as gemm_cfg) of the text-branch GEMMs of multi-sequence frames, which run on the second stream
  *   attn_wgs   persistent workgroups of the hand-scheduled attention kernel (attention.hip::launch_attn_p64; default 512 = two per CU)
- *   gemm_sk    1 = split-tile ("stream-K") schedule of the 256 x 256 pipelined GEMM (gemm.hip::gemm_sk_kernel) wherever it applies (needs the
- *              scratch of uvl_linear_ws); 2 = also whole rounds on persistent workgroups (a timing aid).  Default 0: measured slower than the tile grids
  *   gemm_dr    the direct-to-register GEMM (cfg 36, gemm_dr.hip; needs the packed weight image): 0 = never, 1 = wherever it applies,
  *              default = frames of >= 2048 rows, bf16-type epilogues (bias / GELU / QKV scatter); the f32 read-modify-write epilogue stays with cfg 30 / 31
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
-    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_w4, gemm_sk, gemm_dr;
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_dr;
 } uvl_tuning;
 void uvl_tuning_init(uvl_tuning* t);
 int uvl_tune_set(uvl_model_t* m, const char* key, int value);
@@ -265,20 +261,13 @@ int uvl_linear_splitk(const void* d_x, const void* d_w, const float* d_bias, flo
 int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
                int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune, void* stream);
 
-/* The same with the two optional resources of the many-sequence GEMM kernels (`_ws`: with scratch / packed weights):
- *   d_w_packed  the weight once more in the fragment-native layout of gemm_dr_kernel (cfg 36: 128 x 256 tiles, two workgroups per CU, the
- *               weight fragments loaded straight into registers), made by uvl_pack_weight (N % 16 == 0, K % 64 == 0; same size as d_w).
- *               NULL = that kernel is not available for this call.  A model handle packs its ViT weights at uvl_finalize_weights when
- *               max_batch allows frames of >= 2048 rows.
- *   d_scratch   scratch of the split-tile ("stream-K") schedule (cfg 35): the output tiles that do not fill a whole round of the CUs are
- *               cut along K and the pieces of a tile meet through f32 slabs here (fixed summation order, no atomics).
- *               uvl_gemm_scratch_bytes() bytes, 256-byte aligned, ZERO-FILLED ONCE by the caller (the kernels leave its flags zero
- *               again); one GEMM at a time per scratch.  NULL = tile grids only. */
-size_t uvl_gemm_scratch_bytes(void);
+/* The same with the weight given once more in the fragment-native layout of gemm_dr_kernel (cfg 36: 128 x 256 tiles, two workgroups per
+ * CU, the weight fragments loaded straight into registers): d_w_packed = output of uvl_pack_weight (N % 16 == 0, K % 64 == 0; same size as
+ * d_w); NULL = that kernel is not available for this call.  A model handle packs its own weights at uvl_finalize_weights when max_batch
+ * allows frames of >= 2048 rows. */
 int uvl_pack_weight(const void* d_w, void* d_w_packed, int N, int K, void* stream);
-int uvl_linear_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y,
-                  int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune,
-                  void* d_scratch, size_t scratch_bytes, void* stream);
+int uvl_linear_pk(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y,
+                  int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune, void* stream);
 
 /* Fused multi-head self-attention core of Attention.forward (block.py:50-58) and BertSelfAttention
  * (bert_backbone.py:311-324): softmax(q k^T / sqrt(64) + key_add) v.
@@ -296,9 +285,8 @@ int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const floa
  * q_scale before it is rounded (1.0f = the plain projection). */
 int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt,
                     int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune, void* stream);
-int uvl_qkv_project_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_q, void* d_k, void* d_vt,
-                       int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune,
-                       void* d_scratch, size_t scratch_bytes, void* stream);     /* d_w_packed, scratch: see uvl_linear_ws */
+int uvl_qkv_project_pk(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_q, void* d_k, void* d_vt,
+                       int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune, void* stream);     /* d_w_packed: see uvl_linear_pk */
 
 /* One layer of the box head's four 3x3 conv towers, conv(3x3, pad 1) + BatchNorm2d(eval) + ReLU (heads/utils.py:126-131;
  * towers of modality_adaptive_box_head.py:28-50), as the frame runs it: BatchNorm folded into bf16 weights, the four towers as

@@ -50,25 +50,26 @@ def test_register_map_stays_inside_the_clobber_list():
     assert min(used_s) >= 38 and max(used_s) <= 101          # attention.hip: ATTN_P64_SGPRS = s38..s101
 
 
-# ---- the K loop of gemm_w4_kernel (uvltrack_amd/csrc/gemm_w4_asm.inc, tools/gen/gemm_w4_gen.py)
-def _gen_w4():
-    spec = importlib.util.spec_from_file_location("gemm_w4_gen", os.path.join(ROOT, "tools", "gen", "gemm_w4_gen.py"))
+# ---- the K loop of gemm_dr_kernel (uvltrack_amd/csrc/gemm_dr_asm.inc, tools/gen/gemm_dr_gen.py)
+def _gen_dr():
+    spec = importlib.util.spec_from_file_location("gemm_dr_gen", os.path.join(ROOT, "tools", "gen", "gemm_dr_gen.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
 
 
 def test_committed_gemm_loop_is_the_generators_output():
-    g = _gen_w4()
-    assert open(os.path.join(ROOT, "uvltrack_amd", "csrc", "gemm_w4_asm.inc")).read() == g.render()
+    g = _gen_dr()
+    assert open(os.path.join(ROOT, "uvltrack_amd", "csrc", "gemm_dr_asm.inc")).read() == g.render()
 
 
 def test_gemm_loop_register_map_and_counts():
-    """Every register the block names is in gemm_w4.hip's clobber list (v0..v161, s40..s59) or an accumulator operand (a0..a255, each
-    written by exactly the MFMAs of its block); per K tile and wave: 128 MFMAs, 32 fragment reads, 16 LDS-DMA instructions, one barrier;
-    the wave index is NOT read back from a VALU-written SGPR (the hazard that cost a morning)."""
+    """Every register the block names is in gemm_dr.hip's clobber list (v0..v113, s40..s59) or an accumulator operand (a0..a127, each
+    written by exactly the MFMAs of its block); per K tile and wave: 64 MFMAs, 16 fragment reads, 8 W loads, 4 LDS-DMA instructions, one
+    barrier; the wave index is NOT read back from a VALU-written SGPR; an M0 write and the LDS-DMA that uses it are never adjacent; the loop's
+    vector-memory waits leave exactly the four youngest LDS-DMA pieces in flight."""
     import re
-    g = _gen_w4()
+    g = _gen_dr()
     lines = g.Gen().generate()
     used_v, used_s, used_a = set(), set(), set()
     for ln in lines:
@@ -80,16 +81,19 @@ def test_gemm_loop_register_map_and_counts():
         used_s.update(int(x) for x in re.findall(r"\bs(\d+)\b", ln))
         for a, b in re.findall(r"\ba\[(\d+):(\d+)\]", ln):
             used_a.update(range(int(a), int(b) + 1))
-    assert max(used_v) < g.NV == 162
+    assert max(used_v) < g.NV == 114
     assert min(used_s) >= 40 and max(used_s) <= 59
-    assert used_a == set(range(256))
+    assert used_a == set(range(128))
+    src = open(os.path.join(ROOT, "uvltrack_amd", "csrc", "gemm_dr.hip")).read()
+    assert '"v113"' in src and '"v114"' not in src                      # the clobber list ends where the register map ends
     top = lines.index("top_%=:")
     loop = lines[top:]
-    assert sum("v_mfma_f32_16x16x32_bf16" in ln for ln in loop) == 2 * 128
-    assert sum(ln.startswith("ds_read_b128") for ln in loop) == 2 * 32
-    assert sum(ln.startswith("global_load_lds_dwordx4") for ln in loop) == 2 * 16
-    assert sum(ln == "s_barrier" for ln in loop) == 2
+    assert sum("v_mfma_f32_16x16x32_bf16" in ln for ln in loop) == 4 * 64
+    assert sum(ln.startswith("ds_read_b128") for ln in loop) == 4 * 16
+    assert sum(ln.startswith("global_load_dwordx4") for ln in loop) == 4 * 8
+    assert sum(ln.startswith("global_load_lds_dwordx4") for ln in loop) == 4 * 4
+    assert sum(ln == "s_barrier" for ln in loop) == 4
+    assert [ln for ln in loop if ln.startswith("s_waitcnt vmcnt")][:4] == ["s_waitcnt vmcnt(4)"] * 4
     assert not any("v_readfirstlane" in ln for ln in lines)
-    # an M0 write and the LDS-DMA that uses it are never adjacent without an instruction in between
     for a, b in zip(lines, lines[1:]):
         assert not (a.startswith("s_add_u32 m0") and b.startswith("global_load_lds")), (a, b)

@@ -145,14 +145,13 @@ def test_attention_token_counts(lib, N):
     _attention_case(lib, 1, 2, N, "fill", 10 + N)
 
 
-@pytest.mark.parametrize("cfg", [6, 11, 16, 17, 20, 21, 30, 31, 32, 33, 34])
+@pytest.mark.parametrize("cfg", [6, 11, 16, 17, 20, 21, 30, 31, 32, 33])
 @pytest.mark.parametrize("M,N,K,act", [(777, 512, 192, 0), (300, 256, 64, 1), (6200, 3072, 768, 1), (1000, 256, 128, 0), (513, 768, 448, 2)])
 def test_linear_tile_forms_forced(lib, cfg, M, N, K, act):
     """The tile / ring / wave-role forms of the batched GEMM on shapes the heuristic would not give them: 128x128 and 256x256 tiles,
     32-wide K stages with 4 / 5 ring stages (cfg 16 / 17), the producer-wave form (cfg 20 / 21: 2 / 4 extra waves issue every
     LDS-DMA instruction, the four consumer waves only read fragments and issue MFMAs) and the phase-pipelined 256-wide tiles (cfg 30 /
-    31: gemm_pipe_body, two wave groups half a phase apart; K = 64 falls back to the plain loop) and the four-wave 256x256 tile whose K
-    loop is generated assembly (cfg 34: gemm_w4_kernel, 16x16x32 MFMAs, an odd and an even number of K tiles) -- ragged M, one / two /
+    31: gemm_pipe_body, two wave groups half a phase apart; K = 64 falls back to the plain loop) -- ragged M, one / two /
     three / seven K steps, a long K loop, GELU / ReLU / no activation."""
     x = _rand((M, K), 1).bfloat16()
     w = (_rand((N, K), 2, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
@@ -185,7 +184,7 @@ def test_linear_direct_to_register_form(lib, M, N, K, mode):
     if mode in ("bf16", "gelu", "relu"):
         act = {"bf16": 0, "gelu": 1, "relu": 2}[mode]
         y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        _chk(lib.uvl_linear_ws(_p(x), _p(w), _p(wp), _p(b), _p(y), M, N, K, act, 0, 0, t.ref(), None, 0, _stream()), lib)
+        _chk(lib.uvl_linear_pk(_p(x), _p(w), _p(wp), _p(b), _p(y), M, N, K, act, 0, 0, t.ref(), _stream()), lib)
         r = torch.nn.functional.gelu(ref) if act == 1 else torch.relu(ref) if act == 2 else ref
         torch.cuda.synchronize()
         err = (y.float() - r).abs()
@@ -194,101 +193,53 @@ def test_linear_direct_to_register_form(lib, M, N, K, mode):
         acc = mode == "f32_acc"
         y0 = _rand((M, N), 4) if acc else torch.full((M, N), float("nan"), device="cuda")
         y = y0.clone()
-        _chk(lib.uvl_linear_ws(_p(x), _p(w), _p(wp), _p(b), _p(y), M, N, K, 0, 1, int(acc), t.ref(), None, 0, _stream()), lib)
+        _chk(lib.uvl_linear_pk(_p(x), _p(w), _p(wp), _p(b), _p(y), M, N, K, 0, 1, int(acc), t.ref(), _stream()), lib)
         torch.cuda.synchronize()
         err = (y - (ref + y0 if acc else ref)).abs().max().item()
         assert err < 3e-3, err
 
 
-def _gemm_scratch(lib):
-    """zero-filled scratch of the split-tile GEMM schedule (include/uvltrack_hip.h: uvl_linear_ws)"""
-    n = lib.uvl_gemm_scratch_bytes()
-    return torch.zeros((n,), dtype=torch.uint8, device="cuda"), n
+@pytest.mark.parametrize("dr", [0, -1])
+def test_linear_heuristic_with_and_without_the_direct_to_register_form(lib, dr):
+    """The un-forced choice at >= 2048 rows with a packed weight at hand: cfg 36 by default, the eight-wave tile grids with
+    uvl_tuning.gemm_dr = 0 -- same function, both against torch; a ragged last tile, K = 576 (nine K tiles), GELU."""
+    M, N, K = 8200, 512, 576
+    x = _rand((M, K), 11).bfloat16()
+    w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()
+    b = _rand((N,), 13, 0.5)
+    wp = torch.empty_like(w)
+    _chk(lib.uvl_pack_weight(_p(w), _p(wp), N, K, _stream()), lib)
+    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + b)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _chk(lib.uvl_linear_pk(_p(x), _p(w), _p(wp), _p(b), _p(y), M, N, K, 1, 0, 0, _tune(gemm_dr=dr).ref(), _stream()), lib)
+    torch.cuda.synchronize()
+    err = (y.float() - ref).abs()
+    assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "gemm_dr %d max err %g" % (dr, float(err.max()))
 
 
-@pytest.mark.parametrize("M,N,K,mode", [
-    (6984, 3072, 1024, "bf16"),      # configs[4] QKV shape: 336 tiles = 1 round + 80 tiles cut 3.2 ways
-    (6664, 4096, 1024, "gelu"),      # configs[4] fc1: 432 tiles, the last M tile holds 8 rows
-    (5448, 1024, 4096, "f32_acc"),   # fc2: 88 tiles, no whole round -- every tile is cut; read-modify-write epilogue
-    (2100, 768 * 2, 512, "bf16"),    # 54 tiles of 8 K tiles: the smallest K the schedule takes
-    (3000, 2560, 1536, "f32"),       # 120 tiles, 24 K tiles
-    (7000, 2048, 576, "relu"),       # nine K tiles (odd)
-])
-def test_linear_split_tile_schedule(lib, M, N, K, mode):
-    """gemm_sk_kernel (cfg 35, uvl_tuning.gemm_sk = 1): whole tiles + tiles cut along K whose pieces meet through f32 slabs.  Against
-    torch fp32, ragged M, every epilogue; two consecutive launches on the same scratch give the same bits (fixed summation order,
-    flags left at zero), and the scratch's flags ARE zero afterwards."""
-    x = _rand((M, K), 1).bfloat16()
-    w = (_rand((N, K), 2, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
-    b = _rand((N,), 3, 0.5)
-    ref = x.float() @ w.float().t() + b
-    scratch, nbytes = _gemm_scratch(lib)
-    t = _tune(gemm_sk=1, gemm_cfg=35)
-    outs = []
-    for rep in range(2):
-        if mode in ("bf16", "gelu", "relu"):
-            act = {"bf16": 0, "gelu": 1, "relu": 2}[mode]
-            y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-            _chk(lib.uvl_linear_ws(_p(x), _p(w), None, _p(b), _p(y), M, N, K, act, 0, 0, t.ref(), _p(scratch), nbytes, _stream()), lib)
-            r = torch.nn.functional.gelu(ref) if act == 1 else torch.relu(ref) if act == 2 else ref
-            torch.cuda.synchronize()
-            err = (y.float() - r).abs()
-            assert bool((err <= 1e-2 * r.abs() + 2e-2).all()), "max err %g" % float(err.max())
-        else:
-            acc = mode == "f32_acc"
-            y0 = _rand((M, N), 4) if acc else torch.full((M, N), float("nan"), device="cuda")
-            y = y0.clone()
-            _chk(lib.uvl_linear_ws(_p(x), _p(w), None, _p(b), _p(y), M, N, K, 0, 1, int(acc), t.ref(), _p(scratch), nbytes, _stream()), lib)
-            torch.cuda.synchronize()
-            err = (y - (ref + y0 if acc else ref)).abs().max().item()
-            assert err < 3e-3, err
-        outs.append(y)
-        assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0, "flags not lowered"
-    assert torch.equal(outs[0], outs[1]), "split-tile sums are not reproducible"
-
-
-def test_qkv_project_split_tile_schedule(lib):
-    """The QKV scatter epilogue under the split-tile schedule == the tile-grid kernel's output within bf16 rounding of different
-    summation orders, at the configs[4] shape (8 x 873 rows, D = 1024)."""
+def test_qkv_project_direct_to_register_form(lib):
+    """The QKV scatter epilogue of gemm_dr_kernel (q scaled, k, V^T token-contiguous) at the configs[4] shape (8 x 873 rows, D = 1024) against
+    torch and against the tile-grid kernel's output."""
     B, N, D = 8, 873, 1024
     Npad = 896
     x = _rand((B * N, D), 21).bfloat16()
     w = _rand((3 * D, D), 22, 1.0 / math.sqrt(D)).bfloat16()
     b = _rand((3 * D,), 23, 0.5)
-    scratch, nbytes = _gemm_scratch(lib)
-    res = []
-    for sk in (0, 1):
-        q = torch.zeros((B, D // 64, Npad, 64), dtype=torch.bfloat16, device="cuda")
-        k = torch.zeros_like(q)
-        vt = torch.zeros((B, D // 64, 64, Npad), dtype=torch.bfloat16, device="cuda")
-        t = _tune(gemm_sk=sk, gemm_cfg=35 if sk else 30)
-        _chk(lib.uvl_qkv_project_ws(_p(x), _p(w), None, _p(b), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(QSCALE), t.ref(), _p(scratch), nbytes, _stream()), lib)
-        torch.cuda.synchronize()
-        res.append((q, k, vt))
+    wp = torch.empty_like(w)
+    _chk(lib.uvl_pack_weight(_p(w), _p(wp), 3 * D, D, _stream()), lib)
     ref = (x.float() @ w.float().t() + b).reshape(B, N, 3, D // 64, 64)
     qr = (ref[:, :, 0] * QSCALE).permute(0, 2, 1, 3)
     kr = ref[:, :, 1].permute(0, 2, 1, 3)
     vr = ref[:, :, 2].permute(0, 2, 3, 1)
-    for q, k, vt in res:
+    for cfg in (31, 36):
+        q = torch.zeros((B, D // 64, Npad, 64), dtype=torch.bfloat16, device="cuda")
+        k = torch.zeros_like(q)
+        vt = torch.zeros((B, D // 64, 64, Npad), dtype=torch.bfloat16, device="cuda")
+        _chk(lib.uvl_qkv_project_pk(_p(x), _p(w), _p(wp), _p(b), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(QSCALE), _tune(gemm_cfg=cfg).ref(), _stream()), lib)
+        torch.cuda.synchronize()
         for got, want in ((q[:, :, :N], qr), (k[:, :, :N], kr), (vt[:, :, :, :N], vr)):
             err = (got.float() - want).abs()
-            assert bool((err <= 1e-2 * want.abs() + 2e-2).all()), float(err.max())
-
-
-@pytest.mark.parametrize("w4", [0, 1])
-def test_linear_heuristic_with_and_without_the_four_wave_form(lib, w4):
-    """The un-forced choice at >= 8192 rows: cfg 30 by default, cfg 34 with uvl_tuning.gemm_w4 = 1 (bf16-type epilogues) -- same
-    function, both against torch; a ragged last tile, K = 576 (nine K tiles)."""
-    M, N, K = 8200, 512, 576
-    x = _rand((M, K), 11).bfloat16()
-    w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()
-    b = _rand((N,), 13, 0.5)
-    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + b)
-    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, 1, 0, 0, _tune(gemm_w4=w4).ref(), _stream()), lib)
-    torch.cuda.synchronize()
-    err = (y.float() - ref).abs()
-    assert bool((err <= 1e-2 * ref.abs() + 2e-2).all()), "gemm_w4 %d max err %g" % (w4, float(err.max()))
+            assert bool((err <= 1e-2 * want.abs() + 2e-2).all()), (cfg, float(err.max()))
 
 
 @pytest.mark.parametrize("cfg", [8, 10, 11])

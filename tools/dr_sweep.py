@@ -43,7 +43,7 @@ def run(M, N, K, cfgs=(30, 31, 36), act=0, f32=0, vendor=True):
     out = []
     for cfg in cfgs:
         t = _native.UvlTuning(gemm_cfg=cfg)
-        us = timeit(lambda: lib.uvl_linear_ws(p(x), p(w), p(wp), p(bias), p(y), M, N, K, act, f32, f32, t.ref(), None, 0, st))
+        us = timeit(lambda: lib.uvl_linear_pk(p(x), p(w), p(wp), p(bias), p(y), M, N, K, act, f32, f32, t.ref(), st))
         out.append("cfg%d %6.1f us %5.0f TF" % (cfg, us, flops / us / 1e6))
     if vendor:
         bb = bias.bfloat16()

@@ -1,5 +1,7 @@
-"""Split-tile (stream-K) GEMM schedule beside the tile-grid kernels and hipBLASLt on the shapes of 8 UVLTrack-L sequences.
-Usage (GPU box): python tools/sk_bench.py [M ...]"""
+"""The GEMM forms of many-sequence frames (cfg 30 / 31 tile grids, cfg 36 direct-to-register; round 4 also timed the since-removed
+split-tile schedule with this script, profiles/r04_sk_bench.txt) beside hipBLASLt on the shapes of 8 UVLTrack-L sequences: bias epilogue and
+the frame's epilogue, three interleaved rounds, medians.  SK_ONLY=c31,dr restricts the forms; --lib PATH loads a variant build.
+Usage (GPU box): python tools/gemm_forms_bench.py [M ...]"""
 import ctypes as C
 import os
 import sys
@@ -37,8 +39,6 @@ def timeit(fn, iters=40):
 def main():
     Ms = [int(a) for a in sys.argv[1:]] or [6664, 6984, 5448]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    nb = lib.uvl_gemm_scratch_bytes()
-    scratch = torch.zeros((nb,), dtype=torch.uint8, device="cuda")
     D = 1024
     for M in Ms:
         for name, N, K, act, f32 in (("qkv", 3 * D, D, 0, 0), ("fc1", 4 * D, D, 1, 0), ("proj", D, D, 0, 1), ("fc2", D, 4 * D, 0, 1)):
@@ -49,7 +49,7 @@ def main():
             lib.uvl_pack_weight(p(w), p(wp), N, K, st)
             y = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
             flops = 2.0 * M * N * K
-            forms = (("auto", {}), ("nosk", dict(gemm_sk=0)), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("sk", dict(gemm_cfg=35, gemm_sk=1)), ("dr", dict(gemm_cfg=36)))
+            forms = (("auto", {}), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("dr", dict(gemm_cfg=36)))
             if os.environ.get("SK_ONLY"):
                 forms = [f for f in forms if f[0] in os.environ["SK_ONLY"].split(",")]
             cases = []
@@ -57,7 +57,7 @@ def main():
                 t = _native.UvlTuning(**kw)
                 for ep_label, a_, f_, acc_ in (("bias", 0, 0, 0), ("frame", act, f32, f32)):
                     yy = y if f_ == f32 else torch.zeros(M, N, device="cuda", dtype=torch.float32 if f_ else torch.bfloat16)
-                    cases.append(("%s/%s" % (label, ep_label), (lambda t=t, yy=yy, a_=a_, f_=f_, acc_=acc_: lib.uvl_linear_ws(p(x), p(w), p(wp), p(bias), p(yy), M, N, K, a_, f_, acc_, t.ref(), p(scratch), nb, st))))
+                    cases.append(("%s/%s" % (label, ep_label), (lambda t=t, yy=yy, a_=a_, f_=f_, acc_=acc_: lib.uvl_linear_pk(p(x), p(w), p(wp), p(bias), p(yy), M, N, K, a_, f_, acc_, t.ref(), st))))
             # three interleaved rounds, median: the order of the cases and the clock the part grants do not favour one of them
             res = {c[0]: [] for c in cases}
             for _ in range(3):

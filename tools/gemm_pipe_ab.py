@@ -1,6 +1,6 @@
 """A/B of the batched GEMM forms on the frames' own shapes, beside hipBLASLt (through torch, a yardstick only): the 128x128 product
 loop (cfg 6), its producer-wave form (21), the plain 256x256 tile (11), the phase-pipelined 256-wide tiles (30: 256x256,
-31: 128x256; gemm.hip::gemm_pipe_body; 32 / 33: the same with 32x32x16 MFMAs) and the four-wave tile with the generated K loop (34).  Every configuration is bit-checked against torch before it is timed; rounds are
+31: 128x256; gemm.hip::gemm_pipe_body; 32 / 33: the same with 32x32x16 MFMAs).  Every configuration is bit-checked against torch before it is timed; rounds are
 interleaved in one process and the best of them is reported (guide section 5.4 rule 24).
 Usage (GPU box): python tools/gemm_pipe_ab.py [--epi bf16|gelu|f32acc|qkv] [--cfgs 6,11,30] [--shapes L8,B32,...]"""
 import ctypes as C
@@ -16,7 +16,7 @@ from uvltrack_amd import _native  # noqa: E402
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-LABEL = {4: "64x64 ring", 7: "64x64 2st", 9: "128x64", 10: "64x128", 6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 mi32", 33: "pipe128 mi32", 34: "w4 256x256", -1: "auto"}
+LABEL = {4: "64x64 ring", 7: "64x64 2st", 9: "128x64", 10: "64x128", 6: "128x128", 21: "128x128+4prod", 11: "256x256 plain", 30: "pipe 256x256", 31: "pipe 128x256", 32: "pipe256 mi32", 33: "pipe128 mi32", -1: "auto"}
 
 
 def arg(name, default):

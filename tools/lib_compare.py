@@ -13,7 +13,7 @@ from uvltrack_amd import _native  # noqa: E402
 
 lib = _native.load()
 TUNE = _native.UvlTuning()      # per-call overrides of the launch heuristics (no process-global tuning state)
-CFGS = (4, 7, 9, 10, 6, 11, 30, 31, 34, 36)
+CFGS = (4, 7, 9, 10, 6, 11, 30, 31, 36)
 GMS = (0, 8)
 
 
@@ -45,7 +45,7 @@ def gemms(B, D, ntok):
         bias = torch.randn(N, device="cuda")
         y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         flops = 2.0 * M * N * K
-        call = lambda: lib.uvl_linear_ws(p(x), p(w), p(wp), p(bias), p(y), M, N, K, 0, 0, 0, TUNE.ref(), None, 0, st)
+        call = lambda: lib.uvl_linear_pk(p(x), p(w), p(wp), p(bias), p(y), M, N, K, 0, 0, 0, TUNE.ref(), st)
         bb = bias.bfloat16()
         vendor = lambda: F.linear(x, w, bb)
         # "ours auto" and hipBLASLt: three interleaved rounds, median (neither gets the cooler chip)
@@ -59,7 +59,7 @@ def gemms(B, D, ntok):
         best = (mine, "auto")
         allc = []
         for cfg in CFGS:
-            if (cfg in (2, 3, 6, 10, 12, 13, 15) and N % 128) or (cfg in (11, 14, 30, 31, 34, 36) and N % 256):
+            if (cfg in (2, 3, 6, 10, 12, 13, 15) and N % 128) or (cfg in (11, 14, 30, 31, 36) and N % 256):
                 continue
             TUNE.gemm_cfg = cfg
             for gm in GMS:

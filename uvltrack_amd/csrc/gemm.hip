@@ -12,7 +12,6 @@
 // XOR-swizzled (on the per-lane DMA source address and again on the fragment read) so ds_read_b128 is conflict-free.
 // The workgroup -> tile map is XCD-aware (see gemm_glds_body).
 #include <cstdio>
-#include <cmath>
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -337,17 +336,9 @@ __device__ __forceinline__ void pipe_tile_of(const int L, const int MT, const in
     mt = gi * group_m + (within - nt * gm);
 }
 
-// Split-tile ("stream-K") pieces, gemm_sk_kernel below: the K loop of a piece covers K tiles [kt0, kt0 + nk) of output tile (mt, nt).
-//   sk_mode 0: the whole tile (or a piece that needs no partner): the normal epilogue;
-//   sk_mode 1: a CONTRIBUTOR piece: the f32 accumulators go to slab `sk_slot` (lane-linear image, write-through) and the slot's flag is raised;
-//   sk_mode 2: the OWNER piece (it holds the tile's last K tiles): BEFORE its K loop it waits for the flags of slots [sk_c0, sk_slot),
-//              sums their slabs in ascending slot order (= ascending K: a fixed order, so the sum is the same bits in every run) into the
-//              accumulators the loop then continues on, and lowers the flags again (each flag has exactly one consumer; nothing is
-//              left to reset between launches or graph replays); then the normal epilogue.  (Adding the slabs BEHIND the loop made
-//              hipcc keep two copies of the 128 accumulators: 220-590 spilled registers.)
-template <int BM, int EPI, int VAR = 0, bool MI16 = true, bool SK = false>
-__device__ __forceinline__ void gemm_pipe_tile(const GemmParams& p, const int mt, const int nt, const int kt0, const int nk,
-                                               const int sk_mode, const int sk_slot, const int sk_c0, char* smem) {
+// the phase-pipelined K loop over all nk K tiles of output tile (mt, nt), then the epilogue
+template <int BM, int EPI, int VAR = 0, bool MI16 = true>
+__device__ __forceinline__ void gemm_pipe_tile(const GemmParams& p, const int mt, const int nt, const int nk, char* smem) {
     constexpr int BN = 256, NW = 8, WM = BM / 2, WN = 64, TM = WM / 32, TN = 2, HB = TM / 2;   // HB: A blocks of a half (lo / hi)
     constexpr int STAGE = (BM + BN) * 128;                   // one K tile: A rows then W rows, 128 bytes each
     constexpr int NA = BM / 128, NB = 2;                     // LDS-DMA instructions per wave for an A group / a B group (8 rows each)
@@ -357,8 +348,8 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmParams& p, const int mt
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int m0 = mt * BM, n0 = nt * BN;
-    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda + (SK ? kt0 * 64 : 0));
-    const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw + (SK ? kt0 * 64 : 0));
+    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
 
     // ---- LDS-DMA plan.  Group g of a K tile: 0 = A-lo (rows wm' * WM + [0, WM/2) of both wave groups), 1 = B-lo (rows wn' * 64 + [0, 32)
     // of the four wave columns), 2 = B-hi, 3 = A-hi.  Instruction n of a group, issued by this wave, fills 8 consecutive tile rows.
@@ -418,36 +409,9 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmParams& p, const int mt
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (SK) {
-        // slabs cross XCDs: the loads bypass the caches (sc0 sc1), see the store side below
-        constexpr unsigned SLAB = TM * TN * 4 * 512 * 16;
-        const int c_end = sk_mode == 2 ? sk_slot : sk_c0;
-        for (int c = sk_c0; c < c_end; ++c) {
-            while (__hip_atomic_load(p.sk_flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) __builtin_amdgcn_s_sleep(1);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.sk_slab) + (size_t)c * SLAB, 0, SLAB, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                u32x4 pv[TN * 4];
-#pragma unroll
-                for (int n = 0; n < TN * 4; ++n) pv[n] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, (i * TN * 4 + n) * 8192, 17);
-#pragma unroll
-                for (int n = 0; n < TN * 4; ++n) {
-                    const f32x4 f = __builtin_bit_cast(f32x4, pv[n]);
-                    const int j = n >> 2, q = n & 3;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += f[e];
-                }
-            }
-        }
-        if (sk_mode == 2) {
-            __builtin_amdgcn_s_barrier();                    // every wave has seen the flags
-            if (tid == 0)
-                for (int c = sk_c0; c < sk_slot; ++c) __hip_atomic_store(p.sk_flags + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
     bf16x8 af[HB][4], bl[4], bh[4];
 
-    // nk >= 2 (launcher / piece schedule)
+    // nk >= 2 (launcher)
     // the tile's 256 bias values: requested before the first DMA (so the first tile wait retires them), parked in LDS behind the
     // ring -- 32 registers per lane cannot be held across the loop, and fetched behind it they cost a dependent L2 round trip per tile
     float* sbias = reinterpret_cast<float*>(smem + 2 * STAGE);
@@ -572,30 +536,6 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmParams& p, const int mt
     }
 #endif
 
-    if constexpr (SK) {
-        // A slab is the lane-linear image of a workgroup's accumulators: 16-byte piece n of thread t at (n * 512 + t) * 16, so every store /
-        // load instruction of a wave covers 1 KB of consecutive addresses.  Slabs cross XCDs (the owner of a tile runs on another XCD's L2
-        // than most of its contributors): stores are write-through and loads bypass the caches (sc0 sc1), the flag follows the stores
-        // behind s_waitcnt vmcnt(0) + a workgroup barrier.
-        constexpr int NQ = TM * TN * 4;
-        constexpr unsigned SLAB = NQ * 512 * 16;
-        if (sk_mode == 1) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.sk_slab) + (size_t)sk_slot * SLAB, 0, SLAB, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, tid * 16, ((i * TN + j) * 4 + q) * 8192, 17);
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (tid == 0) __hip_atomic_store(p.sk_flags + sk_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
-    }
     f32x4 bias_v[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -616,7 +556,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
         if (idx >= cnt) return;
         pipe_tile_of(xcd * base + (xcd < rem ? xcd : rem) + idx, MT, NT, p.group_m, mt, nt);
     }
-    gemm_pipe_tile<BM, EPI, VAR, MI16, false>(p, mt, nt, 0, p.K / 64, 0, 0, 0, smem);
+    gemm_pipe_tile<BM, EPI, VAR, MI16>(p, mt, nt, p.K / 64, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -865,126 +805,6 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Split-tile ("stream-K") schedule of the 256 x 256 pipelined GEMM for frames whose tile count is not a whole number of rounds of the
-// CUs (8 UVLTrack-L sequences: the QKV projection is 336 tiles = 1.31 rounds of 256 CUs, fc1 at 6664 rows 432 = 1.69 -- a tile grid
-// pays 2 rounds, or 3 half-rounds of 128 x 256).  One PERSISTENT workgroup per CU:
-//   * the first R * G tiles of the grouped tile order are whole tiles, R per workgroup (XCD x owns a contiguous run of R * G / 8 tiles and
-//     its G / 8 workgroups walk it side by side);
-//   * the remaining `tail` tiles are cut along K: their U = tail * nk K-tile units are dealt out in order, workgroup w of the Gt tail
-//     workers gets units [b(w), b(w + 1)), b(w) = w U / Gt moved off the two positions next to a tile boundary (a piece is never
-//     a single K tile: the loop needs two).  A range touches at most two tiles (tail <= 0.8 G): the END of one tile -- that workgroup OWNS
-//     the tile -- and / or the START of the next, a contributor piece.
-//   * order inside a workgroup: contributor piece, whole tiles, owner piece.  Every contribution is in memory a whole tile's time
-//     before its owner asks for it, so the flag wait never spins in practice (it is there for correctness); all workgroups are resident
-//     (G <= CUs), so a spinning owner cannot keep a contributor from running.
-// Sums are formed in a fixed order (own accumulators, then the slabs in ascending K), no atomics: same bits in every run.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int sk_bound(const int w, const int U, const int Gt, const int nk) {
-    if (w >= Gt) return U;
-    int v = (int)(((unsigned)w * (unsigned)U) / (unsigned)Gt);
-    const int r = v % nk;
-    if (r == 1) v -= 1;
-    else if (r == nk - 1) v += 1;
-    return v;
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_sk_kernel(const GemmParams p, const int R, const int Gt, const int U) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256;
-    const int MT = (p.M + BM - 1) / BM, NT = p.N / 256, nk = p.K / 64;
-    const int G = (int)gridDim.x, g8 = G >> 3, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-    const int gt8 = Gt >> 3;
-    const int w = idx < gt8 ? xcd * gt8 + idx : -1;          // rank among the tail workers: an XCD's workers hold neighbouring tiles
-    int c_tile = -1, c_k0 = 0, c_nk = 0;                      // contributor piece
-    int o_tile = -1, o_k0 = 0, o_c0 = 0;                      // owner piece: K tiles [o_k0, nk), partners are slots [o_c0, w)
-    if (w >= 0) {
-        const int b0 = sk_bound(w, U, Gt, nk), b1 = sk_bound(w + 1, U, Gt, nk);
-        const int a = b0 / nk, off = b0 - a * nk, end = b1 - a * nk;
-        if (end > off) {
-            if (end < nk) { c_tile = a; c_k0 = off; c_nk = end - off; }
-            else {
-                o_tile = a; o_k0 = off;
-                if (end > nk) { c_tile = a + 1; c_nk = end - nk; }
-                o_c0 = w;
-                if (off > 0) do { --o_c0; } while (sk_bound(o_c0, U, Gt, nk) > a * nk);
-            }
-        }
-    }
-    bool ran = false;
-    for (int it = 0; it < R + 2; ++it) {
-        int L, k0, n, mode;
-        if (it == 0) { if (c_tile < 0) continue; L = R * G + c_tile; k0 = c_k0; n = c_nk; mode = 1; }
-        else if (it <= R) { L = xcd * (R * g8) + (it - 1) * g8 + idx; k0 = 0; n = nk; mode = 0; }
-        else { if (o_tile < 0) continue; L = R * G + o_tile; k0 = o_k0; n = nk - o_k0; mode = o_k0 > 0 ? 2 : 0; }
-        if (ran) __builtin_amdgcn_s_barrier();               // the previous item's epilogue staging is out of the buffers
-        ran = true;
-        int mt, nt;
-        pipe_tile_of(L, MT, NT, p.group_m, mt, nt);
-        gemm_pipe_tile<BM, EPI, 1, true, true>(p, mt, nt, k0, n, mode, w, o_c0, smem);
-    }
-}
-
-// Returns hipErrorNotSupported when the schedule does not apply to the shape (the caller then takes the tile-grid kernels).
-static int sk_num_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 8;
-        cus = n;
-    }
-    return cus;
-}
-struct SkPlan { int G, R, tail, Gt, U; bool ok; };
-static SkPlan sk_plan(const GemmParams& p) {
-    SkPlan pl{};
-    pl.ok = false;
-    if (!p.sk_slab || !p.sk_flags || p.N % 256 != 0 || p.K < 512 || p.K % 64 != 0 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return pl;
-    const int MT = (p.M + 255) / 256, NT = p.N / 256, nk = p.K / 64;
-    const long T = (long)MT * NT;
-    int G = sk_num_cus() & ~7;
-    if (G > 256) G = 256;                                     // slabs are sized for 256 workers (uvl_gemm_scratch_bytes)
-    if (G < 8 || G > p.sk_slots) return pl;
-    pl.G = G;
-    pl.R = (int)(T / G);
-    pl.tail = (int)(T - (long)pl.R * G);
-    if (pl.tail == 0 && tune_get(p.tune, &uvl_tuning::gemm_sk, -1) == 2) { pl.Gt = 0; pl.U = 0; pl.ok = true; return pl; }   // tools: whole rounds on persistent workgroups
-    if (pl.tail == 0 || pl.tail * 10 > G * 8) return pl;      // whole rounds, or a last round that is >= 80 % full: the tile grid is as good
-    pl.U = pl.tail * nk;
-    int Gt = (pl.U / 4) & ~7;
-    if (Gt > G) Gt = G;
-    if (Gt < 8 || Gt < pl.tail) return pl;
-    pl.Gt = Gt;
-    pl.ok = true;
-    return pl;
-}
-
-template <int EPI>
-static hipError_t launch_pipe_sk(const GemmParams& p_in, hipStream_t s) {
-    GemmParams p = p_in;
-    const SkPlan pl = sk_plan(p);
-    if (!pl.ok) return hipErrorNotSupported;
-    const int MT = (p.M + 255) / 256;
-    p.group_m = MT >= 16 ? 8 : MT;
-    const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
-    if (forced_gm > 0) p.group_m = forced_gm;
-    constexpr size_t lds = 2 * (size_t)(256 + 256) * 128 + 1024;
-    auto kern = gemm_sk_kernel<EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    static char name[32];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_sk_kernel<%d>", EPI);
-    g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(pl.G), dim3(512), lds, s, p, pl.R, pl.Gt, pl.U);
-    return hipGetLastError();
-}
-
-
 // Two independent plain GEMMs of the same instantiation in one launch (batch-1 frames: a text-branch GEMM rides with the
 // visual GEMM of the same kind).  1-D grid: problem A owns [0, blocks_a) = tiles_a x splitk_a, problem B the rest; tile
 // counts are multiples of 8, so the workgroup -> XCD relation of both tile maps is preserved.
@@ -1097,12 +917,7 @@ static hipError_t launch_plain_cfg(int cfg, const GemmParams& p, hipStream_t s) 
         case 31: return launch_pipe128<EPI, true>(p, s);         // 128 x 256: two phases per K tile, three buffers, 16x16x32 MFMAs
         case 32: return launch_pipe<256, EPI, 1, false>(p, s);   // cfg 30 with 32x32x16 MFMAs (the form of the first half of round 3; A/B)
         case 33: return launch_pipe128<EPI, false>(p, s);        // cfg 31 with 32x32x16 MFMAs
-        case 34: return launch_gemm_w4(p, EPI, s);                // 256 x 256 on four waves (128 x 128 each), register-staged K tiles
         case 36: return launch_gemm_dr(p, EPI, s);                // 128 x 256 on four waves, two workgroups per CU, W fragments straight from global memory
-        case 35: {                                                // cfg 30's loop under the split-tile schedule (gemm_sk_kernel); cfg 30 where it does not apply
-            const hipError_t e = launch_pipe_sk<EPI>(p, s);
-            return e == hipErrorNotSupported ? launch_pipe<256, EPI, 1, true>(p, s) : e;
-        }
     }
     return hipErrorInvalidValue;
 }
@@ -1133,28 +948,7 @@ static int pick_plain_cfg(const GemmParams& p) {
         auto fill = [](long t) { const long rounds = (t + 255) / 256; return (double)t / (double)(rounds * 256); };
         const long nt256 = p.N / 256;
         const double f256 = fill((long)((p.M + 255) / 256) * nt256), f128 = fill((long)((p.M + 127) / 128) * nt256);
-        // The four-wave 256 x 256 form whose K loop is generated assembly (cfg 34, gemm_w4.hip: 16x16x32 MFMAs, LDS-DMA, one wave per
-        // SIMD) is where the 16x16x32 / clock finding came from; against the 32x32x16 cfg 30 it was +3..15 % in isolation and +2.2 % on
-        // 32 UVLTrack-L sequences.  Against TODAY's cfg 30 (same MFMA, two waves per SIMD hiding the epilogue) it loses in the frames
-        // (interleaved A/B: 32 UVLTrack-B sequences 5751-5784 against 5925-5929 frames/s, 32 UVLTrack-L 1352-1357 against 1362-1364), so it
-        // is opt-in: uvl_tuning.gemm_w4 = 1 puts it on bf16-type epilogues from 8192 rows (profiles/r03_gemm_w4.md).
-        // The direct-to-register form (cfg 36, gemm_dr.hip: 128 x 256 tiles on four waves, TWO workgroups per CU, W fragments loaded straight
-        // into registers from the fragment-native weight image): what a tile pays outside its K loop runs under the other workgroup's loop.
-        // Measured beside cfg 30 / 31 and hipBLASLt (profiles/r04_gemm_dr.md): ahead of both with the bias / GELU / QKV epilogues on every
-        // shape of 8 sequences.  uvl_tuning.gemm_dr: 0 = never, 1 = wherever it applies (the f32 epilogue too).
-        {
-            const int want = tune_get(p.tune, &uvl_tuning::gemm_dr, -1);
-            // The f32 read-modify-write epilogue stays with the eight-wave kernels: in isolation cfg 36 wins it from ~400 tiles on (proj of 16 /
-            // 32 UVLTrack-L sequences 41.6 / 64.2 against 44.9 / 71.0 us; 8 sequences = 220 tiles = a single round: 28.3 against 25.0), but in
-            // the frames it loses (interleaved tools/ab_tune.py gemm_dr 2 -1: UVLTrack-L x 8 1156-1157 against 1136-1138 frames/s, UVLTrack-B x 32
-            // 6150-6172 against 6111-6131): 2 x 28 MB of residual traffic per launch, and two workgroups per CU issue it at the same moment.
-            if (want != 0 && p.Wp && p.K % 64 == 0 && (want == 1 || p.epi != EPI_F32)) return 36;
-        }
-        // Split-tile schedule (cfg 35, gemm_sk_kernel): the 256 x 256 loop without tile quantisation.  Measured (profiles/r04_gemm_streamk.md):
-        // every piece of a cut tile pays the ~8 us a whole tile pays outside its K loop, and three pieces per workgroup cost more than the
-        // half-empty round they replace -- slower than the tile grids on every shape of the frames, so it is opt-in (uvl_tuning.gemm_sk = 1).
-        if (tune_get(p.tune, &uvl_tuning::gemm_sk, 0) >= 1 && sk_plan(p).ok) return 35;
-        const int c256 = (p.epi != EPI_F32 && p.K >= 512 && p.M >= 8192 && !(p.epi == EPI_QKV && p.D % 128 != 0) && tune_get(p.tune, &uvl_tuning::gemm_w4, 0)) ? 34 : 30;
+        const int c256 = 30;
         if (f256 >= 0.8) return c256;
         if (f128 >= 0.8) return 31;
         if (f256 >= 0.6 || f128 >= 0.6) return f256 >= f128 ? c256 : 31;
@@ -1181,7 +975,7 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t s) {
     int cfg = pick_plain_cfg(p);
     if ((cfg == 2 || cfg == 3 || cfg == 6 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 15 || (cfg >= 16 && cfg <= 21)) && p.N % 128 != 0) cfg = 0;
     if (cfg >= 16 && cfg <= 21 && p.splitk > 1) cfg = 6;
-    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 36)) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
+    if ((cfg == 11 || cfg == 14 || (cfg >= 30 && cfg <= 33) || cfg == 36) && (p.N % 256 != 0 || p.K < 128 || p.splitk > 1)) cfg = 0;
     return launch_plain_cfg<EPI>(cfg, p, s);
 }
 

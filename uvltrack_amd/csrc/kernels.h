@@ -35,8 +35,6 @@ struct GemmParams {
                                                  // Infinity Cache (text branch): non-temporal weight-tile loads where instantiated
     const uvl_tuning* tune = nullptr;            // host side only: overrides of the launch heuristics (null = heuristics)
     int c_store = 0;                             // EPI_F32 stores: 0 plain, 1 non-temporal, 2 write-through (sc1); A/B knob uvl_tuning.res_store
-    float* sk_slab = nullptr; unsigned* sk_flags = nullptr; int sk_slots = 0;   // scratch of the split-tile schedule (gemm.hip::gemm_sk_kernel):
-                                                 // sk_slots slabs of 256 KB + as many flags (zero between launches); null = tile grids only
     int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
 };
@@ -86,7 +84,6 @@ hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
 hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s);
 // one-sequence frames: LayerNorm(_pair) + the GEMM(_pair) that consumes it in one launch behind a grid barrier (gemm.hip); falls back to the
 // two launches where the fused form does not apply.  bar: 4 KB of zero-initialised device memory owned by the model, gen: 1, 2, 3, ..., *base: arrivals per group so far (updated)
-hipError_t launch_gemm_w4(const GemmParams& p, int epi, hipStream_t s);      // gemm_w4.hip: 256 x 256 on four waves (cfg 34)
 hipError_t launch_pack_w_dr(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);   // [N, K] -> fragment-native image (same size)
 hipError_t launch_gemm_dr(const GemmParams& p, int epi, hipStream_t s);      // gemm_dr.hip: 128 x 256 on four waves, two workgroups per CU, W straight into registers (cfg 36)
 hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const GemmParams& a, const GemmParams* b, unsigned* bar, unsigned gen, unsigned* base, bool* fused, hipStream_t s);   // two independent problems, one launch

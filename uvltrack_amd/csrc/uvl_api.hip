@@ -95,7 +95,6 @@ struct uvl_model {
                                                  // grid barrier (96 -> 72 launches; measured 3-4 % SLOWER than the two launches, so off: profiles/r03_summary.md)
     unsigned* gbar = nullptr;                    // 4 KB of counters for the fused launches' grid barrier (monotonic: never reset)
     unsigned gbar_gen = 0, gbar_base = 0;        // generation of the last fused launch; arrivals per counter group so far
-    void* gemm_scratch = nullptr;                // flags + f32 slabs of the split-tile GEMM schedule (gemm.hip::gemm_sk_kernel), uvl_gemm_scratch_bytes()
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_bert, ev_cont;
     // graph
@@ -110,16 +109,6 @@ struct uvl_model {
     uvl_tuning tune_text;               // = tune with gemm_cfg replaced by text_cfg: what the text-branch GEMMs of multi-sequence frames see
     uvl_model() { uvl_tuning_init(&tune); }
 };
-
-// scratch of the split-tile GEMM schedule: 4 KB of flags, then SK_SLOTS slabs of 256 x 256 f32
-enum : size_t { SK_FLAG_BYTES = 4096, SK_SLOTS = 256, SK_SLAB_BYTES = 256 * 256 * 4 };
-extern "C" size_t uvl_gemm_scratch_bytes(void) { return SK_FLAG_BYTES + SK_SLOTS * SK_SLAB_BYTES; }
-static void set_gemm_scratch(GemmParams& p, void* scratch, size_t bytes) {
-    if (!scratch || bytes < uvl_gemm_scratch_bytes() || ((uintptr_t)scratch & 255)) return;
-    p.sk_flags = reinterpret_cast<unsigned*>(scratch);
-    p.sk_slab = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + SK_FLAG_BYTES);
-    p.sk_slots = (int)SK_SLOTS;
-}
 
 extern "C" void uvl_tuning_init(uvl_tuning* t) {
     if (!t) return;
@@ -157,10 +146,6 @@ extern "C" uvl_model_t* uvl_create(const uvl_config* c) {
         return nullptr;
     }
     if (hipMalloc(&m->gbar, 4096) == hipSuccess) hipMemset(m->gbar, 0, 4096); else m->gbar = nullptr;   // no barrier memory: the fused launches fall back
-    // split-tile GEMM scratch: only frames of >= 2048 rows can use it
-    if ((long)c->max_batch * (m->nj) >= 2048 && hipMalloc(&m->gemm_scratch, uvl_gemm_scratch_bytes()) == hipSuccess) {
-        if (hipMemset(m->gemm_scratch, 0, SK_FLAG_BYTES) != hipSuccess) { hipFree(m->gemm_scratch); m->gemm_scratch = nullptr; }
-    } else m->gemm_scratch = nullptr;
     m->ev_bert.resize(c->depth);
     m->ev_cont.resize(c->depth);
     for (auto& e : m->ev_bert) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -184,7 +169,6 @@ extern "C" void uvl_destroy(uvl_model_t* m) {
     if (m->ev_join) hipEventDestroy(m->ev_join);
     if (m->aux) hipStreamDestroy(m->aux);
     if (m->gbar) hipFree(m->gbar);
-    if (m->gemm_scratch) hipFree(m->gemm_scratch);
     delete m;
 }
 
@@ -648,7 +632,6 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         // BERT weights are read once per frame: up to four sequences (<= 3 M tiles share a weight tile through L2) they are loaded
         // non-temporal so that they do not displace the ViT weights from the Infinity Cache (+2-3 % at 2-4 sequences, -0.5 % from 8 on)
         if (is_text && p.M <= 192) p.w_stream = 1;
-        if (!is_text) set_gemm_scratch(p, m->gemm_scratch, uvl_gemm_scratch_bytes());     // the visual stream's GEMMs run one at a time
         const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K);
         if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.g = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (pend_ln.on && !is_text) {
@@ -1029,7 +1012,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
     static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
         {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
-        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_w4", &uvl_tuning::gemm_w4}, {"gemm_sk", &uvl_tuning::gemm_sk}, {"gemm_dr", &uvl_tuning::gemm_dr}};
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) { m->tune.*(k.field) = value < 0 ? -1 : value; return UVL_OK; }
     if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
@@ -1258,22 +1241,19 @@ extern "C" int uvl_pack_weight(const void* d_w, void* d_w_packed, int N, int K, 
     HIPCHK(launch_pack_w_dr((const bf16_t*)d_w, (bf16_t*)d_w_packed, N, K, (hipStream_t)stream));
     return UVL_OK;
 }
-extern "C" int uvl_linear_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
-                             int accumulate, const uvl_tuning* tune, void* d_scratch, size_t scratch_bytes, void* stream) {
+extern "C" int uvl_linear_pk(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
+                             int accumulate, const uvl_tuning* tune, void* stream) {
     if (!d_x || !d_w || !d_y || M <= 0 || N % 32 != 0 || K % 64 != 0) return fail(UVL_EINVAL, "uvl_linear: need N %% 32 == 0 and K %% 64 == 0");
-    if (d_scratch && (scratch_bytes < uvl_gemm_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
-        return fail(UVL_EINVAL, "uvl_linear_ws: scratch must be 256-byte aligned and hold uvl_gemm_scratch_bytes() = %zu bytes", uvl_gemm_scratch_bytes());
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
     p.epi = out_f32 ? 1 : 0; p.C = d_y; p.ldc = N; p.act = act; p.accumulate = accumulate; p.tune = tune;
     p.Wp = (const bf16_t*)d_w_packed;
-    set_gemm_scratch(p, d_scratch, scratch_bytes);
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
 extern "C" int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int M, int N, int K, int act, int out_f32,
                           int accumulate, const uvl_tuning* tune, void* stream) {
-    return uvl_linear_ws(d_x, d_w, nullptr, d_bias, d_y, M, N, K, act, out_f32, accumulate, tune, nullptr, 0, stream);
+    return uvl_linear_pk(d_x, d_w, nullptr, d_bias, d_y, M, N, K, act, out_f32, accumulate, tune, stream);
 }
 
 /* tuning entry: y[sk] (f32 slabs [splitk][M,N]) = partial sums over K-range sk (bias in slab 0) */
@@ -1317,22 +1297,19 @@ extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt,
     return UVL_OK;
 }
 
-extern "C" int uvl_qkv_project_ws(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
-                                  const uvl_tuning* tune, void* d_scratch, size_t scratch_bytes, void* stream) {
+extern "C" int uvl_qkv_project_pk(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
+                                  const uvl_tuning* tune, void* stream) {
     if (!d_x || !d_w || !d_q || !d_k || !d_vt || D % 64 != 0) return fail(UVL_EINVAL, "uvl_qkv_project: bad argument");
-    if (d_scratch && (scratch_bytes < uvl_gemm_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
-        return fail(UVL_EINVAL, "uvl_qkv_project_ws: scratch must be 256-byte aligned and hold uvl_gemm_scratch_bytes() = %zu bytes", uvl_gemm_scratch_bytes());
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = D; p.W = (const bf16_t*)d_w; p.ldw = D; p.bias = d_bias; p.M = B * N; p.N = 3 * D; p.K = D;
     p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale; p.tune = tune;
     p.Wp = (const bf16_t*)d_w_packed;
-    set_gemm_scratch(p, d_scratch, scratch_bytes);
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
 }
 extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
                                const uvl_tuning* tune, void* stream) {
-    return uvl_qkv_project_ws(d_x, d_w, nullptr, d_bias, d_q, d_k, d_vt, B, N, Npad, D, q_scale, tune, nullptr, 0, stream);
+    return uvl_qkv_project_pk(d_x, d_w, nullptr, d_bias, d_q, d_k, d_vt, B, N, Npad, D, q_scale, tune, stream);
 }
 
 extern "C" int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps, void* d_y_bf16, float* d_y_f32, int M, int D, void* stream) {
