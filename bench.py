@@ -72,33 +72,65 @@ def build_spec(model, template_size, search_size):
     return spec_l(template_size, search_size or 384)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(spec, args, flags):
-    """The numpy oracle (a port of the reference's algorithm) timed on this host's cores on a bounded sample."""
+    """The reference's CPU path, restated: oracle/uvl_oracle_torch.py runs forward_test with the ATen operators the reference's eager
+    forward runs (F.linear / layer_norm / conv2d / softmax / gelu: the loop of tracking/profile_model.py:38-47), timed on this host's cores
+    on a bounded sample (kind "port-torch").  The numpy / OpenBLAS oracle is timed beside it on a smaller sample (`numpy_port`)."""
+    import torch
     from oracle import uvl_oracle as O
+    from oracle import uvl_oracle_torch as OT
     from uvltrack_amd import weightgen as wg
     sd = wg.make_state_dict(spec, 0, include_unused=False)
     inp = wg.make_inputs(spec, batch=1, seed=100, flags=flags[:1])
-    run = lambda: O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"])
-    # OpenBLAS with one thread per host core (256 on the GPU box) thrashes on these small GEMMs: cap the pool
-    threads = min(os.cpu_count() or 1, args.cpu_threads)
+    threads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        sdt = OT.prepare(sd)
+        run_t = lambda: OT.forward_test(sdt, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"], prepared=True)
+        run_t()
+        t0 = time.perf_counter()
+        run_t()
+        one = time.perf_counter() - t0
+        n = int(min(60, max(args.cpu_frames, round(12.0 / max(one, 1e-3)))))          # ~12 s of CPU work, at least --cpu-frames frames
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run_t()
+        dt = time.perf_counter() - t0
+        used = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(prev)
+    # the numpy oracle beside it (OpenBLAS with one thread per host core thrashes on these small GEMMs: cap the pool)
+    run_n = lambda: O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"])
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=threads)
     except Exception:
-        limiter, threads = None, os.cpu_count()
+        limiter = None
     try:
-        run()
-        n = max(1, args.cpu_frames)
+        run_n()
+        nn = max(2, min(4, args.cpu_frames))
         t0 = time.perf_counter()
-        for _ in range(n):
-            run()
-        dt = time.perf_counter() - t0
+        for _ in range(nn):
+            run_n()
+        dtn = time.perf_counter() - t0
     finally:
         if limiter is not None:
             limiter.restore_original_limits()
-    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d frames of the same workload (batch 1, fp32 numpy/OpenBLAS oracle, %d BLAS threads of %d host cores)" % (
-                n, threads, os.cpu_count()),
+    return {"value": n / dt, "unit": "frames/s", "cores": used, "kind": "port-torch", "cpu": _cpu_model(), "host_cores": os.cpu_count(),
+            "sample": "%d frames of the same workload (batch 1, fp32, torch %s CPU operators = the reference's eager ATen path restated in "
+                      "oracle/uvl_oracle_torch.py, %d intra-op threads of %d host cores)" % (n, torch.__version__.split("+")[0], used, os.cpu_count()),
+            "numpy_port": {"value": nn / dtn, "unit": "frames/s", "cores": threads, "sample": "%d frames, numpy / OpenBLAS oracle" % nn},
             # the REAL reference (eager PyTorch fp32, imported from /root/reference) cannot travel to the GPU box; measured at survey time:
             "reference_survey": {"value": 4.8, "unit": "frames/s", "cores": 8,
                                  "source": "BASELINE.md section 3: reference forward_test, UVLTrack-B z256/x256/T40, 8 vCPU Xeon (Icelake), torch 2.10 MKL/oneDNN, 8 threads"}}
@@ -194,7 +226,7 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     eng = HipEngine(spec, dev, max_batch=max(B, 1))
     for kv in args.tune:
         k, v = kv.split("=", 1)
-        if k.strip().startswith("debug."):          # uvl_debug_set keys (A/B aids that are not launch heuristics), e.g. debug.aux_priority=1
+        if k.strip().startswith("debug."):          # uvl_debug_set keys (A/B aids that are not launch heuristics), e.g. debug.fork_text=0
             eng.debug_set(k.strip()[6:], int(v))
         else:
             eng.tune_set(k.strip(), int(v))

@@ -97,6 +97,10 @@ typedef struct uvl_model uvl_model_t;
 
 const char* uvl_last_error(void);
 int  uvl_version(void);
+/* The `hipcc --version` line of the compiler that built the library.  Several kernels count their s_waitcnt by hand around inline-asm /
+ * generated loops and are only known-good for the toolchain uvltrack_amd/build.py names (TESTED_HIPCC); the Python binding refuses a library
+ * built by another one unless UVL_ALLOW_UNTESTED_HIPCC=1. */
+const char* uvl_build_toolchain(void);
 
 /* build_model(cfg) (uvltrack.py:47-57): create an empty model for a geometry. */
 uvl_model_t* uvl_create(const uvl_config* cfg);

@@ -51,6 +51,24 @@ def test_tuning_struct_and_no_global_tuning_state(lib):
     assert lib.uvl_tune_set(None, b"gemm_cfg", 3) < 0          # a handle is required
 
 
+def test_library_is_stamped_with_the_tested_toolchain(lib, monkeypatch):
+    """The build refuses another hipcc than build.TESTED_HIPCC (hand-counted waits), stamps the version into the library, and the
+    binding refuses a library with another stamp -- both behind one environment override."""
+    from uvltrack_amd import _native, build
+    assert lib.uvl_build_toolchain().decode() == build.TESTED_HIPCC == build.hipcc_version("/opt/rocm/bin/hipcc")
+    monkeypatch.delenv(build.OVERRIDE_ENV, raising=False)
+    monkeypatch.setattr(build, "TESTED_HIPCC", "HIP version: 0.0.0")
+    with pytest.raises(RuntimeError, match="not the tested toolchain"):
+        build.check_toolchain("/opt/rocm/bin/hipcc")
+    monkeypatch.setattr(_native, "_lib", None)
+    with pytest.raises(_native.NativeLibraryError, match="not by the tested toolchain"):
+        _native.load()
+    monkeypatch.setenv(build.OVERRIDE_ENV, "1")
+    with pytest.warns(UserWarning):
+        assert _native.load() is not None
+    monkeypatch.setattr(_native, "_lib", None)              # the next load() sees the real constant again
+
+
 def test_create_without_gpu_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():

@@ -119,3 +119,19 @@ def test_submodule_weight_changes_invalidate_the_packed_copy():
     v2 = m._weights_version
     m.mark_weights_dirty()
     assert m._weights_version > v2
+    # a tensor OBJECT replaced by attribute assignment / register_parameter is not in the cached flat list: the clock must tick, and
+    # in-place writes to the NEW tensor must then be seen by the version sum
+    m._tensor_versions()                                       # fills the cache
+    v3 = m._weights_version
+    node = m.box_head.conv_cls
+    leaf_owner = next(mod for mod in node.modules() if any(True for _ in mod.parameters(recurse=False)))
+    pname, old = next(iter(leaf_owner.named_parameters(recurse=False)))
+    setattr(leaf_owner, pname, torch.nn.Parameter(old.detach().clone(), requires_grad=False))
+    assert m._weights_version > v3
+    t3 = m._tensor_versions()
+    with torch.no_grad():
+        getattr(leaf_owner, pname).add_(1.0)
+    assert m._tensor_versions() > t3
+    v4 = m._weights_version
+    leaf_owner.register_buffer("extra_buf", torch.zeros(1))
+    assert m._weights_version > v4

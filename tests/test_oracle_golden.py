@@ -35,6 +35,35 @@ def test_oracle_matches_reference_tiny(name):
     _check(name)
 
 
+def _check_torch(name):
+    """oracle/uvl_oracle_torch.py (the ATen-operator form bench.py's cpu_baseline times) against the same reference outputs, same gate"""
+    from oracle import uvl_oracle_torch as OT
+    meta, spec, ref = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    sd = rebuild_weights(meta, spec)
+    out = OT.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"])
+    n = 0
+    for k, v in ref.items():
+        if k == "flag" or k == "prompt_init" or k.startswith("fwd."):
+            continue
+        got = out[k[:-6]][:, :8, :32] if k.endswith(".slice") else out[k]
+        assert got.shape == v.shape, k
+        np.testing.assert_allclose(got, v, atol=ATOL, rtol=0, err_msg="torch oracle %s/%s" % (name, k))
+        n += 1
+    assert n >= 8
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_torch_oracle_matches_reference_tiny(name):
+    _check_torch(name)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["b_z128_x256", "b_z256_x256"])
+def test_torch_oracle_matches_reference_base(name):
+    _check_torch(name)
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("name", [c for c in BIG if c.startswith("b_")])
 def test_oracle_matches_reference_base(name):

@@ -44,7 +44,7 @@ Registers: W fragments v0..v63 (set p, k step s, block jb: 32 p + 16 s + 4 jb), 
 offsets v96..v99, A DMA source offsets v100..v103, A fragment addresses v104..v105 (k step), temporaries v106..v113.
 s[40:41] / s[42:43] A / W address of the tile being requested, s44 tiles left, s45 A row pitch in bytes, s46 bytes of a 16-row block of the packed W (K / 64 x 2048), s47 last valid A row of
 the tile, s48 LDS base, s49 index of the A tile requested next, s50 nk - 1, s51 scratch, s52 index of the W tile requested next,
-s53 LDS base + 1024 * wave, s[56:57] / s[58:59] A / W address of tile 0.
+s53 LDS base + 1024 * wave, s54 the M0 the block found (restored at its end), s[56:57] / s[58:59] A / W address of tile 0.
 
 Usage: python tools/gen/gemm_dr_gen.py [--check]            (writes / compares uvltrack_amd/csrc/gemm_dr_asm.inc)
        python tools/gen/gemm_dr_gen.py --out PATH [--abl nodma,noread,nobar,nowload]   (timing variants, results wrong)"""
@@ -189,6 +189,7 @@ class Gen:
 
     def prologue(self):
         e = self.e
+        e("s_mov_b32 s54, m0")                                             # handed back at the end: hipcc refuses M0 in a clobber list
         e("s_mov_b64 s[56:57], %[ab]")
         e("s_mov_b64 s[58:59], %[wb]")
         e("s_mov_b32 s45, %[lda2]")
@@ -276,6 +277,7 @@ class Gen:
         self.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         self.e("s_nop 15")
         self.e("s_nop 15")
+        self.e("s_mov_b32 m0, s54")
         return self.out
 
 

@@ -1075,7 +1075,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
 //   * counters are monotonic: the host passes the generation of this launch and the arrivals of all earlier launches (uvl_model keeps
 //     both; grids differ from launch to launch), nothing is ever reset -- which is
 //     why graph capture keeps the two-launch form (a replay would repeat the generation);
-//   * every workgroup must be resident at once: the launcher fuses only when the grid fits two workgroups per CU (<= 512).
+//   * every workgroup must be resident at once: the launcher fuses only when the grid fits what the occupancy query says this device
+//     holds of the kernel (512 on a whole MI355X), and only on an 8-XCD, 256-CU device (the barrier's groups are the dispatch order).
 // Both problems of a paired launch (visual rows + the text branch's rider) go through the same barrier.  Same arithmetic, bit for
 // bit, as layernorm(_pair) followed by gemm(_pair): the device functions are the same.
 // ------------------------------------------------------------------------------------------------
@@ -1173,8 +1174,24 @@ hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const Gem
         return p.conv_F == 0 && p.groups <= 1 && p.N % 64 == 0 && p.K % 64 == 0 && p.M > 0 && p.splitk == 1 && !p.accumulate && (p.epi == EPI_BF16 || p.epi == EPI_QKV);
     };
     const int blocks = 8 * ((((a.M + 63) / 64) * (a.N / 64) + 7) / 8) + (b ? 8 * ((((b->M + 63) / 64) * (b->N / 64) + 7) / 8) : 0);
+    // every workgroup of the grid must be resident at once (they spin on the barrier): the limit is what THIS device holds of this kernel
+    // (two workgroups of 64 KB LDS per CU x its CU count: 512 on a whole MI355X, less on a partitioned or CU-masked one), and the
+    // barrier's per-XCD groups assume the 8-XCD dispatch order -- any other device keeps the two-launch form
+    static int resident_limit = -1;
+    if (resident_limit < 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(ln_gemm_pair_kernel<EPI_BF16, 4, 4>), 256, 4 * (64 + 64) * 128) == hipSuccess) {
+            cus = prop.multiProcessorCount;
+            resident_limit = (cus == 256) ? per_cu * cus : 0;
+        } else {
+            (void)hipGetLastError();
+            resident_limit = 0;
+        }
+    }
     const bool ok = bar && plain(a) && (!b || (plain(*b) && b->epi == a.epi)) && pick_plain_cfg(a) == 4 && (!b || pick_plain_cfg(*b) == 4) && ring1_depth(a) == 4 &&
-                    tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0 && (a.M + 63) / 64 < 16 && (!b || (b->M + 63) / 64 < 16) && blocks <= 512 &&
+                    tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0 && (a.M + 63) / 64 < 16 && (!b || (b->M + 63) / 64 < 16) && blocks <= resident_limit &&
                     (la.D == 768 || la.D == 1024) && (!lb || lb->D == la.D) && la.nsplit <= LN_MAX_SLABS && (!lb || (lb->nsplit <= LN_MAX_SLABS && !lb->ct_x)) &&
                     la.y_bf16 == a.A && (!lb || !b || lb->y_bf16 == b->A) && (lb != nullptr) == (b != nullptr);
     *fused = ok;

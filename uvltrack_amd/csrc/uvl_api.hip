@@ -116,7 +116,11 @@ extern "C" void uvl_tuning_init(uvl_tuning* t) {
     for (size_t i = 0; i < sizeof(uvl_tuning) / sizeof(int32_t); ++i) f[i] = -1;
 }
 extern "C" const char* uvl_last_error(void) { return g_err; }
-extern "C" int uvl_version(void) { return 1; }
+extern "C" int uvl_version(void) { return 2; }
+#ifndef UVL_BUILD_TOOLCHAIN
+#define UVL_BUILD_TOOLCHAIN "unknown"
+#endif
+extern "C" const char* uvl_build_toolchain(void) { return UVL_BUILD_TOOLCHAIN; }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -611,7 +615,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // the next visual launch: LN-1 -> QKV, LN-2 -> fc1 -- takes it along (launch_ln_gemm_pair: LayerNorm rows, grid barrier, GEMM tiles
     // in one launch).  Graph capture keeps the two-launch form: the barrier's generation is a launch argument.
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-    hipStreamIsCapturing(s, &cap_status);
+    if (m->fuse_ln && hipStreamIsCapturing(s, &cap_status) != hipSuccess) {      // (only the default-off fused launch needs to know)
+        (void)hipGetLastError();                                                 // do not leave the error for the next launch check
+        cap_status = hipStreamCaptureStatusActive;                               // unknown: keep the two-launch form
+    }
     const bool fuse_ln = B == 1 && m->fuse_ln && m->gbar && cap_status == hipStreamCaptureStatusNone && (paired || skip || reuse);
     struct PendLn { bool on = false, has_b = false; LnParams a, b; double bytes = 0; } pend_ln;
     struct LnGemm { LnParams la, lb; GemmParams ga, gb; bool has_lb, has_gb; unsigned* bar; unsigned gen; unsigned* base; bool fused; };

@@ -72,24 +72,27 @@ class HipEngine:
     def tune_set(self, key: str, value: int):
         """uvl_tune_set on THIS engine's handle (there is no process-global tuning state); -1 restores the heuristic."""
         _native.check(self.lib.uvl_tune_set(self.handle, key.encode(), int(value)), "uvl_tune_set(%s)" % key)
+        self.__dict__.setdefault("_tuning", {})[key] = int(value)
 
     def debug_set(self, key: str, value: int):
-        """uvl_debug_set on this engine's handle: A/B aids that are not launch heuristics (stop_layer, pair_text, fuse_contrast, aux_priority)."""
+        """uvl_debug_set on this engine's handle: A/B aids that are not launch heuristics (stop_layer, pair_text, fuse_contrast, fork_text, fuse_ln)."""
         _native.check(self.lib.uvl_debug_set(self.handle, key.encode(), int(value)), "uvl_debug_set(%s)" % key)
 
     def tuned(self, **kw):
-        """Context manager: `with eng.tuned(gemm_cfg=11): ...` -- the keys are reset to their heuristics on exit, whatever happens."""
+        """Context manager: `with eng.tuned(gemm_cfg=11): ...` -- on exit the keys get back the values they had on entry (tune_set
+        records what this engine's handle holds; an override made earlier, e.g. by bench.py --tune, survives the block), whatever happens."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
+            before = {k: self.__dict__.setdefault("_tuning", {}).get(k, -1) for k in kw}
             try:
                 for k, v in kw.items():
                     self.tune_set(k, v)
                 yield self
             finally:
-                for k in kw:
-                    self.tune_set(k, -1)
+                for k, v in before.items():
+                    self.tune_set(k, v)
         return cm()
 
     # ------------------------------------------------------------------ weights

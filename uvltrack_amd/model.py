@@ -49,6 +49,23 @@ class _Node(nn.Module):
         self._clock.ticks += 1
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
+    # a tensor OBJECT replaced through the nn.Module API (`node.weight = nn.Parameter(...)`, register_parameter / register_buffer) is not
+    # in the cached flat list of UVLTrack._tensor_versions: tick the clock so that the list is rebuilt and the packed copy refreshed
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor) and "_clock" in self.__dict__:
+            self._clock.ticks += 1
+        super().__setattr__(name, value)
+
+    def register_parameter(self, name, param):
+        if "_clock" in self.__dict__:
+            self._clock.ticks += 1
+        return super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent: bool = True):
+        if "_clock" in self.__dict__:
+            self._clock.ticks += 1
+        return super().register_buffer(name, tensor, persistent=persistent)
+
     def _attach(self, dotted: str, tensor: torch.Tensor):
         parts = dotted.split(".")
         node = self
