@@ -39,13 +39,14 @@ def test_forward_matches_reference_fixture(name):
     assert ok, "\n" + fmt_report(rep)
 
 
-@pytest.mark.parametrize("key,value", [("attn_cfg", 10), ("attn_cfg", 8), ("gemm_cfg", 21), ("gemm_cfg", 11), ("gemm_cfg", 16), ("gemm_cfg", 30), ("gemm_cfg", 31), ("gemm_cfg", 34)])
+@pytest.mark.parametrize("key,value", [("attn_cfg", 10), ("attn_cfg", 8), ("gemm_cfg", 21), ("gemm_cfg", 11), ("gemm_cfg", 16), ("gemm_cfg", 30), ("gemm_cfg", 31), ("gemm_dr", 1), ("gemm_dr", 0)])
 @pytest.mark.parametrize("name", ["b_z256_x256_b8", "l_z256_x384"])
 def test_batched_kernel_forms_match_reference_fixture(name, key, value):
     """The kernels of the many-sequence regime pinned to the reference's own outputs: the fixtures' batches are too small for the
     heuristics to pick attn_w64_kernel (64 queries per wave, pass 1 without a running maximum), the producer-wave GEMM, the 256x256 tiles
-    (plain, phase-pipelined, and the four-wave form with the generated K loop: bias / GELU / QKV / residual epilogues) or the 32-wide K stages, so they are forced through the tuning hook and the whole frame is compared with the reference fixture at the
-    gates of the default path (mixed flags, padded text keys masked, one all-padding text in the batch-8 case)."""
+    (plain and phase-pipelined) or the 32-wide K stages, so they are forced through the tuning hook and the whole frame is compared with the
+    reference fixture at the gates of the default path; gemm_dr = 1 puts the direct-to-register GEMM (cfg 36) on the residual epilogue too,
+    gemm_dr = 0 takes it off everything (the batch-8 fixture has the packed weights; the two-sequence one runs its default either way) (mixed flags, padded text keys masked, one all-padding text in the batch-8 case)."""
     meta, spec, ref = load_case(name)
     inp = rebuild_inputs(meta, spec)
     eng = _engine(meta, spec)

@@ -49,7 +49,8 @@ def main():
             lib.uvl_pack_weight(p(w), p(wp), N, K, st)
             y = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
             flops = 2.0 * M * N * K
-            forms = (("auto", {}), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("dr", dict(gemm_cfg=36)))
+            forms = (("auto", {}), ("c30", dict(gemm_cfg=30)), ("c31", dict(gemm_cfg=31)), ("dr", dict(gemm_cfg=36)),
+                     ("c31wt", dict(gemm_cfg=31, res_store=2)), ("drwt", dict(gemm_cfg=36, res_store=2)))
             if os.environ.get("SK_ONLY"):
                 forms = [f for f in forms if f[0] in os.environ["SK_ONLY"].split(",")]
             cases = []

@@ -1254,6 +1254,7 @@ extern "C" int uvl_linear_pk(const void* d_x, const void* d_w, const void* d_w_p
     GemmParams p;
     p.A = (const bf16_t*)d_x; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K;
     p.epi = out_f32 ? 1 : 0; p.C = d_y; p.ldc = N; p.act = act; p.accumulate = accumulate; p.tune = tune;
+    p.c_store = tune_get(tune, &uvl_tuning::res_store, 0);       // cache policy / atomic form of the f32 stores (0 plain; the frame's default is its own)
     p.Wp = (const bf16_t*)d_w_packed;
     HIPCHK(launch_gemm(p, (hipStream_t)stream));
     return UVL_OK;
