@@ -56,6 +56,24 @@ def test_batched_kernel_forms_match_reference_fixture(name, key, value):
     assert ok, "\n" + fmt_report(rep)
 
 
+def test_default_kernel_choice_of_a_many_sequence_frame():
+    """Which kernels a frame of >= 2048 rows runs BY DEFAULT (a heuristic lost in a clean-up once ran the whole round's benchmarks on the
+    old kernels while every forced-form test stayed green): QKV and fc1 on gemm_dr_kernel (cfg 36, packed weights made at
+    finalize), the residual GEMMs (f32 read-modify-write epilogue) on the tile-grid kernels."""
+    meta, spec, ref = load_case("b_z256_x256_b8")
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]), profile=True)
+    torch.cuda.synchronize()
+    by_site = {}
+    for e in eng.profile_entries():
+        by_site.setdefault(e["site"], set()).add(e["kernel"])
+    assert by_site["gemm.qkv"] == {"gemm_dr_kernel<2>"}, by_site["gemm.qkv"]
+    assert by_site["gemm.fc1"] == {"gemm_dr_kernel<0>"}, by_site["gemm.fc1"]
+    assert not any(k.startswith("gemm_dr") for k in by_site["gemm.proj"] | by_site["gemm.fc2"]), (by_site["gemm.proj"], by_site["gemm.fc2"])
+
+
 _oracle_cache = {}
 
 

@@ -948,6 +948,18 @@ static int pick_plain_cfg(const GemmParams& p) {
         auto fill = [](long t) { const long rounds = (t + 255) / 256; return (double)t / (double)(rounds * 256); };
         const long nt256 = p.N / 256;
         const double f256 = fill((long)((p.M + 255) / 256) * nt256), f128 = fill((long)((p.M + 127) / 128) * nt256);
+        // The direct-to-register form (cfg 36, gemm_dr.hip: 128 x 256 tiles on four waves, TWO workgroups per CU, W fragments loaded straight
+        // into registers from the fragment-native weight image): what a tile pays outside its K loop runs under the other workgroup's loop.
+        // Measured beside cfg 30 / 31 and hipBLASLt (profiles/r04_gemm_dr.md): ahead of both with the bias / GELU / QKV epilogues on every
+        // shape of 8 sequences.  uvl_tuning.gemm_dr: 0 = never, 1 = wherever it applies (the f32 epilogue too).
+        {
+            const int want = tune_get(p.tune, &uvl_tuning::gemm_dr, -1);
+            // The f32 read-modify-write epilogue stays with the eight-wave kernels: in isolation cfg 36 wins it from ~400 tiles on (proj of 16 /
+            // 32 UVLTrack-L sequences 41.6 / 64.2 against 44.9 / 71.0 us; 8 sequences = 220 tiles = a single round: 28.3 against 25.0), but in
+            // the frames it loses (interleaved tools/ab_tune.py gemm_dr 2 -1: UVLTrack-L x 8 1156-1157 against 1136-1138 frames/s, UVLTrack-B x 32
+            // 6150-6172 against 6111-6131): 2 x 28 MB of residual traffic per launch, and two workgroups per CU issue it at the same moment.
+            if (want != 0 && p.Wp && p.K % 64 == 0 && (want == 1 || p.epi != EPI_F32)) return 36;
+        }
         const int c256 = 30;
         if (f256 >= 0.8) return c256;
         if (f128 >= 0.8) return 31;
