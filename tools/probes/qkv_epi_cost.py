@@ -3,6 +3,8 @@ Usage (GPU box): python tools/probes/qkv_epi_cost.py"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from uvltrack_amd import _native
+if "--lib" in sys.argv:
+    _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 lib = _native.load()
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -103,6 +103,29 @@ __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Output row m -> (sample b = m / rpb, row inside the sample m % rpb) for the rows of ONE block of at most 32 consecutive rows, without a division per
+// row and lane: the block's first row is divided once (wave-uniform), a row of the block is that plus at most one wrap.  (An integer division by a
+// run-time value is ~40 VALU; the QKV-scatter and residual epilogues did one per stored row group: 4-8 us of a 45-us GEMM, tools/probes/qkv_epi_cost.py.)
+struct RowMap { int b0, rem0, rpb; };
+__device__ __forceinline__ RowMap rowmap_of(int first_row, int rpb) {
+    const int rf = __builtin_amdgcn_readfirstlane(first_row);
+    const int b0 = rf / rpb;
+    return RowMap{b0, rf - b0 * rpb, rpb};
+}
+// r = row - first_row, 0 <= r <= 32; exact for rpb > 32, and for any rpb through the division
+__device__ __forceinline__ void rowmap_at(const RowMap& m, int first_row, int r, int& b, int& rem) {
+    if (m.rpb > 32) {
+        const int rr = m.rem0 + r;
+        const bool wrap = rr >= m.rpb;
+        b = m.b0 + (wrap ? 1 : 0);
+        rem = rr - (wrap ? m.rpb : 0);
+    } else {
+        const int row = first_row + r;
+        b = row / m.rpb;
+        rem = row - b * m.rpb;
+    }
+}
+
 // MFMA 32x32x16 bf16 C/D fragment: register r of lane l holds
 //   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

@@ -54,7 +54,8 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
             __builtin_amdgcn_sched_barrier(0);
             const int rowl = m0 + ib * 16 + l15;
             if (rowl < p.M) {
-                const int b = rowl / p.rpb, rem = rowl - b * p.rpb;
+                int b, rem;
+                rowmap_at(rowmap_of(m0 + ib * 16, p.rpb), m0 + ib * 16, l15, b, rem);
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {
                     const int col = colw + 16 * jb + 4 * g;
@@ -102,10 +103,11 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
     f32x4 ov[1][EPI == EPI_F32 ? NIT : 1], tv[1][EPI == EPI_F32 ? NIT : 1];
     auto res_dst = [&](int i, int it, bool& inb) __attribute__((always_inline)) -> float* {
         const int r = it * RPI + lane / LPR;
+        const int rfirst = min(m0 + i * 32, p.M - 1);
         const int row = m0 + i * 32 + r;
         inb = row < p.M;
-        const int rc = inb ? row : p.M - 1;
-        const int b = rc / p.rpb, rem = rc - b * p.rpb;
+        int b, rem;
+        rowmap_at(rowmap_of(rfirst, p.rpb), rfirst, inb ? row - rfirst : p.M - 1 - rfirst, b, rem);      // rows past M read the last valid one
         return reinterpret_cast<float*>(p.C) + ((size_t)b * p.obs + p.oro + rem) * p.ldc + colw + (lane % LPR) * 4;
     };
     auto load_res = [&](int i) __attribute__((always_inline)) {
@@ -121,7 +123,9 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int r = it * RPI + lane / LPR, row = m0 + i * 32 + r;
-                    const int rc = row < p.M ? row : p.M - 1, rem = rc - (rc / p.rpb) * p.rpb;
+                    const int rfirst = min(m0 + i * 32, p.M - 1);
+                    int bt, rem;
+                    rowmap_at(rowmap_of(rfirst, p.rpb), rfirst, (row < p.M ? row : p.M - 1) - rfirst, bt, rem);
                     tv[0][it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + colw + (lane % LPR) * 4);
                 }
             }
@@ -155,7 +159,8 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                     if (EPI == EPI_BF16) {
                         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col) = v;
                     } else {
-                        const int b = row / p.rpb, rem = row - b * p.rpb;
+                        int b, rem;
+                        rowmap_at(rowmap_of(m0 + i * 32, p.rpb), m0 + i * 32, r, b, rem);
                         const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
                         const int hh = cc >> 6, dd = cc & 63;
                         *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;
@@ -226,14 +231,25 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
 
     float* sbias = reinterpret_cast<float*>(smem + DR_LDS_BIAS);
     if (wave == 0) *reinterpret_cast<f32x4*>(sbias + lane * 4) = *reinterpret_cast<const f32x4*>((p.bias ? p.bias + n0 : reinterpret_cast<const float*>(g_zero_page)) + lane * 4);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int lda2 = p.lda * 2, ldw2 = nk * 2048, rmax = min(BM, p.M - m0) - 1;      // rows past M re-read the last valid one (never stored)
+    // every "s" operand of the block is made wave-uniform EXPLICITLY: with enough scalar values live across the statement hipcc hands an "s"
+    // constraint a VGPR (seen when an epilogue experiment grew: `s_mov_b64 s[56:57], v[118:119]`, which -S prints and only the assembler refuses)
+    auto pin64 = [](const char* q) __attribute__((always_inline)) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    a_base = pin64(a_base);
+    w_base = pin64(w_base);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const int lda2 = __builtin_amdgcn_readfirstlane(p.lda * 2), ldw2 = __builtin_amdgcn_readfirstlane(nk * 2048);
+    const int rmax = __builtin_amdgcn_readfirstlane(min(BM, p.M - m0) - 1);      // rows past M re-read the last valid one (never stored)
+    const int nk_s = __builtin_amdgcn_readfirstlane(nk);
 #if __HIP_DEVICE_COMPILE__              // the host pass of hipcc parses kernel bodies too and knows no gfx950 register names
     asm volatile(
 #include "gemm_dr_asm.inc"
         : "+{a[0:15]}"(accv[0]), "+{a[16:31]}"(accv[1]), "+{a[32:47]}"(accv[2]), "+{a[48:63]}"(accv[3]),
           "+{a[64:79]}"(accv[4]), "+{a[80:95]}"(accv[5]), "+{a[96:111]}"(accv[6]), "+{a[112:127]}"(accv[7])
-        : [tid] "v"(tid), [ab] "s"(a_base), [wb] "s"(w_base), [lda2] "s"(lda2), [ldw2] "s"(ldw2), [rmax] "s"(rmax), [nk] "s"(nk), [lds] "s"(lds0), [wave] "s"(wave)
+        : [tid] "v"(tid), [ab] "s"(a_base), [wb] "s"(w_base), [lda2] "s"(lda2), [ldw2] "s"(ldw2), [rmax] "s"(rmax), [nk] "s"(nk_s), [lds] "s"(lds0), [wave] "s"(wave)
         : "memory", "scc", GEMM_DR_SGPRS, GEMM_DR_VGPRS);
 #endif
     if (EPI == EPI_BF16 && p.act == 1) gemm_epilogue_dr<EPI, 1>(p, accv, smem, sbias, m0, n0, lane, wave);

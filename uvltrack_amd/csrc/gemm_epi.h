@@ -50,9 +50,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
         if (vpart) {
 #pragma unroll
             for (int hi = 0; hi < (L16 ? 2 : 1); ++hi) {
-                const int rowl = m0 + wm * WM + i * 32 + (L16 ? 16 * hi + (lane & 15) : (lane & 31));
+                const int rfirst = m0 + wm * WM + i * 32, rl = L16 ? 16 * hi + (lane & 15) : (lane & 31);
+                const int rowl = rfirst + rl;
                 if (rowl < p.M) {
-                    const int b = rowl / p.rpb, rem = rowl - b * p.rpb;
+                    int b, rem;
+                    rowmap_at(rowmap_of(rfirst, p.rpb), rfirst, rl, b, rem);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -104,13 +106,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 f32x4 v[CH], tv[CH], ov[CH];
                 float* dst[CH];
                 bool inb[CH];
+                const int rfirst = min(m0 + wm * WM + i * 32, p.M - 1);      // a block past M reads (and never stores) the last valid row
+                const RowMap rmap = rowmap_of(rfirst, p.rpb);
 #pragma unroll
                 for (int it = 0; it < CH; ++it) {
                     const int r = (h0 + it) * RPI + lane / LPR;
                     const int row = m0 + wm * WM + i * 32 + r;
                     inb[it] = row < p.M;
-                    const int rc = inb[it] ? row : p.M - 1;
-                    const int b = rc / p.rpb, rem = rc - b * p.rpb;
+                    int b, rem;
+                    rowmap_at(rmap, rfirst, (inb[it] ? row : p.M - 1) - rfirst, b, rem);
                     v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
                     dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
                     if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
@@ -144,7 +148,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     if (EPI == EPI_BF16) {
                         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + (size_t)g * p.N + col) = v;
                     } else {
-                        const int b = row / p.rpb, rem = row - b * p.rpb;
+                        int b, rem;
+                        rowmap_at(rowmap_of(m0 + wm * WM + i * 32, p.rpb), m0 + wm * WM + i * 32, r, b, rem);
                         const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
                         const int hh = cc >> 6, dd = cc & 63;
                         *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;
