@@ -252,9 +252,12 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
         : [tid] "v"(tid), [ab] "s"(a_base), [wb] "s"(w_base), [lda2] "s"(lda2), [ldw2] "s"(ldw2), [rmax] "s"(rmax), [nk] "s"(nk_s), [lds] "s"(lds0), [wave] "s"(wave)
         : "memory", "scc", GEMM_DR_SGPRS, GEMM_DR_VGPRS);
 #endif
-    if (EPI == EPI_BF16 && p.act == 1) gemm_epilogue_dr<EPI, 1>(p, accv, smem, sbias, m0, n0, lane, wave);
-    else if (EPI == EPI_BF16 && p.act == 2) gemm_epilogue_dr<EPI, 2>(p, accv, smem, sbias, m0, n0, lane, wave);
-    else gemm_epilogue_dr<EPI, 0>(p, accv, smem, sbias, m0, n0, lane, wave);
+    // the epilogue takes its lane index from the hardware again: the block clobbers v0..v113, and every per-lane value the compiler keeps
+    // across it has to live in the 14 registers above (one more was a spill = scratch for the whole kernel)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (EPI == EPI_BF16 && p.act == 1) gemm_epilogue_dr<EPI, 1>(p, accv, smem, sbias, m0, n0, lane_e, wave);
+    else if (EPI == EPI_BF16 && p.act == 2) gemm_epilogue_dr<EPI, 2>(p, accv, smem, sbias, m0, n0, lane_e, wave);
+    else gemm_epilogue_dr<EPI, 0>(p, accv, smem, sbias, m0, n0, lane_e, wave);
 }
 
 template <int EPI>
