@@ -244,6 +244,7 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
     const int lda2 = __builtin_amdgcn_readfirstlane(p.lda * 2), ldw2 = __builtin_amdgcn_readfirstlane(nk * 2048);
     const int rmax = __builtin_amdgcn_readfirstlane(min(BM, p.M - m0) - 1);      // rows past M re-read the last valid one (never stored)
     const int nk_s = __builtin_amdgcn_readfirstlane(nk);
+    (void)a_base; (void)w_base; (void)lds0; (void)lda2; (void)ldw2; (void)rmax; (void)nk_s;      // (the host pass does not see the asm statement that reads them)
 #if __HIP_DEVICE_COMPILE__              // the host pass of hipcc parses kernel bodies too and knows no gfx950 register names
     asm volatile(
 #include "gemm_dr_asm.inc"
