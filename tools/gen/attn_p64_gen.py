@@ -598,7 +598,7 @@ def generate(trace=False):
     else:
         # the block writes M0 for its LDS-DMA; hipcc refuses M0 in a clobber list ("reserved register"), so the block hands back the value it
         # found -- the compiler-scheduled code behind it (attn_w64_item, the exact pass) issues LDS-DMA through the builtin
-        a.e("s_mov_b32 s100, m0")
+        a.e("s_mov_b32 s38, m0")
     # ---- operands -> fixed registers
     for n in ("q", "k", "vt", "ka", "o"):
         a.e("s_mov_b64 %s, %%[%s]" % (s2(n), n))
@@ -772,7 +772,7 @@ def generate(trace=False):
     if trace:
         a.e("s_dcache_wb")
     else:
-        a.e("s_mov_b32 m0, s100")
+        a.e("s_mov_b32 m0, s38")
     a.e("s_mov_b64 %[bad], " + s2("bad"))
     return a.lines
 

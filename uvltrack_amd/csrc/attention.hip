@@ -1255,7 +1255,7 @@ static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
 // every register attn_p64_asm.inc names: s38..s101 (its fixed scalar map; hipcc keeps its operands below) and all 256 VGPRs
 #define ATTN_R4(p, n) p #n "0", p #n "1", p #n "2", p #n "3"
 #define ATTN_R10(p, n) p #n "0", p #n "1", p #n "2", p #n "3", p #n "4", p #n "5", p #n "6", p #n "7", p #n "8", p #n "9"
-#define ATTN_P64_SGPRS "s38", "s39", ATTN_R10("s", 4), ATTN_R10("s", 5), ATTN_R10("s", 6), ATTN_R10("s", 7), ATTN_R10("s", 8), ATTN_R10("s", 9), "s100", "s101"
+#define ATTN_P64_SGPRS "s38", "s39", ATTN_R10("s", 4), ATTN_R10("s", 5), ATTN_R10("s", 6), ATTN_R10("s", 7), ATTN_R10("s", 8), ATTN_R10("s", 9)
 #define ATTN_P64_VGPRS "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", ATTN_R10("v", 1), ATTN_R10("v", 2), ATTN_R10("v", 3), ATTN_R10("v", 4), \
     ATTN_R10("v", 5), ATTN_R10("v", 6), ATTN_R10("v", 7), ATTN_R10("v", 8), ATTN_R10("v", 9), ATTN_R10("v", 10), ATTN_R10("v", 11), ATTN_R10("v", 12), \
     ATTN_R10("v", 13), ATTN_R10("v", 14), ATTN_R10("v", 15), ATTN_R10("v", 16), ATTN_R10("v", 17), ATTN_R10("v", 18), ATTN_R10("v", 19), ATTN_R10("v", 20), \
@@ -1282,7 +1282,11 @@ __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, co
           [q] "s"(p.q), [k] "s"(p.k), [vt] "s"(p.vt), [ka] "s"(p.key_add), [o] "s"(p.o), [N] "s"(p.N), [Npad] "s"(p.Npad), [H] "s"(p.H),
           [total] "s"(total), [cnt] "s"(cnt), [v] "s"(v0), [G] "s"(G), [kas] "s"(kas), [wave] "s"(wave), [lds] "s"(lds0), [nqb] "s"(nqb),
           [mq] "s"(mq), [mh] "s"(mh)
-        : "memory", "vcc", "scc", ATTN_P64_SGPRS, ATTN_P64_VGPRS);
+        : "memory", "vcc", "scc", ATTN_P64_SGPRS, ATTN_P64_VGPRS
+#ifdef ATTN_WGTRACE
+          , "s100", "s101"
+#endif
+        );
 #endif
 #ifdef ATTN_P64_NOFALLBACK      // timing probes whose pass 1 is wrong by construction: never take the exact pass
     return;
