@@ -74,6 +74,48 @@ def test_default_kernel_choice_of_a_many_sequence_frame():
     assert not any(k.startswith("gemm_dr") for k in by_site["gemm.proj"] | by_site["gemm.fc2"]), (by_site["gemm.proj"], by_site["gemm.fc2"])
 
 
+@pytest.mark.parametrize("forms", [{}, {"gemm_cfg": 31}, {"gemm_cfg": 30}, {"attn_cfg": 11}, {"gemm_cfg": 31, "attn_cfg": 11}], ids=lambda f: "+".join("%s%d" % kv for kv in f.items()) or "default")
+def test_text_riders_of_a_many_sequence_frame_match_reference_fixture(forms):
+    """uvl_debug_set("pair_text", 2): in a frame of >= 2048 visual rows the text branch has no stream and no launches of its own -- its GEMMs ride
+    behind the visual tiles (gemm_dr_pair_kernel for QKV / intermediate, gemm_pipe_pair_kernel for the residual GEMMs where the visual problem
+    takes cfg 30 / 31), its attention items behind the persistent walk (attn_p64_rider_kernel where the visual attention takes cfg 11), its
+    LayerNorm rows in ln_pair_kernel.  The batch-8 fixture's own heuristics pick the 64 x 128 grid for the residual GEMMs and the streaming
+    attention kernel, so those pair forms are forced through the tuning hook; every variant is compared with the reference's outputs at the
+    gates of the default path, and the profile must show that the pair kernels ran."""
+    meta, spec, ref = load_case("b_z256_x256_b8")
+    inp = rebuild_inputs(meta, spec)
+    eng = _engine(meta, spec)
+    eng.debug_set("pair_text", 2)
+    try:
+        with eng.tuned(**forms):
+            got = _run(eng, inp)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]), profile=True)
+            torch.cuda.synchronize()
+            by_site = {}
+            for e in eng.profile_entries():
+                by_site.setdefault(e["site"], set()).add(e["kernel"])
+            if not forms:                      # the frame is a single-stream one now: ONE graph, bit-identical to the eager launches
+                st, outs = eng.capture(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
+                eng.replay()
+                eng.replay()
+                torch.cuda.synchronize()
+                for k in ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "text"):
+                    np.testing.assert_array_equal(outs[k].cpu().numpy(), got[k])
+    finally:
+        eng.debug_set("pair_text", 1)
+    ok, rep = compare_outputs(got, ref, depth=spec.depth)
+    assert ok, "\n" + fmt_report(rep)
+    if "gemm_cfg" not in forms:
+        assert "gemm_dr_pair_kernel<2>" in by_site["gemm.qkv"] and "gemm_dr_pair_kernel<0>" in by_site["gemm.fc1"], by_site
+    else:
+        want = "gemm_pipe_pair_kernel<%d,1>" % (128 if forms["gemm_cfg"] == 31 else 256)
+        assert want in by_site["gemm.proj"] and want in by_site["gemm.fc2"], by_site
+    if "attn_cfg" in forms:
+        assert "attn_p64_rider_kernel" in by_site["attention"], by_site["attention"]
+    assert any(k.startswith("ln_pair_kernel") for k in by_site["layernorm"]), by_site["layernorm"]
+
+
 _oracle_cache = {}
 
 

@@ -1260,8 +1260,7 @@ static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
     ATTN_R10("v", 5), ATTN_R10("v", 6), ATTN_R10("v", 7), ATTN_R10("v", 8), ATTN_R10("v", 9), ATTN_R10("v", 10), ATTN_R10("v", 11), ATTN_R10("v", 12), \
     ATTN_R10("v", 13), ATTN_R10("v", 14), ATTN_R10("v", 15), ATTN_R10("v", 16), ATTN_R10("v", 17), ATTN_R10("v", 18), ATTN_R10("v", 19), ATTN_R10("v", 20), \
     ATTN_R10("v", 21), ATTN_R10("v", 22), ATTN_R10("v", 23), ATTN_R10("v", 24), "v250", "v251", "v252", "v253", "v254", "v255"
-__global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_p64_walk(const AttnParams& p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh, char* smem) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int v0 = (int)blockIdx.x, G = (int)gridDim.x;
@@ -1291,7 +1290,7 @@ __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, co
 #ifdef ATTN_P64_NOFALLBACK      // timing probes whose pass 1 is wrong by construction: never take the exact pass
     return;
 #endif
-    if (bad == 0) return;
+    if (bad == 0) return;                   // (wave-uniform: the flag word is an SGPR pair)
     int it = 0;
     for (int v = v0; v < 8 * cnt; v += G) {
         int qb, h, b;
@@ -1301,17 +1300,52 @@ __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, co
     }
 }
 
-static hipError_t launch_attn_p64(const AttnParams& p_in, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * 16384 + (size_t)4 * 4 * 256 + 16;
-    const int nt = (p_in.N + 63) / 64;
-    if (!p_in.q_prescaled || nt < 2) return launch_attn_w64<4>(p_in, s);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_p64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+__global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
+}
+
+// The persistent walk with a RIDER: a second attention problem of few keys (the text branch of a many-sequence frame: B x H items of 40 x 40)
+// whose items are taken by workgroups once their own walk is done -- no launch and no second queue for them.  `tail_only`: every workgroup
+// walks exactly one 256-query item and the items of the last query block are short (UVLTrack-L, N = 873: 105 of 256 queries), so those
+// B x H workgroups take one rider item each and the kernel ends when the full-length items end; otherwise the rider's items go round-robin,
+// last workgroup first.
+__global__ __launch_bounds__(256, 2) void attn_p64_rider_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh,
+                                                                const AttnParams pb, const int tail_only) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
+    const int nqb_b = (pb.N + 127) / 128, total_b = nqb_b * pb.H * pb.B;
+    int first = (int)gridDim.x - 1 - (int)blockIdx.x, step = (int)gridDim.x;      // round-robin from the END of the grid: the walk gives the low indices one item more
+    if (tail_only) {
+        int qb, h, b;
+        if (!attn_decode_block((int)blockIdx.x, total, nqb, p.H, true, qb, h, b) || qb != nqb - 1) return;
+        first = h + p.H * b;
+        step = p.H * p.B;
     }
-    g_last_kernel = "attn_p64_kernel";
+    for (int t = first; t < total_b; t += step) {
+        __syncthreads();                    // the walk's (or the previous item's) last LDS reads are done before the ring is refilled
+        const int qb = t % nqb_b, r = t / nqb_b;
+        attn_body<4, 1, 2>(pb, qb, r % pb.H, r / pb.H, smem);
+    }
+}
+
+// rider = nullptr: the plain kernel
+static hipError_t launch_attn_p64(const AttnParams& p_in, hipStream_t s, const AttnParams* rider = nullptr) {
+    constexpr size_t lds = (size_t)4 * 16384 + (size_t)4 * 4 * 256 + 16;
+    static_assert(lds >= 4 * 34 * 64 * 4 && lds >= 2 * (8192 + 8192 + 256 + 16), "the rider's attn_body<4,1,2> fits");
+    const int nt = (p_in.N + 63) / 64;
+    if (!p_in.q_prescaled || nt < 2) {
+        const hipError_t e = launch_attn_w64<4>(p_in, s);
+        return (e != hipSuccess || !rider) ? e : launch_attention(*rider, s);
+    }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[rider ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(rider ? reinterpret_cast<const void*>(attn_p64_rider_kernel) : reinterpret_cast<const void*>(attn_p64_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[rider ? 1 : 0] = true;
+    }
+    g_last_kernel = rider ? "attn_p64_rider_kernel" : "attn_p64_kernel";
     const int nqb = (nt + 3) / 4;
     const int total = nqb * p_in.H * p_in.B, cnt = (total + 7) / 8;
     int wgs = tune_get(p_in.tune, &uvl_tuning::attn_wgs, 512);          // persistent workgroups (two per CU)
@@ -1321,7 +1355,13 @@ static hipError_t launch_attn_p64(const AttnParams& p_in, hipStream_t s) {
     auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
     AttnParams p = p_in;
     p.xcd_map = 1;
-    hipLaunchKernelGGL(attn_p64_kernel, dim3(grid), dim3(256), lds, s, p, total, cnt, nqb, magic(nqb), magic(p_in.H));
+    if (rider) {
+        // one item per workgroup and a short last query block: the workgroups of those items have the time for the rider
+        const int tail_only = (grid == 8 * cnt && nqb >= 2 && p.N - (nqb - 1) * 256 <= 160) ? 1 : 0;
+        hipLaunchKernelGGL(attn_p64_rider_kernel, dim3(grid), dim3(256), lds, s, p, total, cnt, nqb, magic(nqb), magic(p_in.H), *rider, tail_only);
+    } else {
+        hipLaunchKernelGGL(attn_p64_kernel, dim3(grid), dim3(256), lds, s, p, total, cnt, nqb, magic(nqb), magic(p_in.H));
+    }
     return hipGetLastError();
 }
 
@@ -1417,6 +1457,7 @@ hipError_t launch_attention_pair(const AttnParams& a, const AttnParams& b, hipSt
         case 7: return launch_attn_pair_cfg<2, 4, 2>(a, b, s);
         case 5: if (ntb <= 6) return launch_attn_pair_cfg<1, 6, 1>(a, b, s); break;
         case 6: if (ntb <= 9) return launch_attn_pair_cfg<1, 9, 1>(a, b, s); break;
+        case 11: return launch_attn_p64(a, s, &b);         // many sequences: the rider's items behind the persistent walk
         default: break;
     }
     const hipError_t e = launch_attention(a, s);

@@ -826,6 +826,50 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     }
 }
 
+// The same for the eight-wave tiles of many-sequence frames (residual GEMMs: f32 read-modify-write epilogue): problem A on 256 x 256
+// (BMA = 256, cfg 30) or 128 x 256 tiles (cfg 31), the rider -- a few hundred text rows -- on 128 x 256 tiles behind them.  A's grid is a
+// single round of at most 256 workgroups on the shapes that take these kernels, and the rider's 9-30 tiles fit beside it.
+template <int BMA, int EPI>
+__global__ __launch_bounds__(512) void gemm_pipe_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= blocks_b) {              // the rider's workgroups first (see gemm_dr_pair_kernel)
+        if constexpr (BMA == 256) gemm_pipe_body<256, EPI, 1, true>(pa, (int)blockIdx.x - blocks_b, smem);
+        else gemm_pipe128_body<EPI, true>(pa, (int)blockIdx.x - blocks_b, smem);
+    } else {
+        gemm_pipe128_body<EPI, true>(pb, blockIdx.x, smem);
+    }
+}
+
+static bool pipe_ok(const GemmParams& p) { return p.M > 0 && p.N % 256 == 0 && p.K >= 128 && p.K % 64 == 0 && p.splitk <= 1 && p.conv_F == 0 && p.groups <= 1; }
+
+template <int BMA, int EPI>
+static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
+    GemmParams a = a_in, b = b_in;
+    if (!pipe_ok(a) || !pipe_ok(b)) return hipErrorInvalidValue;
+    auto grid = [](GemmParams& p, int BM) {
+        const int MT = (p.M + BM - 1) / BM, NT = p.N / 256;
+        p.group_m = MT >= 16 ? 8 : MT;
+        const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
+        if (forced_gm > 0) p.group_m = forced_gm;
+        return 8 * ((MT * NT + 7) / 8);
+    };
+    const int ba = grid(a, BMA), bb = grid(b, 128);
+    constexpr size_t lds = 3 * (size_t)(128 + 256) * 128 + 1024;      // the larger of the two bodies' needs (cfg 31's three buffers)
+    static_assert(lds >= 2 * (size_t)(256 + 256) * 128 + 1024, "cfg 30's two buffers fit");
+    auto kern = gemm_pipe_pair_kernel<BMA, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[48];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_pair_kernel<%d,%d>", BMA, EPI);
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(512), lds, s, a, b, bb);
+    return hipGetLastError();
+}
+
 // K-slice map (see gemm_glds_body): a split-K GEMM with few M tiles whose slices and N panels divide over the 8 XCDs
 static bool gemm_kxcd_ok(const GemmParams& p, int MT, int NT) {
     return tune_get(p.tune, &uvl_tuning::gemm_kxcd, 1) && p.splitk > 1 && 8 % p.splitk == 0 && NT % (8 / p.splitk) == 0 && MT < 16 && p.conv_F == 0 && p.groups <= 1;
@@ -1027,6 +1071,15 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
     const bool pairable = plain(a) && plain(b) && a.epi == b.epi && pick_plain_cfg(a) == 4 && pick_plain_cfg(b) == 4 &&
                           tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0 && (a.M + 63) / 64 < 16 && (b.M + 63) / 64 < 16;
     if (!pairable) {
+        // many-sequence frames: the visual problem on one of the large-tile kernels, the rider on the same kernel's 128 x 256 tiles
+        if (plain(a) && plain(b) && a.epi == b.epi && a.splitk == 1 && b.splitk == 1 && a.N % 256 == 0 && a.K >= 128 && tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0) {
+            const int cfg = pick_plain_cfg(a);
+            if (cfg == 36 && gemm_dr_pairable(a, b)) return launch_gemm_dr_pair(a, b, s);
+            if (a.epi == EPI_F32 && pipe_ok(a) && pipe_ok(b)) {
+                if (cfg == 30) return launch_pipe_pair<256, EPI_F32>(a, b, s);
+                if (cfg == 31) return launch_pipe_pair<128, EPI_F32>(a, b, s);
+            }
+        }
         const hipError_t e = launch_gemm(a, s);
         return e != hipSuccess ? e : launch_gemm(b, s);
     }

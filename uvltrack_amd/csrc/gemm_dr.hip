@@ -291,6 +291,61 @@ static hipError_t launch_dr(const GemmParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Two GEMMs of the same epilogue in one launch (many-sequence frames: the text branch's QKV / intermediate GEMM rides behind the visual
+// one's).  The RIDER's workgroups come first, [0, blocks_b): its weights are read once per frame by three row tiles, so its K loop runs at
+// HBM latency and a rider tile lives longer than a visual one -- dispatched last it was the launch's tail (+6 us on the QKV launch of
+// 8 UVLTrack-L sequences), dispatched first it ends under the visual rounds.  blocks_b is a multiple of 8: both tile maps keep their
+// workgroup -> XCD relation.  Two calls, not a selected reference (see gemm_glds_pair_kernel).
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_dr_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= blocks_b) gemm_dr_body<EPI>(pa, (int)blockIdx.x - blocks_b, smem);
+    else gemm_dr_body<EPI>(pb, blockIdx.x, smem);
+}
+
+static bool dr_ok(const GemmParams& p) {
+    return p.Wp && p.M > 0 && p.N % 256 == 0 && p.K >= 64 && p.K % 64 == 0 && p.splitk <= 1 && p.conv_F == 0 && p.groups <= 1;
+}
+
+static int dr_grid(GemmParams& p) {
+    const int MT = (p.M + 127) / 128, NT = p.N / 256;
+    p.group_m = MT >= 16 ? 8 : MT;
+    const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
+    if (forced_gm > 0) p.group_m = forced_gm;
+    return 8 * ((MT * NT + 7) / 8);
+}
+
+template <int EPI>
+static hipError_t launch_dr_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
+    GemmParams a = a_in, b = b_in;
+    if (!dr_ok(a) || !dr_ok(b)) return hipErrorInvalidValue;
+    const int ba = dr_grid(a), bb = dr_grid(b);
+    auto kern = gemm_dr_pair_kernel<EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DR_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static char name[48];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_dr_pair_kernel<%d>", EPI);
+    g_last_kernel = name;
+    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(256), DR_LDS_BYTES, s, a, b, bb);
+    return hipGetLastError();
+}
+
+bool gemm_dr_pairable(const GemmParams& a, const GemmParams& b) { return dr_ok(a) && dr_ok(b) && a.epi == b.epi; }
+
+hipError_t launch_gemm_dr_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
+    if (a.epi != b.epi) return hipErrorInvalidValue;
+    switch (a.epi) {
+        case EPI_BF16: return launch_dr_pair<EPI_BF16>(a, b, s);
+        case EPI_F32: return launch_dr_pair<EPI_F32>(a, b, s);
+        case EPI_QKV: return launch_dr_pair<EPI_QKV>(a, b, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gemm_dr(const GemmParams& p, int epi, hipStream_t s) {
     switch (epi) {
         case EPI_BF16: return launch_dr<EPI_BF16>(p, s);

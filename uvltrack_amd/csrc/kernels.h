@@ -86,6 +86,8 @@ hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream
 // two launches where the fused form does not apply.  bar: 4 KB of zero-initialised device memory owned by the model, gen: 1, 2, 3, ..., *base: arrivals per group so far (updated)
 hipError_t launch_pack_w_dr(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);   // [N, K] -> fragment-native image (same size)
 hipError_t launch_gemm_dr(const GemmParams& p, int epi, hipStream_t s);      // gemm_dr.hip: 128 x 256 on four waves, two workgroups per CU, W straight into registers (cfg 36)
+bool gemm_dr_pairable(const GemmParams& a, const GemmParams& b);
+hipError_t launch_gemm_dr_pair(const GemmParams& a, const GemmParams& b, hipStream_t s);   // both problems on cfg 36, one launch (b = the text rider)
 hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const GemmParams& a, const GemmParams* b, unsigned* bar, unsigned gen, unsigned* base, bool* fused, hipStream_t s);   // two independent problems, one launch
 
 // set-up + BERT embedding + im2row of a single-stream frame in one launch (rowops.hip::prologue_kernel)

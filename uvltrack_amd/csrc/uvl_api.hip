@@ -88,7 +88,8 @@ struct uvl_model {
     bf16_t *pr_w1 = nullptr, *pr_w2 = nullptr;
     // streams / events
     hipStream_t aux = nullptr;                   // text-branch stream (frames of several sequences)
-    int pair_text = 1;                           // uvl_debug_set("pair_text", 0): text branch on its own stream even for one sequence
+    int pair_text = 1;                           // uvl_debug_set("pair_text", v): 0 = the text branch always on its own stream, 1 = riders for one sequence and for the
+                                                 // many-sequence frames text_rides() lists, 2 = riders wherever the pair forms exist, 3 = one sequence only (A/B)
     int text_dr_res = 0;                         // uvl_debug_set("text_dr_res", 1): the text branch's residual GEMMs (12 tiles) on gemm_dr_kernel too (A/B)
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
@@ -565,6 +566,24 @@ static int run_prompter(uvl_model* m, const Workspace& w, int B, const float* te
 // rolled by half a batch, two-channel cont_score.
 struct TrainBranch { const uint8_t* template_mask; const uint8_t* context_mask; float* prompts_out; };
 
+// Does the text branch ride in the visual launches (single-stream frame), or run on its own stream?
+// One sequence: always (unless pair_text = 0).  Many sequences: only where the visual GEMMs take the large-tile kernels, which have pair forms
+// (launch_gemm_pair), and by default only where the riders measured ahead of the second stream (interleaved tools/ab_tune.py debug.pair_text 3 1,
+// profiles/r04_text_branch.md): UVLTrack-L x 8 / 16 / 32 +1.9 / +1.4 / +0.3 %, UVLTrack-B x 32 +1.3..1.8 %, but UVLTrack-B x 12 / 16 -1.0 % (a rider tile
+// streams its BERT weights at HBM latency -- three to ten row tiles per weight panel -- and holds its slot about twice as long as a visual
+// tile; the six-layer branch of UVLTrack-B hides better on the second stream until the frame is long).
+static bool text_rides(const uvl_model* m, int B, int skip, int reuse) {
+    if (skip || reuse || m->nf <= 0 || !m->pair_text) return false;
+    if (B == 1) return true;
+    if (m->pair_text == 3) return false;
+    const long rows = (long)B * m->nv;
+    const bool forms = rows >= 2048 && !m->bert.empty() && m->bert[0].pqkv && tune_get(&m->tune, &uvl_tuning::gemm_dr, -1) != 0 &&
+                       tune_get(&m->tune, &uvl_tuning::gemm_pipe, 1) != 0 && m->tune.text_cfg < 0;
+    if (!forms) return false;
+    if (m->pair_text >= 2) return true;
+    return rows >= 6000 && (m->D >= 1024 || rows >= 16000) && m->tune.gemm_cfg < 0 && m->tune.attn_cfg < 0;
+}
+
 static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, hipStream_t s, Profiler* prof,
                        int parts = PART_ALL, const TrainBranch* tb = nullptr) {
     if (!m || !in || !out) return fail(UVL_EINVAL, "null argument");
@@ -592,7 +611,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // attention with attention, LayerNorm with LayerNorm -- the two layer structures line up op for op), so the 40-token branch
     // costs neither launches nor a second queue; measured, the two-stream form slows each visual layer by ~11 us through
     // contention and ends level with visual layer nf-1 (profiles/r01_summary.md).  Larger batches keep the second stream.
-    const bool paired = !skip && !reuse && m->nf > 0 && m->pair_text && B == 1;
+    // Many sequences (uvl_debug_set "pair_text" 2): the same riders on the large-tile kernels -- the text GEMMs' 12-48 tiles behind the visual
+    // tiles of gemm_dr_pair_kernel / gemm_pipe_pair_kernel, the 40 x 40 attention items behind the persistent walk (attn_p64_rider_kernel),
+    // the LayerNorm rows in ln_pair_kernel; in-place residual epilogue for the text rows (no split-K slabs).
+    const bool paired = text_rides(m, B, skip, reuse);
+    const bool paired_many = paired && B > 1;
     // The text branch of a many-sequence frame (B x T rows: 320 at 8 sequences) overlaps the visual layers on the second stream, and what it
     // costs the frame is the CU time of its workgroups: as 64 x 64 tiles (240 workgroups of ~6 us per GEMM at ~15 % MFMA efficiency) that was
     // 8 % of the UVLTrack-L x 8 frame (1241 against 1351 frames/s without the branch).  On gemm_dr_kernel's 128 x 256 tiles the same GEMM is
@@ -781,7 +804,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 p.q = w.Tq; p.k = w.Tk; p.vt = w.Tvt; p.key_add = w.bert_add; p.key_add_stride = 64; p.o = w.To; p.B = B; p.H = H; p.N = T; p.Npad = 64; p.q_prescaled = 1;
                 run_attn(sa, p, "attention.bert", 4.0 * T * (double)T * D * B, 8.0 * Mt * D, true);
             }
-            residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, !(text_dr && m->text_dr_res), true, (text_dr && m->text_dr_res) ? bw.pao : nullptr);
+            residual_gemm(sa, "gemm.bert_ao", w.To, D, bw.wao, bw.bao, Mt, D, T, nv, w.PartT, pend_t, !(text_dr && m->text_dr_res) && !paired_many, true, (text_dr && m->text_dr_res) ? bw.pao : nullptr);
             {
                 LnParams p;        // post-LN in place on the text rows
                 p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
@@ -795,7 +818,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 p.epi = 0; p.C = w.Th; p.ldc = Fn; p.act = 1;
                 run_gemm(sa, p, "gemm.bert_i", true);
             }
-            residual_gemm(sa, "gemm.bert_o", w.Th, Fn, bw.wo, bw.bo, Mt, Fn, T, nv, w.PartT, pend_t, !(text_dr && m->text_dr_res), true, (text_dr && m->text_dr_res) ? bw.po : nullptr);
+            residual_gemm(sa, "gemm.bert_o", w.Th, Fn, bw.wo, bw.bo, Mt, Fn, T, nv, w.PartT, pend_t, !(text_dr && m->text_dr_res) && !paired_many, true, (text_dr && m->text_dr_res) ? bw.po : nullptr);
             {
                 LnParams p;
                 p.x = w.X; p.M = Mt; p.D = D; p.rpb = T; p.xbs = nj; p.xro = nv;
@@ -1030,7 +1053,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
 extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!m || !key) return fail(UVL_EINVAL, "null argument");
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
-    if (!strcmp(key, "pair_text")) { m->pair_text = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return UVL_OK; }
@@ -1062,7 +1085,7 @@ extern "C" int uvl_graph_capture(uvl_model_t* m, const uvl_inputs* in, const uvl
     if (!m->cap_stream) HIPCHK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     HIPCHK(hipDeviceSynchronize());
     // one sequence with paired text kernels is a single-stream frame: one graph, like the no-text case
-    const bool text = !in->skip_text && !in->reuse_text && m->nf >= 0 && !(m->pair_text && in->batch == 1 && m->nf > 0);
+    const bool text = !in->skip_text && !in->reuse_text && m->nf >= 0 && !text_rides(m, in->batch, 0, 0);
     const int part_of[3] = {PART_TEXT, PART_V1, PART_V2};
     for (int k = 0; k < 3; ++k) {
         if (!text && k != 1) continue;
