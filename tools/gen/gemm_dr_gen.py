@@ -262,6 +262,13 @@ class Gen:
         self.in_loop = True
         if "prio" in self.abl:
             self.e("s_setprio 1")
+        if "aprio" in self.abl:            # variant: the two workgroups of a CU in different priority classes (by wave slot parity), to take them out of phase
+            self.e("s_getreg_b32 s55, hwreg(HW_REG_HW_ID, 0, 4)")
+            self.e("s_and_b32 s55, s55, 1")
+            self.e("s_cmp_eq_u32 s55, 0")
+            self.e("s_cbranch_scc1 lo_%=")
+            self.e("s_setprio 2")
+            self.e("lo_%=:")
         self.e("top_%=:")
         start, vstart = list(self.ldsq), list(self.vmq)
         for u in range(NSTG):
@@ -271,7 +278,7 @@ class Gen:
             self.e("s_cbranch_scc1 done_%=" if u < NSTG - 1 else "s_cbranch_scc0 top_%=")
             assert self.abl or (start == self.ldsq and vstart == self.vmq), (u, start, self.ldsq, vstart, self.vmq)
         self.e("done_%=:")
-        if "prio" in self.abl:
+        if "prio" in self.abl or "aprio" in self.abl:
             self.e("s_setprio 0")
         # nothing of the block may be in flight when the compiler's code resumes: LDS-DMA, fragment reads, MFMAs
         self.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
