@@ -126,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                     const int rfirst = min(m0 + i * 32, p.M - 1);
                     int bt, rem;
                     rowmap_at(rowmap_of(rfirst, p.rpb), rfirst, (row < p.M ? row : p.M - 1) - rfirst, bt, rem);
-                    tv[0][it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + colw + (lane % LPR) * 4);
+                    tv[0][it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)(p.addtab_split ? (rem >= p.addtab_split ? 1 : 0) : rem) * p.N + colw + (lane % LPR) * 4);
                 }
             }
         }

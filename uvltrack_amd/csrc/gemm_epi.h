@@ -117,7 +117,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     rowmap_at(rmap, rfirst, (inb[it] ? row : p.M - 1) - rfirst, b, rem);
                     v[it] = *reinterpret_cast<const f32x4*>(cw + r * RS + c16 * 16);
                     dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
-                    if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)rem * p.N + col);
+                    if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)(p.addtab_split ? (rem >= p.addtab_split ? 1 : 0) : rem) * p.N + col);
                 }
                 if (p.accumulate) {
 #pragma unroll

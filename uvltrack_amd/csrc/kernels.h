@@ -25,6 +25,7 @@ struct GemmParams {
     int accumulate = 0;                          // C += ...                         (EPI_F32)
     int rpb = 1 << 30, obs = 0, oro = 0;         // row m -> (b = m / rpb, t = m % rpb) -> output row b*obs + oro + t
     const float* addtab = nullptr;               // [rpb, N] f32 added by t            (EPI_F32; pos-embed)
+    int addtab_split = 0;                        // > 0: addtab is [2, N], row (t >= addtab_split) (the modal embeddings of the fusion layers, mae_vit.py:196)
     bf16_t *q = nullptr, *k = nullptr, *vt = nullptr; int H = 0, Npad = 0, D = 0;   // EPI_QKV
     float q_scale = 1.0f;                        // EPI_QKV: factor applied to the q columns before rounding (log2(e)/8 in the frame)
     int groups = 1;
@@ -79,6 +80,11 @@ struct LnParams {
     const float* ct_txt = nullptr;               // [B, ct_T, D] text rows of that layer (pre-fusion layers) or null = snapshot row ct_nv
     int ct_nz = 0, ct_nv = 0, ct_nx = 0, ct_T = 0, ct_skip_text = 0, ct_slot = 0, ct_ncont = 0;
     const int64_t* ct_flag = nullptr; const float* ct_logit_scale = nullptr; float* ct_logits = nullptr;
+    // ct_self: the job's rows are this launch's own input rows (ct_x = x, which the launch must not modify: no slabs, no pre_add on the rows it
+    // reads) -- many-sequence frames, whose fc2 epilogue has already added the next layer's modal embedding (GemmParams.addtab_split): the
+    // job takes it off again (ct_sub_vis from the search rows and the vis token, ct_sub_txt from the text token), no snapshot is written.
+    int ct_self = 0;
+    const float *ct_sub_vis = nullptr, *ct_sub_txt = nullptr;
 };
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s);
 hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s);

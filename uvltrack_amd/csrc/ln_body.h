@@ -61,10 +61,11 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
         const float* xb = p.ct_x + (size_t)b * p.xbs * p.D;
         const float* xs = xb + (size_t)t * p.D;
         const float* tk = p.ct_skip_text ? xb : (p.ct_txt ? p.ct_txt + (size_t)b * p.ct_T * p.D : xb + (size_t)p.ct_nv * p.D);
+        const float* xs_eff = p.ct_self ? g_zero_row : xs;       // ct_self: the search row is this wave's own row (v[], untouched below: no slabs, no pre_add)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = ok[i] ? (lane + 64 * i) * 4 : 0;
-            ca[i] = *reinterpret_cast<const float4*>(xs + c);
+            ca[i] = *reinterpret_cast<const float4*>(xs_eff + c);
             cv[i] = *reinterpret_cast<const float4*>(xb + c);
             cq[i] = *reinterpret_cast<const float4*>(tk + c);
         }
@@ -133,6 +134,20 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     if (do_ct) {
         const int s = t - 1 - p.ct_nz;
         float xx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
+        if (p.ct_self) {
+            // the search row is this wave's own row; the NEXT layer's modal embedding, which the fc2 epilogue has already added to every row, comes
+            // off again (two L2-hot rows, requested here rather than with the row: 32 registers less through the load phase)
+            const float* sv = p.ct_sub_vis ? p.ct_sub_vis : g_zero_row;
+            const float* sq = (p.ct_sub_txt && !p.ct_txt) ? p.ct_sub_txt : g_zero_row;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = ok[i] ? (lane + 64 * i) * 4 : 0;
+                const float4 m0 = *reinterpret_cast<const float4*>(sv + c), m1 = *reinterpret_cast<const float4*>(sq + c);
+                ca[i].x = v[i].x - m0.x; ca[i].y = v[i].y - m0.y; ca[i].z = v[i].z - m0.z; ca[i].w = v[i].w - m0.w;
+                cv[i].x -= m0.x; cv[i].y -= m0.y; cv[i].z -= m0.z; cv[i].w -= m0.w;
+                cq[i].x -= m1.x; cq[i].y -= m1.y; cq[i].z -= m1.z; cq[i].w -= m1.w;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             if (ok[i]) {

@@ -93,6 +93,7 @@ struct uvl_model {
     int text_dr_res = 0;                         // uvl_debug_set("text_dr_res", 1): the text branch's residual GEMMs (12 tiles) on gemm_dr_kernel too (A/B)
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
+    int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
     int fuse_ln = 0;                             // uvl_debug_set("fuse_ln", 1): one-sequence frames launch LayerNorm + its consumer GEMM as ONE kernel behind a
                                                  // grid barrier (96 -> 72 launches; measured 3-4 % SLOWER than the two launches, so off: profiles/r03_summary.md)
     unsigned* gbar = nullptr;                    // 4 KB of counters for the fused launches' grid barrier (monotonic: never reset)
@@ -759,8 +760,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     Pending pend_t;
     auto consume = [](LnParams& p, Pending& pd) { p.part = pd.part; p.nsplit = pd.nsplit; p.part_rows = pd.rows; p.part_stride = pd.stride; pd = Pending(); };
     auto is_cont_layer = [&](int i) { bool c = false; for (int k = 0; k < m->cfg.n_cont; ++k) c |= (m->cfg.cont_layers[k] == i); return c; };
+    // tab (optional): a [2, D] table whose row (t >= tab_split) is added too -- only the in-place form takes it; returns whether it did
     auto residual_gemm = [&](hipStream_t st, const char* what, const bf16_t* A, int lda, const bf16_t* Wt, const float* bias, int Mr, int K,
-                             int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false, const bf16_t* Wpk = nullptr) {
+                             int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false, const bf16_t* Wpk = nullptr,
+                             const float* tab = nullptr, int tab_split = 0) -> bool {
         GemmParams p;
         p.A = A; p.lda = lda; p.W = Wt; p.Wp = Wpk; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
         const int sk = allow_split ? choose_splitk(Mr, D, K, &m->tune) : 1;
@@ -771,8 +774,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             // write-through (sc1) stores of x: no dirty lines wait for the end-of-kernel write-back, and the LayerNorm that follows reads
             // x from memory, not from another XCD's L2 anyway (+0.9 % at 8 sequences of UVLTrack-B / -L, 0 at 32; tools/ab_tune.py res_store 0 2)
             p.C = w.X; p.accumulate = 1; p.rpb = rpb; p.obs = nj; p.oro = oro; p.c_store = tune_get(&m->tune, &uvl_tuning::res_store, 2);
+            if (tab) { p.addtab = tab; p.addtab_split = tab_split; }
         }
         run_gemm(st, p, what, is_text);
+        return sk <= 1 && tab != nullptr;
     };
     if (!one_queue) {
         struct BeCtx { const uvl_model* m; const uvl_inputs* in; Workspace w; int B; } bc{m, in, w, B};
@@ -852,6 +857,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     int cont_slot = 0;
     int head_ct_slot = -1;                       // >= 0: head_prep also writes the last layer's logits into this slot
     int fused_ct = -1, fused_slot = 0;           // contrast layer whose logits the next layer's LayerNorm-2 will write
+    bool direct_ct = false;                      // ... or the next layer's LayerNorm-1 (many-sequence frames, see below)
+    bool modal_folded = false;                   // the last fc2 epilogue has added the next (fusion) layer's modal embedding
     Pending pend_v;                              // split-K slabs not yet folded into the residual stream (visual/joint rows)
     for (int i = 0; i < m->depth; ++i) {
         const bool joint = i >= m->nf;
@@ -869,10 +876,28 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
             consume(p, pend_v);
-            if (joint) { p.pre_add0 = m->modal; p.pre_add1 = m->modal + D; p.split = nv; }     // forward_joint, mae_vit.py:196
+            if (joint) {                             // forward_joint, mae_vit.py:196: img_feat + modal_embed[0], txt_feat + modal_embed[1]
+                // modal_folded: the previous layer's fc2 epilogue has added it already (in-place residual form; the text rows of the FIRST
+                // fusion layer come from the text branch and still take theirs here)
+                p.pre_add0 = modal_folded ? nullptr : m->modal;
+                p.pre_add1 = (modal_folded && i > m->nf) ? nullptr : m->modal + D;
+                p.split = nv;
+            }
             if (reuse && i == m->nf) { p.x_alt = w.TxtSnap + (size_t)(m->nf - 1) * B * T * D; p.x_alt_rows = T; }   // text rows kept from the last full frame
             p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
-            if (fused_ct >= 0) p.x_snap = w.XSnap;   // this fold completes layer `fused_ct`: keep its output for the logits
+            if (fused_ct >= 0 && direct_ct) {
+                // the logits of layer `fused_ct` ride on THIS launch: it leaves the rows the job reads untouched (no slabs, no pre-add on visual rows;
+                // the text token of a pre-fusion layer comes from the text branch's snapshot), so no copy of the layer's output is kept
+                if (!skip) L.cur = PART_V2;
+                p.ct_x = w.X; p.ct_self = 1; p.ct_sub_vis = modal_folded ? m->modal : nullptr; p.ct_sub_txt = (modal_folded && fused_ct >= m->nf) ? m->modal + D : nullptr;
+                p.ct_nz = nz; p.ct_nv = nv; p.ct_nx = nx; p.ct_T = T; p.ct_skip_text = skip;
+                p.ct_slot = fused_slot; p.ct_ncont = m->cfg.n_cont;
+                p.ct_flag = in->d_flag; p.ct_logit_scale = m->logit_scale_bb; p.ct_logits = out->d_logits;
+                if (fused_ct < m->nf && !skip) p.ct_txt = w.TxtSnap + (size_t)fused_ct * B * T * D;
+                fused_ct = -1;
+            } else if (fused_ct >= 0) p.x_snap = w.XSnap;   // this fold completes layer `fused_ct`: keep its output for the logits
+            direct_ct = false;
+            modal_folded = false;
             run_ln(s, p, (double)M * D * 6, false);
         }
         {
@@ -911,7 +936,15 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
             run_gemm(s, p, "gemm.fc1", false);
         }
-        residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last, false, vw.pfc2);
+        {
+            // the NEXT layer is a fusion layer: its "+ modal_embed" (a permanent change of the residual stream) is one more term of this epilogue
+            // instead of a read-modify-write of every row in that layer's LayerNorm-1 (in-place residual form only: many-sequence frames)
+            // (not where this layer's logits are computed by the stand-alone contrast kernel, which reads the residual stream as it is)
+            const bool ct_alone = is_cont_layer(i) && out->d_logits && (m->cfg.txt_token_mean || !m->fuse_contrast);
+            const bool next_joint = !last && i + 1 < m->depth && i + 1 >= m->nf && m->fold_modal && !ct_alone;
+            modal_folded = residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last, false, vw.pfc2,
+                                         next_joint ? m->modal : nullptr, nv);
+        }
         if (i <= last_bert && !paired) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
         if (is_cont_layer(i)) {
@@ -922,6 +955,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 // next LayerNorm-2 computes the logits from it (no launch of its own)
                 fused_ct = i;
                 fused_slot = cont_slot;
+                // direct form: the next LayerNorm-1 computes them itself from its own input rows -- possible where that launch does not modify the
+                // rows (the modal embedding already added by fc2 above, no slabs pending) and the text token is there when it starts (fusion
+                // layers: row nv of x; the last pre-fusion layer: the text branch's snapshot, joined before the first fusion layer)
+                direct_ct = modal_folded && pend_v.nsplit == 0 && i + 1 >= m->nf;
             } else if (out->d_logits) {
                 // a stand-alone contrast kernel of a pre-fusion layer reads that BERT layer's snapshot: its last LayerNorm may
                 // still be waiting for a partner
@@ -1053,6 +1090,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
 extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!m || !key) return fail(UVL_EINVAL, "null argument");
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
+    if (!strcmp(key, "fold_modal")) { m->fold_modal = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
