@@ -19,7 +19,10 @@ __device__ __forceinline__ float4 sel4(bool c, const float4& a) { return c ? a :
 // addresses, the slab count and the pre-add selection live in scalar registers.
 // SLABS / CT: the launch has split-K slabs to fold / a contrastive job riding on it (host-known); without them their operand
 // slots cost neither registers nor load issue (batched frames: no slabs, LayerNorm is HBM-bound there).
-template <int NV, bool FULL, bool SLABS, bool CT>
+// CT: 0 = no second job, 1 = contrastive job from a snapshot (operands requested with the row), 2 = from the launch's own input rows (ct_self:
+// the job's operands are requested AFTER the LayerNorm outputs are stored -- L2-hot rows -- so the load phase holds 48 registers less.
+// Measured in the UVLTrack-L x 8 frame (7304 rows): plain 8.9-9.5 us, with the self job 14.6 us of which 2.9 are its four L2-hot rows and 2.2 its five reductions)
+template <int NV, bool FULL, bool SLABS, int CT>
 __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = bx * (int)(blockDim.x >> 6) + wave;     // one row per wave, blockDim.x / 64 rows per workgroup
@@ -57,15 +60,14 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     float4 ca[NV], cv[NV], cq[NV];
     float ct_ls = 0.f;
     int ct_fl = 0;
-    if (do_ct) {
+    if (CT == 1 && do_ct) {
         const float* xb = p.ct_x + (size_t)b * p.xbs * p.D;
         const float* xs = xb + (size_t)t * p.D;
         const float* tk = p.ct_skip_text ? xb : (p.ct_txt ? p.ct_txt + (size_t)b * p.ct_T * p.D : xb + (size_t)p.ct_nv * p.D);
-        const float* xs_eff = p.ct_self ? g_zero_row : xs;       // ct_self: the search row is this wave's own row (v[], untouched below: no slabs, no pre_add)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = ok[i] ? (lane + 64 * i) * 4 : 0;
-            ca[i] = *reinterpret_cast<const float4*>(xs_eff + c);
+            ca[i] = *reinterpret_cast<const float4*>(xs + c);
             cv[i] = *reinterpret_cast<const float4*>(xb + c);
             cq[i] = *reinterpret_cast<const float4*>(tk + c);
         }
@@ -134,14 +136,20 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     if (do_ct) {
         const int s = t - 1 - p.ct_nz;
         float xx = 0.f, xv = 0.f, vv = 0.f, xt = 0.f, tt = 0.f;
-        if (p.ct_self) {
-            // the search row is this wave's own row; the NEXT layer's modal embedding, which the fc2 epilogue has already added to every row, comes
-            // off again (two L2-hot rows, requested here rather than with the row: 32 registers less through the load phase)
+        if (CT == 2) {
+            // the search row is this wave's own row (v[]: no slabs, no pre-add touched it); the vis / text token rows of the sample are requested
+            // now; the NEXT layer's modal embedding, which the fc2 epilogue has already added to every row, comes off again
+            const float* xb = p.ct_x + (size_t)b * p.xbs * p.D;
+            const float* tk = p.ct_skip_text ? xb : (p.ct_txt ? p.ct_txt + (size_t)b * p.ct_T * p.D : xb + (size_t)p.ct_nv * p.D);
             const float* sv = p.ct_sub_vis ? p.ct_sub_vis : g_zero_row;
             const float* sq = (p.ct_sub_txt && !p.ct_txt) ? p.ct_sub_txt : g_zero_row;
+            ct_ls = p.ct_logit_scale[0];
+            ct_fl = (int)p.ct_flag[b];
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = ok[i] ? (lane + 64 * i) * 4 : 0;
+                cv[i] = *reinterpret_cast<const float4*>(xb + c);
+                cq[i] = *reinterpret_cast<const float4*>(tk + c);
                 const float4 m0 = *reinterpret_cast<const float4*>(sv + c), m1 = *reinterpret_cast<const float4*>(sq + c);
                 ca[i].x = v[i].x - m0.x; ca[i].y = v[i].y - m0.y; ca[i].z = v[i].z - m0.z; ca[i].w = v[i].w - m0.w;
                 cv[i].x -= m0.x; cv[i].y -= m0.y; cv[i].z -= m0.z; cv[i].w -= m0.w;

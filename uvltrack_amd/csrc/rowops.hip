@@ -16,16 +16,16 @@ namespace uvl {
 // ------------------------------------------------------------------------------------------------
 // (LN_MAX_SLABS, g_zero_row, sel4 and ln_body live in ln_body.h: the fused LayerNorm + GEMM kernel in gemm.hip shares them)
 
-template <int NV, bool FULL, bool SLABS, bool CT>
+template <int NV, bool FULL, bool SLABS, int CT>
 __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) { ln_body<NV, FULL, SLABS, CT>(p, blockIdx.x); }
 
 // Two independent LayerNorm problems in one launch (batch-1 frames pair every text-branch kernel with the visual kernel
 // of the same kind, see uvl_api.hip): workgroups [0, split) work on pa, the rest on pb.
-template <int NV, bool FULL, bool SLABS, bool CT>
+template <int NV, bool FULL, bool SLABS, int CT>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
     if ((int)blockIdx.x < split) ln_body<NV, FULL, SLABS, CT>(pa, (int)blockIdx.x);
-    else ln_body<NV, FULL, SLABS, false>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
+    else ln_body<NV, FULL, SLABS, 0>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
 }
 
 // Rows (= waves) per workgroup.  With one memory round trip per row, one sequence of UVLTrack-B (553 rows) is 1.5-2.6 % faster in
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const L
 static int ln_waves_per_block(int M) { return M <= 768 ? 1 : 4; }
 
 // name of the instantiation as rocprofv3 prints it (bench.py keys its per-kernel rooflines and the committed PMC traffic on it)
-static const char* ln_name(bool pair, int nv, bool full, bool slabs, bool ct) {
-    static char names[2][5][2][2][2][40];              // interned: the profiler keeps the pointer
+static const char* ln_name(bool pair, int nv, bool full, bool slabs, int ct) {
+    static char names[2][5][2][2][3][40];              // interned: the profiler keeps the pointer
     char* name = names[pair][nv & 7 ? (nv > 4 ? 4 : nv) : 0][full][slabs][ct];
     if (!name[0]) snprintf(name, 40, "%s<%d,%d,%d,%d>", pair ? "ln_pair_kernel" : "ln_kernel", nv, (int)full, (int)slabs, (int)ct);
     return name;
@@ -44,15 +44,17 @@ static const char* ln_name(bool pair, int nv, bool full, bool slabs, bool ct) {
 template <int NV, bool FULL>
 static void launch_ln_variant(const LnParams& p, int grid, int wpb, hipStream_t s) {
     const bool slabs = p.nsplit > 0, ct = p.ct_x != nullptr;
-    g_last_kernel = ln_name(false, NV, FULL, slabs, ct);
-    if (slabs && ct) hipLaunchKernelGGL((ln_kernel<NV, FULL, true, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    const bool self = ct && p.ct_self && !slabs;         // (a self job never comes with slabs: the launch must leave its input rows alone)
+    g_last_kernel = ln_name(false, NV, FULL, slabs, self ? 2 : ct);
+    if (self) hipLaunchKernelGGL((ln_kernel<NV, FULL, false, 2>), dim3(grid), dim3(64 * wpb), 0, s, p);
+    else if (slabs && ct) hipLaunchKernelGGL((ln_kernel<NV, FULL, true, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
     else if (slabs) hipLaunchKernelGGL((ln_kernel<NV, FULL, true, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
     else if (ct) hipLaunchKernelGGL((ln_kernel<NV, FULL, false, true>), dim3(grid), dim3(64 * wpb), 0, s, p);
     else hipLaunchKernelGGL((ln_kernel<NV, FULL, false, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
 }
 
 hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
-    if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0 || p.nsplit > LN_MAX_SLABS) return hipErrorInvalidValue;
+    if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0 || p.nsplit > LN_MAX_SLABS || (p.ct_x && p.ct_self && (p.nsplit > 0 || p.ct_x != p.x))) return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(p.M);
     const int grid = (p.M + wpb - 1) / wpb;
     if (p.D == 768) launch_ln_variant<3, true>(p, grid, wpb, s);
@@ -66,15 +68,18 @@ hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
 template <int NV, bool FULL>
 static void launch_ln_pair_variant(const LnParams& a, const LnParams& b, int ga, int gb, int wpb, hipStream_t s) {
     const bool slabs = a.nsplit > 0 || b.nsplit > 0, ct = a.ct_x != nullptr;
-    g_last_kernel = ln_name(true, NV, FULL, slabs, ct);
-    if (slabs && ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    const bool self = ct && a.ct_self && !slabs;
+    g_last_kernel = ln_name(true, NV, FULL, slabs, self ? 2 : ct);
+    if (self) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, 2>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+    else if (slabs && ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
     else if (slabs) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
     else if (ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
     else hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
 }
 
 hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s) {
-    if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0 || a.nsplit > LN_MAX_SLABS || b.nsplit > LN_MAX_SLABS || b.ct_x)
+    if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0 || a.nsplit > LN_MAX_SLABS || b.nsplit > LN_MAX_SLABS || b.ct_x ||
+        (a.ct_x && a.ct_self && (a.nsplit > 0 || b.nsplit > 0 || a.ct_x != a.x)))
         return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(a.M);
     const int ga = (a.M + wpb - 1) / wpb, gb = (b.M + wpb - 1) / wpb;
