@@ -361,6 +361,7 @@ __device__ __forceinline__ bool attn_decode_block(int blk, int total, int nqb, i
 
 template <int QW, int KS, int NS>
 __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(const AttnParams p) {
+    kernarg_warm<sizeof(AttnParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];      // NS * STAGE (>= the merge exchange area)
     const int nqb = (p.N + 32 * QW - 1) / (32 * QW);
     int qb, h, b;
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
 // one's configuration).  1-D grid, problem A owns [0, blocks_a); (query block, head, sample) are decoded per problem.
 template <int QW, int KS, int NS>
 __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_pair_kernel(const AttnParams pa, const AttnParams pb, int blocks_a) {
+    kernarg_warm<2 * sizeof(AttnParams) + 8>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < blocks_a) {                 // blocks_a is a multiple of 8: the XCD relation of the map is preserved
         const int nqb = (pa.N + 32 * QW - 1) / (32 * QW);
@@ -407,6 +409,7 @@ template <int V_> struct AttnIC { static constexpr int value = V_; };
 
 template <int NS>
 __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p) {
+    kernarg_warm<sizeof(AttnParams)>();
     constexpr int STAGE = 16384;                          // K tile 8 KB + V^T tile 8 KB
     constexpr int KADD0 = NS * STAGE;                     // [NS][4 waves][64] f32 key_add rows
     constexpr int VM = 5;                                 // VMEM operations per wave and tile: 2 K + 2 V^T pieces + the key_add row
@@ -1212,6 +1215,7 @@ __device__ __forceinline__ void attn_w64_item(const AttnParams& p, const int qb,
 
 template <int NS>
 __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
+    kernarg_warm<sizeof(AttnParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
     int qb, h, b;
@@ -1301,6 +1305,7 @@ __device__ __forceinline__ void attn_p64_walk(const AttnParams& p, const int tot
 }
 
 __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
+    kernarg_warm<sizeof(AttnParams) + 24>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
 }
@@ -1312,6 +1317,7 @@ __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, co
 // last workgroup first.
 __global__ __launch_bounds__(256, 2) void attn_p64_rider_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh,
                                                                 const AttnParams pb, const int tail_only) {
+    kernarg_warm<2 * sizeof(AttnParams) + 32>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
     const int nqb_b = (pb.N + 127) / 128, total_b = nqb_b * pb.H * pb.B;

@@ -137,3 +137,20 @@ __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + (
 // Same tile read by ds_read_b64 with lane = row (32-lane service groups, 64 banks): XOR the 8-byte
 // chunk index (0..15) with (row>>1)&15.
 __device__ __forceinline__ int swz64(int row, int chunk8) { return row * 128 + ((chunk8 ^ ((row >> 1) & 15)) << 3); }
+
+// All cache lines of the kernel-argument segment requested at once, at kernel entry.  hipcc loads the fields of a by-value argument block where
+// they are first used, in dependency order (a condition, then the pointers behind it, ...): each first touch of a 64-byte line of the freshly
+// written segment is a miss, and a launch-bound kernel pays them one after the other before its first global load.  Measured on the
+// one-sequence frame (rocprofv3 --stats, two runs each): GEMM launches -0.3..0.7 us, attention -0.2..0.5, LayerNorm -0.1..0.4; the frame's kernel
+// time 760-775 -> 739-740 us.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#ifndef UVL_NO_KERNARG_WARM            // (development A/B: tools/probes/bench_lib.py on a variant build)
+    typedef const uint32_t __attribute__((address_space(4))) cu32;
+    cu32* k = (cu32*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t a = 0;
+#pragma unroll
+    for (int off = 0; off < BYTES; off += 64) a |= k[off / 4];
+    asm volatile("" ::"s"(a));
+#endif
+}

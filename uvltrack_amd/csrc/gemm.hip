@@ -291,6 +291,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
 __global__ __launch_bounds__(64 * (WGM * WGN + PROD), PROD ? (2 * (WGM * WGN + PROD)) / 4 : 1) void gemm_glds_kernel(const GemmParams p) {
+    kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
 }
@@ -742,6 +743,7 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
 
 template <int EPI, bool MI16>
 __global__ __launch_bounds__(512) void gemm_pipe128_kernel(const GemmParams p) {
+    kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_pipe128_body<EPI, MI16>(p, blockIdx.x, smem);
 }
@@ -772,6 +774,7 @@ static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
 
 template <int BM, int EPI, int VAR, bool MI16>
 __global__ __launch_bounds__(512) void gemm_pipe_kernel(const GemmParams p) {
+    kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_pipe_body<BM, EPI, VAR, MI16>(p, blockIdx.x, smem);
 }
@@ -815,6 +818,7 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
 // is reused, because the nine M tiles of a visual GEMM share each weight tile through L2).
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b) {
+    kernarg_warm<2 * sizeof(GemmParams) + 16>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
     if ((int)blockIdx.x < blocks_a) {
@@ -831,6 +835,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
 // single round of at most 256 workgroups on the shapes that take these kernels, and the rider's 9-30 tiles fit beside it.
 template <int BMA, int EPI>
 __global__ __launch_bounds__(512) void gemm_pipe_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
+    kernarg_warm<2 * sizeof(GemmParams) + 8>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= blocks_b) {              // the rider's workgroups first (see gemm_dr_pair_kernel)
         if constexpr (BMA == 256) gemm_pipe_body<256, EPI, 1, true>(pa, (int)blockIdx.x - blocks_b, smem);
@@ -1177,6 +1182,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, const unsigned gen, 
 template <int EPI, int NS, int NV>
 __global__ __launch_bounds__(256, 2) void ln_gemm_pair_kernel(const LnParams la, const LnParams lb, const int vba, const int vbb, const GemmParams pa, const GemmParams pb,
                                                               const int blocks_a, const int tiles_a, const int tiles_b, unsigned* bar, const unsigned gen, const unsigned base) {
+    kernarg_warm<2 * sizeof(LnParams) + 2 * sizeof(GemmParams) + 32>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // phase 0: the weight halves of this workgroup's first three K tiles go out (cold, from HBM): they fly under phases 1 and 2
     if ((int)blockIdx.x < blocks_a) {

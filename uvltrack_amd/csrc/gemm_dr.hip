@@ -263,6 +263,7 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_dr_kernel(const GemmParams p) {
+    kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_dr_body<EPI>(p, blockIdx.x, smem);
 }
@@ -298,6 +299,7 @@ static hipError_t launch_dr(const GemmParams& p_in, hipStream_t s) {
 // workgroup -> XCD relation.  Two calls, not a selected reference (see gemm_glds_pair_kernel).
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_dr_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
+    kernarg_warm<2 * sizeof(GemmParams) + 8>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= blocks_b) gemm_dr_body<EPI>(pa, (int)blockIdx.x - blocks_b, smem);
     else gemm_dr_body<EPI>(pb, blockIdx.x, smem);

@@ -17,12 +17,14 @@ namespace uvl {
 // (LN_MAX_SLABS, g_zero_row, sel4 and ln_body live in ln_body.h: the fused LayerNorm + GEMM kernel in gemm.hip shares them)
 
 template <int NV, bool FULL, bool SLABS, int CT>
-__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) { ln_body<NV, FULL, SLABS, CT>(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
+    kernarg_warm<sizeof(LnParams)>(); ln_body<NV, FULL, SLABS, CT>(p, blockIdx.x); }
 
 // Two independent LayerNorm problems in one launch (batch-1 frames pair every text-branch kernel with the visual kernel
 // of the same kind, see uvl_api.hip): workgroups [0, split) work on pa, the rest on pb.
 template <int NV, bool FULL, bool SLABS, int CT>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
+    kernarg_warm<2 * sizeof(LnParams) + 8>();
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
     if ((int)blockIdx.x < split) ln_body<NV, FULL, SLABS, CT>(pa, (int)blockIdx.x);
     else ln_body<NV, FULL, SLABS, 0>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ 
 // the cls rows, the next n_embed do the BERT embedding + LayerNorm, the rest gather the image patches.
 template <int NV>
 __global__ __launch_bounds__(256) void prologue_kernel(const PrologueParams p) {
+    kernarg_warm<sizeof(PrologueParams)>();
     const int bx = blockIdx.x;
     if (bx < p.n_setup) {
         setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, p.skip_text, p.setup_what, bx);
@@ -359,6 +362,7 @@ struct RowView {
 };
 
 __global__ __launch_bounds__(256) void contrast_kernel(const ContrastParams p) {
+    kernarg_warm<sizeof(ContrastParams)>();
     extern __shared__ float sh[];              // [D] txt token, [D] vis token
     const int b = blockIdx.y, D = p.D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -466,6 +470,7 @@ __device__ __forceinline__ void write_cont(const HeadPrepParams& p, int b, int s
 // round trip, see ln_body); FULL: D == NV * 256.
 template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void head_prep_kernel(const HeadPrepParams p) {
+    kernarg_warm<sizeof(HeadPrepParams)>();
     extern __shared__ float sh[];              // [D] txt token, [D] cls-tokenize token
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -665,6 +670,7 @@ hipError_t launch_head_prep(const HeadPrepParams& p, hipStream_t s) {
 // workgroup instead of one per channel group; C8 == 0: any width, plain loops.
 template <int C8>
 __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) {
+    kernarg_warm<sizeof(HeadTailParams)>();
     extern __shared__ float shw[];              // [7*c8] weights, [8] bias
     __shared__ float red_v[256];
     __shared__ int red_i[256];
@@ -805,6 +811,7 @@ hipError_t launch_slab_relu(const float* slabs, int nsplit, size_t stride, bf16_
 // Every operand (the position's scores and box, the sample's state / scale / frame size) is requested before the first use; the
 // thread that owns the winning position finishes the box from its own registers.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+    kernarg_warm<sizeof(DecodeParams)>();
     __shared__ float red_v[256];
     __shared__ int red_i[256];
     const int b = blockIdx.x;

@@ -664,7 +664,9 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         // BERT weights are read once per frame: up to four sequences (<= 3 M tiles share a weight tile through L2) they are loaded
         // non-temporal so that they do not displace the ViT weights from the Infinity Cache (+2-3 % at 2-4 sequences, -0.5 % from 8 on)
         if (is_text && p.M <= 192) p.w_stream = 1;
-        const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K);
+        // algorithmic bytes: both operands once + what the epilogue moves (bf16 rows; f32 rows, read too by the in-place residual form, once per slab)
+        const double out_b = (double)p.M * p.N * (p.epi == 1 ? 4.0 * (p.accumulate ? 2 : 1) * (p.splitk > 1 ? p.splitk : 1) : 2.0);
+        const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K) + out_b;
         if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.g = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (pend_ln.on && !is_text) {
             LnGemm c{};
