@@ -443,11 +443,14 @@ def test_fused_layernorm_gemm_launch_is_bit_identical(name):
         eng.debug_set("fuse_ln", 0)
 
 
-@pytest.mark.parametrize("name,batch", [("b_z128_x256", 16), ("b_z256_x256", 8), ("l_z256_x384", 8)])
+@pytest.mark.parametrize("name,batch", [("b_z128_x256", 16), ("b_z256_x256", 8), ("l_z256_x384", 8), ("b_z256_x256", 32)])
 def test_large_batch_matches_single_sequence_runs(name, batch):
     """The batched regime takes other kernels than the fixtures' 2-3 samples (grouped tile order, 64x128 / 128x128 tiles,
-    128x128 implicit-GEMM conv tiles, 128-query attention workgroups with 2 or 3 ring stages): a batch of 8-16 sequences with
-    mixed flags must reproduce the one-sequence runs (themselves checked against the reference) sample by sample."""
+    128x128 implicit-GEMM conv tiles, 128-query attention workgroups with 2 or 3 ring stages): a batch of 8-32 sequences with
+    mixed flags must reproduce the one-sequence runs (themselves checked against the reference) sample by sample.  The 8-sequence
+    UVLTrack-L frame and the 32-sequence UVLTrack-B frame take the text riders by default (uvl_api.hip::text_rides): the first with one
+    attention item per workgroup (the rider's items go to the workgroups of the short last query block), the second with 1152 items on
+    512 workgroups (rider items round-robin from the end of the grid) and the residual GEMMs on gemm_pipe_pair_kernel<256,1>."""
     from uvltrack_amd import weightgen as wg
     from uvltrack_amd.engine import HipEngine
     meta, spec, _ = load_case(name)
@@ -459,6 +462,17 @@ def test_large_batch_matches_single_sequence_runs(name, batch):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     big = eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
     big = {k: v.cpu().numpy() for k, v in big.items() if torch.is_tensor(v)}
+    # which text placement the frame took BY DEFAULT: riders for UVLTrack-L from 6000 visual rows and for any model from 16000, else the second stream
+    eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]), profile=True)
+    torch.cuda.synchronize()
+    kernels = {e["kernel"] for e in eng.profile_entries()}
+    rows = batch * (1 + (spec.template_size // 16) ** 2 + (spec.search_size // 16) ** 2)
+    want_riders = rows >= 16000 or (spec.dim >= 1024 and rows >= 6000)
+    has_riders = any(k.startswith(("gemm_dr_pair_kernel", "gemm_pipe_pair_kernel", "attn_p64_rider_kernel")) for k in kernels)
+    assert has_riders == want_riders, (rows, sorted(kernels))
+    if want_riders:
+        assert {"gemm_dr_pair_kernel<2>", "gemm_dr_pair_kernel<0>", "attn_p64_rider_kernel"} <= kernels, sorted(kernels)
+        assert any(k.startswith("gemm_pipe_pair_kernel") for k in kernels), sorted(kernels)
     scale = max(1.0, spec.depth / 12.0)
     for b in range(batch):
         one = eng.forward(*[t(inp[k][b:b + 1]) for k in ("template", "search", "ids", "mask", "prompt", "flag")])
