@@ -154,3 +154,23 @@ __device__ __forceinline__ void kernarg_warm() {
     asm volatile("" ::"s"(a));
 #endif
 }
+
+// Prefetch of the NEXT launch's weight into the memory-side cache (one-sequence frames: a launch-bound GEMM whose weight was read by the kernel
+// before it is 0.7-1.2 us shorter, tools/probes/wprefetch_probe.py).  Every thread requests up to four 128-byte lines of [ptr, ptr + bytes) at
+// kernel entry -- BEFORE the first LDS-DMA, so the loop's counted s_waitcnt see them as the oldest entries of the queue -- into one register
+// that stays live until prefetch_retire at the end of the kernel (hipcc does not know that the asm's result arrives later: a dead register
+// would be handed to another value and overwritten when the load lands).
+template <int THREADS>
+__device__ __forceinline__ uint32_t prefetch_issue(const void* ptr, uint32_t bytes, uint32_t wg, uint32_t nwg) {
+    uint32_t sink = 0;
+    if (ptr) {
+        const uint32_t total = nwg * THREADS, id = wg * THREADS + threadIdx.x, lines = bytes >> 7;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t l = id + k * total;
+            if (l < lines) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(reinterpret_cast<const char*>(ptr) + (size_t)l * 128) : "memory");
+        }
+    }
+    return sink;
+}
+__device__ __forceinline__ void prefetch_retire(uint32_t sink) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory"); }

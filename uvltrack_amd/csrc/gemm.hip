@@ -293,7 +293,9 @@ template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW
 __global__ __launch_bounds__(64 * (WGM * WGN + PROD), PROD ? (2 * (WGM * WGN + PROD)) / 4 : 1) void gemm_glds_kernel(const GemmParams p) {
     kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t pfs = prefetch_issue<64 * (WGM * WGN + PROD)>(p.pf, p.pf_bytes, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
+    prefetch_retire(pfs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -820,6 +822,7 @@ template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b) {
     kernarg_warm<2 * sizeof(GemmParams) + 16>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t pfs = prefetch_issue<64 * WGM * WGN>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);     // (the visual problem's next weight; the rider's gain nothing from it)
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
     if ((int)blockIdx.x < blocks_a) {
         const int id = (int)blockIdx.x, sk = id / tiles_a;
@@ -828,6 +831,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
         const int id = (int)blockIdx.x - blocks_a, sk = id / tiles_b;
         gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false, true>(pb, id - sk * tiles_b, sk, 0, smem);
     }
+    prefetch_retire(pfs);
 }
 
 // The same for the eight-wave tiles of many-sequence frames (residual GEMMs: f32 read-modify-write epilogue): problem A on 256 x 256

@@ -93,6 +93,7 @@ struct uvl_model {
     int text_dr_res = 0;                         // uvl_debug_set("text_dr_res", 1): the text branch's residual GEMMs (12 tiles) on gemm_dr_kernel too (A/B)
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
+    int prefetch_w = 1;                          // uvl_debug_set("prefetch_w", v): 0 = no next-weight requests in the GEMM launches, 1 = in frames below 2000 visual rows, 2 = always (A/B)
     int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
     int fuse_ln = 0;                             // uvl_debug_set("fuse_ln", 1): one-sequence frames launch LayerNorm + its consumer GEMM as ONE kernel behind a
                                                  // grid barrier (96 -> 72 launches; measured 3-4 % SLOWER than the two launches, so off: profiles/r03_summary.md)
@@ -513,12 +514,12 @@ static hipError_t tramp(void* ctx, hipStream_t s) { return F(*(const P_*)ctx, s)
 // One layer of the four conv towers (heads/utils.py:126-131 with BatchNorm folded, modality_adaptive_box_head.py:28-50): grouped
 // implicit GEMM over NHWC tokens; few output tiles and a long K (9 * Cin) split K into f32 slabs that a small kernel folds (+ReLU).
 static void run_conv_layer(Launcher& L, hipStream_t s, int layer, const bf16_t* x, int in_ld, const int goff[4], const bf16_t* wpk, const float* bias,
-                           int B, int F, int cin, int cout, bf16_t* y, float* slabs, const uvl_tuning* tune) {
+                           int B, int F, int cin, int cout, bf16_t* y, float* slabs, const uvl_tuning* tune, const void* pf = nullptr, size_t pf_bytes = 0) {
     static const char* const conv_site[4] = {"conv3x3.0", "conv3x3.1", "conv3x3.2", "conv3x3.3"};
     GemmParams p;
     p.A = x; p.lda = in_ld; p.W = wpk; p.ldw = 9 * cin; p.bias = bias;
     p.M = B * F * F; p.N = cout; p.K = 9 * cin; p.ldc = 4 * cout;
-    p.groups = 4; p.conv_F = F; p.cin_g = cin; p.tune = tune;
+    p.groups = 4; p.conv_F = F; p.cin_g = cin; p.tune = tune; p.pf = pf; p.pf_bytes = (uint32_t)pf_bytes;
     for (int g = 0; g < 4; ++g) p.a_goff[g] = goff[g];
     const long tiles = (long)((p.M + 63) / 64) * (p.N / 64 > 0 ? p.N / 64 : 1) * 4;
     const int nk = p.K / 64;
@@ -604,6 +605,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     if ((uintptr_t)d_ws % 256) return fail(UVL_EINVAL, "workspace must be 256-byte aligned");
 
     const int D = m->D, H = m->H, nz = m->nz, nx = m->nx, nv = m->nv, nj = m->nj, npad = m->npad, T = m->T, Fn = m->ffn;
+    // Next-weight requests in the GEMM launches (common.h::prefetch_issue): frames below ~2000 visual rows -- launch-bound GEMMs that start on a cold
+    // weight -- of a model whose weights cannot stay in the 256 MB memory-side cache from frame to frame.  Interleaved tools/ab_tune.py debug.prefetch_w 0 2:
+    // UVLTrack-L (909 MB of weights) x 1 426-428 -> 437-443 frames/s (+2.6..3.4 %), x 2 596 -> 620 (+4.1 %), x 4 867 -> 861 (-0.7 %); UVLTrack-B (its 170 MB
+    // of ViT weights stay resident, see launch_gemm_pair) x 1 1362-1375 -> 1362-1364, x 2 0, x 4 -3 %.  The text branch's weights (riders: each byte read
+    // once, by one CU) gain nothing from it (UVLTrack-L x 1 +2.6 % with them against +3.4 % without).
+    const bool pfw = m->prefetch_w == 2 || (m->prefetch_w == 1 && (long)B * nv < 2000 && (double)m->depth * 12.0 * D * D * 2.0 > 2.0e8);
     Launcher L{prof};
     L.parts = parts;
     // eager full-frame runs fork the text branch onto the library's second stream and join with events; a partial walk
@@ -765,9 +772,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // tab (optional): a [2, D] table whose row (t >= tab_split) is added too -- only the in-place form takes it; returns whether it did
     auto residual_gemm = [&](hipStream_t st, const char* what, const bf16_t* A, int lda, const bf16_t* Wt, const float* bias, int Mr, int K,
                              int rpb, int oro, float* slab, Pending& pd, bool allow_split, bool is_text = false, const bf16_t* Wpk = nullptr,
-                             const float* tab = nullptr, int tab_split = 0) -> bool {
+                             const float* tab = nullptr, int tab_split = 0, const void* pf = nullptr, size_t pf_bytes = 0) -> bool {
         GemmParams p;
         p.A = A; p.lda = lda; p.W = Wt; p.Wp = Wpk; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
+        p.pf = pf; p.pf_bytes = (uint32_t)pf_bytes;
         const int sk = allow_split ? choose_splitk(Mr, D, K, &m->tune) : 1;
         if (sk > 1) {             // slabs [sk][Mr, D], folded in by the next LayerNorm / contrast kernel
             p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D; p.c_store = tune_get(&m->tune, &uvl_tuning::slab_store, 2);   // write-through slabs: +1 % at one sequence (both A/B orders)
@@ -854,6 +862,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         p.A = w.P; p.lda = 768; p.W = m->w_patch; p.ldw = 768; p.bias = m->b_patch;
         p.M = B * (nz + nx); p.N = D; p.K = 768; p.epi = 1; p.C = w.X; p.ldc = D;
         p.rpb = nz + nx; p.obs = nj; p.oro = 1; p.addtab = m->pos_tab; p.tune = &m->tune;
+        if (pfw && m->depth > 0) { p.pf = m->vit[0].wqkv; p.pf_bytes = (uint32_t)((size_t)3 * D * D * 2); }
         RUN_GEMM(L, s, p, "gemm.patch");
     }
     int cont_slot = 0;
@@ -906,6 +915,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             GemmParams p;
             p.A = w.Xn; p.lda = D; p.W = vw.wqkv; p.Wp = vw.pqkv; p.ldw = D; p.bias = vw.bqkv; p.M = M; p.N = 3 * D; p.K = D;
             p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D; p.q_scale = UVL_QSCALE;
+            // every GEMM launch of the small-tile kernels also requests the NEXT GEMM's weight (common.h::prefetch_issue)
+            if (pfw) { p.pf = vw.wproj; p.pf_bytes = (uint32_t)((size_t)D * D * 2); }
             run_gemm(s, p, "gemm.qkv", false);
         }
         {
@@ -913,7 +924,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad; p.q_prescaled = 1;
             run_attn(s, p, "attention", 4.0 * N * (double)N * D * B, 8.0 * M * D, false);
         }
-        residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true, false, vw.pproj);
+        residual_gemm(s, "gemm.proj", w.O, D, vw.wproj, vw.bproj, M, D, N, 0, w.Part, pend_v, true, false, vw.pproj, nullptr, 0,
+                      pfw ? vw.wfc1 : nullptr, (size_t)Fn * D * 2);
         {
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
@@ -936,6 +948,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             GemmParams p;
             p.A = w.Xn; p.lda = D; p.W = vw.wfc1; p.Wp = vw.pfc1; p.ldw = D; p.bias = vw.bfc1; p.M = M; p.N = Fn; p.K = D;
             p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
+            if (pfw) { p.pf = vw.wfc2; p.pf_bytes = (uint32_t)((size_t)Fn * D * 2); }
             run_gemm(s, p, "gemm.fc1", false);
         }
         {
@@ -944,8 +957,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             // (not where this layer's logits are computed by the stand-alone contrast kernel, which reads the residual stream as it is)
             const bool ct_alone = is_cont_layer(i) && out->d_logits && (m->cfg.txt_token_mean || !m->fuse_contrast);
             const bool next_joint = !last && i + 1 < m->depth && i + 1 >= m->nf && m->fold_modal && !ct_alone;
+            // (the last layer's fc2 requests the first conv layer of the head towers)
+            const void* nextw = !pfw ? nullptr : (i + 1 < m->depth && !last) ? (const void*)m->vit[i + 1].wqkv : (const void*)m->conv[0].w;
+            const size_t nextb = (i + 1 < m->depth && !last) ? (size_t)3 * D * D * 2 : (size_t)4 * m->conv[0].cout * 9 * m->conv[0].cin * 2;
             modal_folded = residual_gemm(s, "gemm.fc2", w.Hb, Fn, vw.wfc2, vw.bfc2, M, Fn, N, 0, w.Part, pend_v, !last, false, vw.pfc2,
-                                         next_joint ? m->modal : nullptr, nv);
+                                         next_joint ? m->modal : nullptr, nv, nextw, nextb);
         }
         if (i <= last_bert && !paired) { text_layer(i); if (text_err) return text_err; }
         // ---- contrastive logits (extractor.py:64-65,85-93) ----
@@ -1025,7 +1041,9 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         const ConvLayerW& cw = m->conv[l];
         int goff[4];
         for (int g = 0; g < 4; ++g) goff[g] = (l == 0) ? ((g == 0 && m->cfg.cls_tokenize) ? D : 0) : g * cw.cin;
-        run_conv_layer(L, s, l, cin[l], in_ld[l], goff, cw.w, cw.b, B, m->F, cw.cin, cw.cout, cout[l], w.ConvPart, &m->tune);
+        const ConvLayerW* nx = (pfw && l + 1 < 4) ? &m->conv[l + 1] : nullptr;
+        run_conv_layer(L, s, l, cin[l], in_ld[l], goff, cw.w, cw.b, B, m->F, cw.cin, cw.cout, cout[l], w.ConvPart, &m->tune,
+                       nx ? nx->w : nullptr, nx ? (size_t)4 * nx->cout * 9 * nx->cin * 2 : 0);
     }
     {
         HeadTailParams p;
@@ -1092,6 +1110,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
 extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!m || !key) return fail(UVL_EINVAL, "null argument");
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
+    if (!strcmp(key, "prefetch_w")) { m->prefetch_w = value < 0 ? 0 : (value > 2 ? 2 : value); return UVL_OK; }
     if (!strcmp(key, "fold_modal")) { m->fold_modal = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
