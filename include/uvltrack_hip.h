@@ -222,8 +222,13 @@ int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int
 
 /* Test hooks.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
  * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs.
- * keys "pair_text" / "fuse_contrast" (default 1): 0 selects the two-stream form of a one-sequence frame / stand-alone
- * contrast kernels, so that tests and tools can compare the launch forms (same results).  "fork_text" (default 1): 0 runs the
+ * "pair_text" (default 1): where the text branch rides in the visual launches instead of running on a second stream -- 0 never,
+ * 1 one-sequence frames and the many-sequence frames it measured ahead on (UVLTrack-L from 6000 visual rows, any model from
+ * 16000), 2 wherever the pair kernels exist (>= 2048 rows), 3 one-sequence frames only.  "fuse_contrast" (default 1): 0 selects
+ * the stand-alone contrast kernels, so that tests and tools can compare the launch forms (same results).  "fold_modal"
+ * (default 1): 0 keeps the fusion layers' modal embedding in their LayerNorm-1 (1: in the previous fc2 epilogue where the
+ * residual GEMMs run in place; logits equal within one f32 rounding).  "prefetch_w" (default 1): next-weight requests in the
+ * small-tile GEMM launches -- 0 never, 1 below 2000 visual rows for models whose weights exceed the memory-side cache, 2 always.  "fork_text" (default 1): 0 runs the
  * text branch of multi-sequence frames on the caller's stream.  "fuse_ln" (default 0): 1 launches LayerNorm and the GEMM that
  * consumes it as one kernel behind a grid barrier in one-sequence frames (96 -> 72 launches, same bits, measured slower). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
