@@ -223,7 +223,7 @@ int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int
 /* Test hooks.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
  * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs.
  * "pair_text" (default 1): where the text branch rides in the visual launches instead of running on a second stream -- 0 never,
- * 1 one-sequence frames and the many-sequence frames it measured ahead on (UVLTrack-L from 6000 visual rows, any model from
+ * 1 one-sequence frames and the many-sequence frames it measured ahead on (UVLTrack-L from 5000 visual rows, any model from
  * 16000), 2 wherever the pair kernels exist (>= 2048 rows), 3 one-sequence frames only.  "fuse_contrast" (default 1): 0 selects
  * the stand-alone contrast kernels, so that tests and tools can compare the launch forms (same results).  "fold_modal"
  * (default 1): 0 keeps the fusion layers' modal embedding in their LayerNorm-1 (1: in the previous fc2 epilogue where the

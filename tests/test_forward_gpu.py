@@ -462,12 +462,12 @@ def test_large_batch_matches_single_sequence_runs(name, batch):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     big = eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
     big = {k: v.cpu().numpy() for k, v in big.items() if torch.is_tensor(v)}
-    # which text placement the frame took BY DEFAULT: riders for UVLTrack-L from 6000 visual rows and for any model from 16000, else the second stream
+    # which text placement the frame took BY DEFAULT: riders for UVLTrack-L from 5000 visual rows and for any model from 16000, else the second stream
     eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]), profile=True)
     torch.cuda.synchronize()
     kernels = {e["kernel"] for e in eng.profile_entries()}
     rows = batch * (1 + (spec.template_size // 16) ** 2 + (spec.search_size // 16) ** 2)
-    want_riders = rows >= 16000 or (spec.dim >= 1024 and rows >= 6000)
+    want_riders = rows >= 16000 or (spec.dim >= 1024 and rows >= 5000)
     has_riders = any(k.startswith(("gemm_dr_pair_kernel", "gemm_pipe_pair_kernel", "attn_p64_rider_kernel")) for k in kernels)
     assert has_riders == want_riders, (rows, sorted(kernels))
     if want_riders:

@@ -571,7 +571,8 @@ struct TrainBranch { const uint8_t* template_mask; const uint8_t* context_mask; 
 // Does the text branch ride in the visual launches (single-stream frame), or run on its own stream?
 // One sequence: always (unless pair_text = 0).  Many sequences: only where the visual GEMMs take the large-tile kernels, which have pair forms
 // (launch_gemm_pair), and by default only where the riders measured ahead of the second stream (interleaved tools/ab_tune.py debug.pair_text 3 1,
-// profiles/r04_text_branch.md): UVLTrack-L x 8 / 16 / 32 +1.9 / +1.4 / +0.3 %, UVLTrack-B x 32 +1.3..1.8 %, but UVLTrack-B x 12 / 16 -1.0 % (a rider tile
+// profiles/r04_text_branch.md): UVLTrack-L x 6 / 8 / 16 / 32 +0.7 / +1.9 / +1.4 / +0.3 % (x 4: -4.8 %, its kernels have no pair forms), UVLTrack-B x 32 +1.3..1.8 %,
+// but UVLTrack-B x 12 / 16 / 24 -1.0 / -1.0 / -1.6 % (a rider tile
 // streams its BERT weights at HBM latency -- three to ten row tiles per weight panel -- and holds its slot about twice as long as a visual
 // tile; the six-layer branch of UVLTrack-B hides better on the second stream until the frame is long).
 static bool text_rides(const uvl_model* m, int B, int skip, int reuse) {
@@ -583,7 +584,7 @@ static bool text_rides(const uvl_model* m, int B, int skip, int reuse) {
                        tune_get(&m->tune, &uvl_tuning::gemm_pipe, 1) != 0 && m->tune.text_cfg < 0;
     if (!forms) return false;
     if (m->pair_text >= 2) return true;
-    return rows >= 6000 && (m->D >= 1024 || rows >= 16000) && m->tune.gemm_cfg < 0 && m->tune.attn_cfg < 0;
+    return rows >= 5000 && (m->D >= 1024 || rows >= 16000) && m->tune.gemm_cfg < 0 && m->tune.attn_cfg < 0;
 }
 
 static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, hipStream_t s, Profiler* prof,
