@@ -1305,7 +1305,7 @@ __device__ __forceinline__ void attn_p64_walk(const AttnParams& p, const int tot
 }
 
 __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
-    kernarg_warm<sizeof(AttnParams) + 24>();
+    kernarg_warm<sizeof(AttnParams) + 24 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
 }
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, co
 // last workgroup first.
 __global__ __launch_bounds__(256, 2) void attn_p64_rider_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh,
                                                                 const AttnParams pb, const int tail_only) {
-    kernarg_warm<2 * sizeof(AttnParams) + 32>();
+    kernarg_warm<2 * sizeof(AttnParams) + 32 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
     const int nqb_b = (pb.N + 127) / 128, total_b = nqb_b * pb.H * pb.B;

@@ -143,6 +143,8 @@ __device__ __forceinline__ int swz64(int row, int chunk8) { return row * 128 + (
 // written segment is a miss, and a launch-bound kernel pays them one after the other before its first global load.  Measured on the
 // one-sequence frame (rocprofv3 --stats, two runs each): GEMM launches -0.3..0.7 us, attention -0.2..0.5, LayerNorm -0.1..0.4; the frame's kernel
 // time 760-775 -> 739-740 us.
+// (kernels that read gridDim / blockDim add 64 bytes: the first line of the hidden arguments behind the explicit ones.  Only those: a kernel that
+// uses no hidden argument has none in its segment, and the request must stay inside the segment.)
 template <int BYTES>
 __device__ __forceinline__ void kernarg_warm() {
 #ifndef UVL_NO_KERNARG_WARM            // (development A/B: tools/probes/bench_lib.py on a variant build)

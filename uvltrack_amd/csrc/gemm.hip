@@ -291,7 +291,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
 __global__ __launch_bounds__(64 * (WGM * WGN + PROD), PROD ? (2 * (WGM * WGN + PROD)) / 4 : 1) void gemm_glds_kernel(const GemmParams p) {
-    kernarg_warm<sizeof(GemmParams)>();
+    kernarg_warm<sizeof(GemmParams) + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t pfs = prefetch_issue<64 * (WGM * WGN + PROD)>(p.pf, p.pf_bytes, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>(p, blockIdx.x, blockIdx.y, CONV ? blockIdx.z : 0, smem);
@@ -820,7 +820,7 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
 // is reused, because the nine M tiles of a visual GEMM share each weight tile through L2).
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b) {
-    kernarg_warm<2 * sizeof(GemmParams) + 16>();
+    kernarg_warm<2 * sizeof(GemmParams) + 16 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t pfs = prefetch_issue<64 * WGM * WGN>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);     // (the visual problem's next weight; the rider's gain nothing from it)
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch

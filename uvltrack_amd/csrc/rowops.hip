@@ -18,13 +18,13 @@ namespace uvl {
 
 template <int NV, bool FULL, bool SLABS, int CT>
 __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
-    kernarg_warm<sizeof(LnParams)>(); ln_body<NV, FULL, SLABS, CT>(p, blockIdx.x); }
+    kernarg_warm<sizeof(LnParams) + 64>(); ln_body<NV, FULL, SLABS, CT>(p, blockIdx.x); }
 
 // Two independent LayerNorm problems in one launch (batch-1 frames pair every text-branch kernel with the visual kernel
 // of the same kind, see uvl_api.hip): workgroups [0, split) work on pa, the rest on pb.
 template <int NV, bool FULL, bool SLABS, int CT>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
-    kernarg_warm<2 * sizeof(LnParams) + 8>();
+    kernarg_warm<2 * sizeof(LnParams) + 8 + 64>();
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
     if ((int)blockIdx.x < split) ln_body<NV, FULL, SLABS, CT>(pa, (int)blockIdx.x);
     else ln_body<NV, FULL, SLABS, 0>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
