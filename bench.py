@@ -10,7 +10,8 @@ tracking/profile_model.py:30-47 (warm-up, then K timed forwards, sync only at bo
 
 A step = one pass of the hot path over one batch of synthetic frames per GPU (inputs resident in HBM, weights
 from the deterministic generator).  Each rank owns its own sequences (independent per-sequence
-shards, weights replicated); after every step the per-shard boxes are all-gathered over RCCL on the process group's stream.
+shards, weights replicated); the per-shard boxes of every step are all-gathered over RCCL, eight steps per collective, in stream order
+(uvltrack_amd.shard.BoxGatherer: an overlapped collective per step cost the one-sequence frame 11 %, this form a quarter of a percent).
 A timed BLOCK is exactly `--steps` steps between barrier + synchronize on both sides, maximum over ranks; the line reports the
 MEDIAN of `--blocks` such blocks (default: as many as fit in about three seconds, 3..400), so a 20-step run of a 0.7 ms frame is
 not a 15 ms sample.  Rank 0 prints ONE JSON line.
@@ -166,30 +167,28 @@ class NoDist:
 def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmup: int, blocks: int, on_result=None):
     """THE loop of this benchmark -- also what tests/test_bench_loop_gloo.py drives with a stub step over gloo.
     step_fn(i) enqueues one frame of this rank's sequences; local_boxes_fn() is the [n_local, 4] tensor it leaves; gatherer
-    (uvltrack_amd.shard.BoxGatherer, or None for one process) all-gathers them, double-buffered so the collective of step i
-    overlaps step i + 1.  on_result(i, boxes) is called on every rank with the gathered boxes of step i once they are complete
-    (one step late, as a consumer of the boxes would).  Returns the list of block times (seconds, maximum over ranks), `blocks`
+    (uvltrack_amd.shard.BoxGatherer, or None for one process) all-gathers them, a group of steps per collective.  on_result(i, boxes)
+    is called on every rank, in step order, with the gathered boxes of step i once its group is complete (and at the end of a run).  Returns the list of block times (seconds, maximum over ranks), `blocks`
     entries (0 = choose from the first block: about three seconds in total, 3..400)."""
     counter = [0]
     delivered = [-1]
 
-    def deliver(i):
-        if gatherer is not None and on_result is not None and i > delivered[0]:
-            on_result(i, gatherer.result(i))
-            delivered[0] = i
+    def deliver_upto(i):
+        if gatherer is not None and on_result is not None:
+            for j in range(delivered[0] + 1, i + 1):
+                on_result(j, gatherer.result(j))
+        delivered[0] = max(delivered[0], i)
 
     def one(i):
         step_fn(i)
-        if gatherer is not None:
-            gatherer.submit(i, local_boxes_fn())
-            if i >= 1:
-                deliver(i - 1)
+        if gatherer is not None and gatherer.submit(i, local_boxes_fn()):
+            deliver_upto(i)
 
     def finish(last):
         if gatherer is not None:
-            if last >= 0:
-                deliver(last)
             gatherer.drain()
+            if last >= 0:
+                deliver_upto(last)
 
     def run(n):
         first = counter[0]

@@ -115,8 +115,8 @@ def _worker_one(port, q):
         for i in range(4):
             b = torch.stack([_boxes(s, i) for s in range(3)])
             g.submit(i, b)
-            ok &= g._pending[i & 1] is not None            # a real collective was enqueued, also for a group of one rank
             ok &= bool(torch.equal(g.result(i), b))
+            ok &= g.collectives == i + 1                   # a real collective was enqueued, also for a group of one rank
         g.drain()
         q.put(ok)
     finally:

@@ -1,10 +1,10 @@
 """Multi-GPU sharding of the per-frame path: independent per-sequence batch shards, weights replicated,
-one all-gather of the per-shard boxes per step.
+the per-shard boxes all-gathered in groups of a few steps.
 
 The reference runs one sequence per worker with `gpu_id = worker_id % num_gpu` and no communication
 (lib/test/evaluation/running.py:96-100,168-171); here one process per GPU owns a contiguous shard of the
 sequences and the decoded boxes are gathered over RCCL (backend "nccl" on ROCm) so every rank -- in particular
-rank 0 -- sees the boxes of all sequences after each step.  Backend-agnostic: the CPU tests use gloo.
+rank 0 -- sees the boxes of all sequences of every step.  Backend-agnostic: the CPU tests use gloo.
 """
 from __future__ import annotations
 
@@ -28,10 +28,18 @@ def shard_sizes(n_sequences: int, world: int) -> List[int]:
 
 
 class BoxGatherer:
-    """All-gather of [n_local, 4] boxes into [n_total, 4] in global sequence order, double-buffered so the collective
-    of step i overlaps the forward pass of step i+1 (the gather runs on the process group's own stream)."""
+    """All-gather of [n_local, 4] boxes into [n_total, 4] in global sequence order.  The boxes of `every` consecutive steps travel in ONE
+    collective ([every, n_local, 4] per rank), issued in stream order on the caller's stream (a synchronous c10d call: the stream waits for
+    the collective, the host does not): the ranks meet once per group instead of once per frame, and a consumer sees a step's boxes at
+    most `every` - 1 frames late (result() of a step that is still waiting gathers what is there).
 
-    def __init__(self, n_sequences: int, device, group=None):
+    Why not one overlapped collective per step (the form of rounds 1-3: async_op=True, double-buffered, waited for two steps later)?
+    Measured on one MI355X under torch.distributed.run (tools/probes/gather_cost.py, UVLTrack-B one sequence, us per step): no gather 771,
+    the box copy alone 773, the overlapped per-step gather 860 (+11.5 %) -- and 853-856 with the same asynchronous call every EIGHTH step:
+    what costs is a second queue that stays live beside the frame's ~96 dependent launches, not the collective; the synchronous call on
+    the frame's own stream costs 782 (+1.4 %) per step, a group of eight a quarter of a percent."""
+
+    def __init__(self, n_sequences: int, device, group=None, every: int = 8):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -39,35 +47,50 @@ class BoxGatherer:
         self.sizes = shard_sizes(n_sequences, self.world)
         self.lo, self.hi = shard_range(n_sequences, self.rank, self.world)
         self.pad = max(self.sizes) if self.sizes else 0          # ragged shards are padded to the largest one
-        self._in = [torch.zeros(self.pad, 4, device=device) for _ in range(2)]
-        self._out = [torch.zeros(self.world * self.pad, 4, device=device) for _ in range(2)]
-        self._pending = [None, None]
+        self.every = max(1, int(every))
+        self._ring = torch.zeros(self.every, self.pad, 4, device=device)
+        self._out = torch.zeros(self.world, self.every, self.pad, 4, device=device)
+        self._first, self._count = 0, 0                          # steps [first, first + count) wait in the ring
+        self._done_first, self._done_n = 0, 0                    # steps [done_first, done_first + done_n) are in _out
+        self.collectives = 0
 
-    def submit(self, step: int, local_boxes: torch.Tensor):
-        """Enqueue the gather of this step's boxes ([n_local, 4]); returns immediately."""
-        k = step & 1
-        if self._pending[k] is not None:
-            self._pending[k].wait()
+    def submit(self, step: int, local_boxes: torch.Tensor) -> bool:
+        """Take this step's boxes ([n_local, 4]); True when that completed a group and its collective has been enqueued."""
         n_local = self.hi - self.lo
         if tuple(local_boxes.shape) != (n_local, 4):
             raise ValueError("expected [%d, 4] local boxes, got %s" % (n_local, tuple(local_boxes.shape)))
-        self._in[k][:n_local].copy_(local_boxes)
+        if self._count == 0:
+            self._first = step
+        elif step != self._first + self._count:
+            raise ValueError("steps must be submitted in order: expected %d, got %d" % (self._first + self._count, step))
+        self._ring[self._count, :n_local].copy_(local_boxes)
+        self._count += 1
+        if self._count == self.every:
+            self.flush()
+            return True
+        return False
+
+    def flush(self):
+        """Gather whatever waits in the ring (every rank calls this at the same steps)."""
+        if self._count == 0:
+            return
         if dist.is_initialized():          # also a group of ONE rank: the collective leg (RCCL on GPUs) is the same code at every world size
-            self._pending[k] = dist.all_gather_into_tensor(self._out[k], self._in[k], group=self.group, async_op=True)
+            dist.all_gather_into_tensor(self._out.view(self.world * self.every, self.pad, 4), self._ring, group=self.group)   # rank-major concatenation
         else:
-            self._out[k].copy_(self._in[k])
+            self._out[0].copy_(self._ring)
+        self._done_first, self._done_n = self._first, self._count
+        self._count = 0
+        self.collectives += 1
 
     def result(self, step: int) -> torch.Tensor:
-        """Boxes of every sequence for `step`, [n_sequences, 4] in global order (waits for that step's gather)."""
-        k = step & 1
-        if self._pending[k] is not None:
-            self._pending[k].wait()
-            self._pending[k] = None
-        parts = [self._out[k][r * self.pad: r * self.pad + self.sizes[r]] for r in range(self.world)]
+        """Boxes of every sequence for `step`, [n_sequences, 4] in global order (a step still in the ring is gathered now)."""
+        if self._count and self._first <= step < self._first + self._count:
+            self.flush()
+        s = step - self._done_first
+        if not 0 <= s < self._done_n:
+            raise ValueError("step %d is not among the gathered steps [%d, %d)" % (step, self._done_first, self._done_first + self._done_n))
+        parts = [self._out[r, s, :self.sizes[r]] for r in range(self.world)]
         return torch.cat(parts, dim=0)
 
     def drain(self):
-        for k in range(2):
-            if self._pending[k] is not None:
-                self._pending[k].wait()
-                self._pending[k] = None
+        self.flush()
