@@ -61,3 +61,50 @@ def test_box_gather_world2_gloo(n_seq):
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == [0, 1]
     assert all(ok for _, ok in res)
+
+
+def _worker_groups(rank, world, port, n_seq, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = BoxGatherer(n_seq, torch.device("cpu"), every=8)
+        lo, hi = shard_range(n_seq, rank, world)
+        box = lambda s, t: torch.tensor([s, t, s * t, 1.0])
+        ok, done = True, []
+        for step in range(19):
+            local = torch.stack([box(s, step) for s in range(lo, hi)]) if hi > lo else torch.zeros(0, 4)
+            if g.submit(step, local):              # a group of eight steps has just been gathered: all of its steps can be read
+                done.append(step)
+                for t in range(step - 7, step + 1):
+                    ok &= bool(torch.equal(g.result(t), torch.stack([box(s, t) for s in range(n_seq)])))
+        ok &= done == [7, 15] and g.collectives == 2
+        g.drain()                                  # the three steps left in the ring travel in a third collective
+        ok &= g.collectives == 3
+        for t in (16, 17, 18):
+            ok &= bool(torch.equal(g.result(t), torch.stack([box(s, t) for s in range(n_seq)])))
+        try:
+            g.result(3)                            # an earlier group's slot has been reused
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_box_gather_groups_of_eight_steps_world2_gloo():
+    """The form bench.py runs: the boxes of eight steps per collective, a partial group at the end of a run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_groups, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == [0, 1]
+    assert all(ok for _, ok in res)
