@@ -198,6 +198,10 @@ hipError_t launch_pack_w_dr(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream
     return hipGetLastError();
 }
 
+#ifdef GEMM_DR_TRACE          // development (tools/dr_wgtrace.py on a variant build): per workgroup {start, K loop done, end} in 100 MHz ticks + where it ran
+__device__ unsigned long long g_dr_trace[4096 * 4];
+#endif
+
 constexpr int DR_LDS_BIAS = 73728, DR_LDS_BYTES = DR_LDS_BIAS + 1024;       // A ring (4 x 16 KB) / epilogue slices (<= 72 KB), then the tile's bias row
 
 template <int EPI>
@@ -218,6 +222,11 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
         nt = within / gm;
         mt = gi * p.group_m + (within - nt * gm);
     }
+#ifdef GEMM_DR_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned tr_hw = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);       // HW_REG_HW_ID, 32 bits (simm16 = (size - 1) << 11 | offset << 6 | id)
+    const unsigned tr_xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);                              // HW_REG_XCC_ID, bits 0..3
+#endif
     const int m0 = mt * BM, n0 = nt * BN;
     const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
     const int nk = p.K / 64;
@@ -255,10 +264,19 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
 #endif
     // the epilogue takes its lane index from the hardware again: the block clobbers v0..v113, and every per-lane value the compiler keeps
     // across it has to live in the 14 registers above (one more was a spill = scratch for the whole kernel)
+#ifdef GEMM_DR_TRACE
+    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (EPI == EPI_BF16 && p.act == 1) gemm_epilogue_dr<EPI, 1>(p, accv, smem, sbias, m0, n0, lane_e, wave);
     else if (EPI == EPI_BF16 && p.act == 2) gemm_epilogue_dr<EPI, 2>(p, accv, smem, sbias, m0, n0, lane_e, wave);
     else gemm_epilogue_dr<EPI, 0>(p, accv, smem, sbias, m0, n0, lane_e, wave);
+#ifdef GEMM_DR_TRACE
+    if (threadIdx.x == 0 && bx < 4096) {                     // (no wait for the output stores: the wave ends with them in flight, as in the product)
+        g_dr_trace[bx * 4 + 0] = tr0; g_dr_trace[bx * 4 + 1] = tr1; g_dr_trace[bx * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        g_dr_trace[bx * 4 + 3] = ((unsigned long long)tr_xcc << 32) | tr_hw;
+    }
+#endif
 }
 
 template <int EPI>
@@ -358,3 +376,7 @@ hipError_t launch_gemm_dr(const GemmParams& p, int epi, hipStream_t s) {
 }
 
 }  // namespace uvl
+
+#ifdef GEMM_DR_TRACE
+extern "C" int uvl_debug_dr_trace(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(uvl::g_dr_trace), (size_t)n * 4 * sizeof(unsigned long long)); }
+#endif
