@@ -39,7 +39,6 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
     constexpr int LPR = WN * ES / 16;                           // lanes per row on the way out
     constexpr int RPI = 64 / LPR;                               // rows per store instruction
     constexpr int NSL = (EPI == EPI_F32) ? 2 : 4;               // 32-row slices per wave (4 waves x NSL x 32 rows x RS <= 72 KB)
-    const bool has_bias = p.bias != nullptr;
     const int colw = n0 + wave * WN;                            // first column of this wave's sub-tile
     const bool vpart = EPI == EPI_QKV && colw >= 2 * p.D;       // wave-uniform: D % 64 == 0
     const float qs = (EPI == EPI_QKV && colw < p.D) ? p.q_scale : 1.0f;
@@ -62,7 +61,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                     const int cc = col - 2 * p.D, hh = cc >> 6, dd = cc & 63;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(accv[ib][4 * jb + e] + (has_bias ? bv[jb][e] : 0.f));
+                        p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(accv[ib][4 * jb + e] + bv[jb][e]);
                 }
             }
         }
@@ -79,7 +78,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                 const int cl = 16 * jb + 4 * g;
                 const f32x16& a = accv[ib];
                 f32x4 v = {a[4 * jb], a[4 * jb + 1], a[4 * jb + 2], a[4 * jb + 3]};
-                if (has_bias) v += bv[jb];
+                v += bv[jb];                                   // (an absent bias is a row of zeros in LDS: no select per element -- 128 v_cndmask per wave and tile)
                 if (EPI == EPI_QKV) v *= qs;
                 if (EPI == EPI_F32) {
                     *reinterpret_cast<f32x4*>(cw + (16 * h + l15) * RS + cl * 4) = v;
