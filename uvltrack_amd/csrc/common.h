@@ -101,6 +101,31 @@ __device__ __forceinline__ f32x2 gelu_erf_poly2(f32x2 x) {
     const f32x2 hx = x * 0.5f;
     return __builtin_elementwise_fma(hx, e, hx);
 }
+// Two pairs at once, the two Horner chains written step by step side by side: a chain alone is eight DEPENDENT packed operations (hipcc even
+// puts an s_nop between consecutive ones), and the epilogue that runs it holds a workgroup slot (profiles/r04_gemm_dr.md, last section).  Same
+// operations on every element as gelu_erf_poly2: same bits.
+__device__ __forceinline__ f32x4 gelu_erf_poly4(f32x4 x) {
+    const f32x2 xa = {x[0], x[1]}, xb = {x[2], x[3]};
+    const f32x2 ca = {__builtin_amdgcn_fmed3f(x[0], -3.8f, 3.8f), __builtin_amdgcn_fmed3f(x[1], -3.8f, 3.8f)};
+    const f32x2 cb = {__builtin_amdgcn_fmed3f(x[2], -3.8f, 3.8f), __builtin_amdgcn_fmed3f(x[3], -3.8f, 3.8f)};
+    const f32x2 ta = ca * ca, tb = cb * cb;
+    f32x2 qa = __builtin_elementwise_fma(ta, f32x2{7.331552609e-08f, 7.331552609e-08f}, f32x2{-4.544922376e-06f, -4.544922376e-06f});
+    f32x2 qb = __builtin_elementwise_fma(tb, f32x2{7.331552609e-08f, 7.331552609e-08f}, f32x2{-4.544922376e-06f, -4.544922376e-06f});
+    qa = __builtin_elementwise_fma(qa, ta, f32x2{1.213695723e-04f, 1.213695723e-04f});
+    qb = __builtin_elementwise_fma(qb, tb, f32x2{1.213695723e-04f, 1.213695723e-04f});
+    qa = __builtin_elementwise_fma(qa, ta, f32x2{-1.863094978e-03f, -1.863094978e-03f});
+    qb = __builtin_elementwise_fma(qb, tb, f32x2{-1.863094978e-03f, -1.863094978e-03f});
+    qa = __builtin_elementwise_fma(qa, ta, f32x2{1.863326877e-02f, 1.863326877e-02f});
+    qb = __builtin_elementwise_fma(qb, tb, f32x2{1.863326877e-02f, 1.863326877e-02f});
+    qa = __builtin_elementwise_fma(qa, ta, f32x2{-1.314395666e-01f, -1.314395666e-01f});
+    qb = __builtin_elementwise_fma(qb, tb, f32x2{-1.314395666e-01f, -1.314395666e-01f});
+    qa = __builtin_elementwise_fma(qa, ta, f32x2{7.973535061e-01f, 7.973535061e-01f});
+    qb = __builtin_elementwise_fma(qb, tb, f32x2{7.973535061e-01f, 7.973535061e-01f});
+    const f32x2 ea = ca * qa, eb = cb * qb;
+    const f32x2 ha = xa * 0.5f, hb = xb * 0.5f;
+    const f32x2 ra = __builtin_elementwise_fma(ha, ea, ha), rb = __builtin_elementwise_fma(hb, eb, hb);
+    return f32x4{ra[0], ra[1], rb[0], rb[1]};
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // Output row m -> (sample b = m / rpb, row inside the sample m % rpb) for the rows of ONE block of at most 32 consecutive rows, without a division per

@@ -84,8 +84,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                     *reinterpret_cast<f32x4*>(cw + (16 * h + l15) * RS + cl * 4) = v;
                 } else {
                     if (EPI == EPI_BF16 && ACT == 1) {
-                        const f32x2 g0 = gelu_erf_poly2(f32x2{v[0], v[1]}), g1 = gelu_erf_poly2(f32x2{v[2], v[3]});
-                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                        v = gelu_erf_poly4(v);
                     } else if (EPI == EPI_BF16 && ACT == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);

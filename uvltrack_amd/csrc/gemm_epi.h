@@ -85,8 +85,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     *reinterpret_cast<f32x4*>(cw + rl * RS + cl * 4) = v;
                 } else {
                     if (EPI == EPI_BF16 && p.act == 1) {
-                        const f32x2 g0 = gelu_erf_poly2(f32x2{v[0], v[1]}), g1 = gelu_erf_poly2(f32x2{v[2], v[3]});
-                        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                        v = gelu_erf_poly4(v);
                     } else if (EPI == EPI_BF16 && p.act == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
