@@ -35,7 +35,6 @@ __device__ __forceinline__ void gemm_bias_preload(const GemmParams& p, int colw,
 template <int TM, int TN, int WM, int WN, int EPI, int NW, bool L16 = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
                                                   int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4]) {
-    const bool has_bias = p.bias && sk == 0;
     constexpr int ES = (EPI == EPI_F32) ? 4 : 2;               // output element size
     constexpr int RS = WN * ES + 16;                            // padded LDS row stride
     constexpr int LPR = WN * ES / 16;                           // lanes per row on the way out
@@ -64,7 +63,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                             const int r0 = L16 ? 4 * (2 * hi + q) : 4 * q;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][r0 + e] + (has_bias ? bv[j][q][e] : 0.f));
+                                p.vt[(((size_t)b * p.H + hh) * 64 + dd + e) * p.Npad + rem] = f2bf(acc[i][j][r0 + e] + bv[j][q][e]);
                         }
                 }
             }
@@ -79,7 +78,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 const int rl = L16 ? 16 * hi + (lane & 15) : (lane & 31);
                 const int cl = j * 32 + (L16 ? 16 * hj + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5));
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (has_bias) v += bv[j][L16 ? hj : q];
+                v += bv[j][L16 ? hj : q];                       // (bv is zero where there is no bias to add -- absent, or a split-K slice other than 0 -- so no select per element)
                 if (EPI == EPI_QKV) v *= qs;
                 if (EPI == EPI_F32) {
                     *reinterpret_cast<f32x4*>(cw + rl * RS + cl * 4) = v;
