@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--profile-json", default=None, help="also write the per-kernel breakdown to this file")
     ap.add_argument("--dist", action="store_true", help="run under torch.distributed.run even with --gpus 1 (RCCL process group of one rank)")
+    ap.add_argument("--gather-every", type=int, default=0, help="steps per box all-gather (0 = from the step time: 1 when a step is >= 2 ms, else 8; uvltrack_amd/shard.py)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="tools only: uvl_tune_set(KEY, VALUE) on the engine's handle (include/uvltrack_hip.h: uvl_tuning); recorded in the line")
     return ap.parse_args(argv)
@@ -220,7 +221,7 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     """Build an engine for `spec`, run the timed blocks; returns (times, engine, targs, outs, step description)."""
     from uvltrack_amd import weightgen as wg
     from uvltrack_amd.engine import HipEngine
-    from uvltrack_amd.shard import BoxGatherer
+    from uvltrack_amd.shard import BoxGatherer, choose_every
     flags = [flag_val] * B
     eng = HipEngine(spec, dev, max_batch=max(B, 1))
     for kv in args.tune:
@@ -239,12 +240,27 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     else:
         _, outs = eng.capture(*targs, skip_text=skip_text)
         step_fn = eng.replay
-    # RCCL all-gather of the per-shard boxes: rank r owns sequences [r*B, (r+1)*B)
-    gatherer = BoxGatherer(env.world * B, dev) if isinstance(env, DistEnv) else None      # also with ONE rank under torch.distributed.run
+    # RCCL all-gather of the per-shard boxes: rank r owns sequences [r*B, (r+1)*B).  One collective per step wherever a
+    # step is >= 2 ms (configs[4]); sub-millisecond frames send eight steps per collective (shard.choose_every): the cadence comes from a
+    # few untimed steps, the slowest rank's figure, so that every rank builds the same groups
+    gatherer = None
+    if isinstance(env, DistEnv):                      # also with ONE rank under torch.distributed.run
+        every = int(getattr(args, "gather_every", 0) or 0)
+        if every <= 0:
+            for _ in range(3):
+                step_fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step_fn()
+            torch.cuda.synchronize()
+            every = choose_every(env.max_over_ranks((time.perf_counter() - t0) / 5) * 1e3)
+        gatherer = BoxGatherer(env.world * B, dev, every=every)
     times = timed_blocks(lambda i: step_fn(), lambda: outs["pred_boxes"].view(B, 4), gatherer, env, torch.cuda.synchronize, steps, warmup, blocks)
     finite = bool(torch.isfinite(outs["bbox_map"]).all().item()) and bool(torch.isfinite(outs["logits"]).all().item())
     if not finite:
         raise SystemExit("bench.py: the forward pass produced non-finite outputs -- timing of a broken path is not reported")
+    eng.gather_every = gatherer.every if gatherer is not None else None
     return times, eng, targs, outs
 
 
@@ -264,15 +280,21 @@ def kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, singl
     event_overhead_ms = max(0.0, (sum(e["ms"] for e in prof) - frame_ms) / max(n_launch, 1)) if single_stream else 0.0
     by_kernel = {}
     for e in prof:
-        k = by_kernel.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, sites=[]))
+        k = by_kernel.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, bytes_weights=0.0, launches=0, sites=[]))
         k["ms"] += e["ms"]; k["flops"] += e["flops"]; k["bytes"] += e["bytes"]; k["launches"] += e["launches"]
+        k["bytes_weights"] += e.get("bytes_weights", e["bytes"])
         k["sites"].append(e["site"])
 
     def block(name, d):
         raw_avg_ms = d["ms"] / max(d["launches"], 1)
         avg_ms = max(raw_avg_ms - event_overhead_ms, 0.25 * raw_avg_ms)
         tf = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12 if d["flops"] > 0 else 0.0
-        gbs = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+        # TWO byte counts.  `bytes_weights` = SURVEY 8(d)'s algorithmic count (weights touched once, activations cache-resident; attention:
+        # q, k, v in + o out): `bound` / `achieved` / `frac` are formed on IT, so the figure is comparable across rounds (rounds 1-3: 0.074-0.078
+        # for the same ~9.1 us kernel that round 4's wider count reported as 0.183).  `bytes` = that + what the kernel must also move (A rows,
+        # the bf16 / f32 output, the f32 read-modify-write of the residual epilogue, once per split-K slab): reported beside it as frac_hbm_moved.
+        gbs_moved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+        gbs = d["bytes_weights"] / d["launches"] / (avg_ms * 1e-3) / 1e9
         frac_mfma, frac_hbm = tf / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, see
         # profiles/*_pmc_summary.md); null when no PMC pass of this kernel instantiation on this workload has been committed
@@ -293,7 +315,9 @@ def kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, singl
         regime = "latency" if max(frac_mfma, frac_hbm) < 0.15 else bound
         return {"bound": bound, "regime": regime, "kernel": name, "sites": sorted(set(d["sites"])), "launches_per_frame": d["launches"],
                 "avg_launch_us": avg_ms * 1e3, "avg_launch_us_event_pair": raw_avg_ms * 1e3, "event_overhead_us": event_overhead_ms * 1e3,
-                "flops_per_launch": d["flops"] / max(d["launches"], 1), "bytes_per_launch": d["bytes"] / max(d["launches"], 1),
+                "flops_per_launch": d["flops"] / max(d["launches"], 1), "bytes_per_launch": d["bytes_weights"] / max(d["launches"], 1),
+                "bytes_weights_per_launch": d["bytes_weights"] / max(d["launches"], 1), "frac_hbm_weights": frac_hbm,
+                "bytes_moved_per_launch": d["bytes"] / max(d["launches"], 1), "achieved_gbs_moved": gbs_moved, "frac_hbm_moved": gbs_moved / PEAK_HBM_GBS,
                 "achieved": tf if bound == "mfma" else gbs, "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(frac_mfma, frac_hbm),
                 "achieved_tflops": tf, "frac_mfma": frac_mfma, "achieved_gbs": gbs, "frac_hbm": frac_hbm, "traffic": traffic,
@@ -386,7 +410,10 @@ def main():
                 args.model, spec.template_size, spec.search_size, spec.text_len, args.mode, " (text branch skipped)" if skip_text else (" (text branch reused from the first frame)" if reuse_text else ""), B),
                 "per_gpu_batch": B, "global_batch": B * world, "tokens_visual": spec.nv, "tokens_joint": spec.nj,
                 "gflop_per_frame": flops_frame / 1e9, "launches_per_frame": n_launch,
-                "launch": "hipgraph" if use_graph else ("eager-1-stream" if single_stream else "eager-2-streams"), "parallelism": "dp%d" % world},
+                "launch": "hipgraph" if use_graph else ("eager-1-stream" if single_stream else "eager-2-streams"), "parallelism": "dp%d" % world,
+                # the box all-gather's cadence (uvltrack_amd/shard.py): steps per collective and the worst-case lateness of a step's boxes,
+                # in steps; null without a process group (one plain process: nothing to gather)
+                "gather_every": eng.gather_every, "gather_lateness_steps": None if eng.gather_every is None else eng.gather_every - 1},
             "frame_model_tflops": flops_frame * fps / 1e12,
             "frame_mfma_frac": flops_frame * fps / 1e12 / (PEAK_BF16_TFLOPS * world),
             "frame_hbm_frac": (weight_bytes * (args.steps / elapsed)) / 1e9 / PEAK_HBM_GBS,

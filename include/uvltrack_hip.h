@@ -219,6 +219,9 @@ int uvl_forward_test_profiled(uvl_model_t* m, const uvl_inputs* in, const uvl_ou
 int uvl_profile_count(const uvl_model_t* m);
 int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int name_cap,
                       double* ms, double* flops, double* bytes, int* launches);
+/* The same entry's bytes on SURVEY section 8(d)'s count -- weights touched once, activations cache-resident (GEMM / conv sites: the
+ * weight; attention: q, k, v in + o out; row kernels: as `bytes`) -- beside `bytes`, which also counts what the epilogue moves. */
+int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
 
 /* Test hooks.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
  * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs.

@@ -56,6 +56,10 @@ def test_library_is_stamped_with_the_tested_toolchain(lib, monkeypatch):
     binding refuses a library with another stamp -- both behind one environment override."""
     from uvltrack_amd import _native, build
     assert lib.uvl_build_toolchain().decode() == build.TESTED_HIPCC == build.hipcc_version("/opt/rocm/bin/hipcc")
+    # the same release under another build hash is the same compiler; another version number, or an unstamped library, is not
+    assert build.same_toolchain(build.TESTED_HIPCC.rsplit("-", 1)[0] + "-0123456789")
+    assert not build.same_toolchain("HIP version: 7.3.0-" + build.TESTED_HIPCC.rsplit("-", 1)[1])
+    assert not build.same_toolchain("unknown") and not build.same_toolchain("")
     monkeypatch.delenv(build.OVERRIDE_ENV, raising=False)
     monkeypatch.setattr(build, "TESTED_HIPCC", "HIP version: 0.0.0")
     with pytest.raises(RuntimeError, match="not the tested toolchain"):

@@ -8,6 +8,7 @@ import socket
 import sys
 import time
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -20,7 +21,7 @@ def _boxes(seq, step):
     return torch.rand(4, generator=g)
 
 
-def _worker(rank, world, port, B, q):
+def _worker(rank, world, port, B, every, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -43,23 +44,28 @@ def _worker(rank, world, port, B, q):
             exp = torch.stack([_boxes(s, i) for s in range(world * B)])
             seen.append((i, bool(torch.equal(boxes, exp))))
 
-        gatherer = BoxGatherer(world * B, dev)
+        gatherer = BoxGatherer(world * B, dev, every=every)
         steps, warmup, blocks = 6, 3, 2
         times = bench.timed_blocks(step_fn, lambda: local, gatherer, env, lambda: None, steps, warmup, blocks, on_result=on_result)
         ok = len(times) == blocks and all(t >= steps * 0.002 * 0.9 for t in times)          # rank 0 reports rank 1's time too
         ok &= [i for i, _ in seen] == list(range(warmup + blocks * steps)) and all(f for _, f in seen)
+        # one collective per step, or one per group of `every` steps + one per partial group at the end of a run (warm-up, each block)
+        runs = [warmup] + [steps] * blocks
+        ok &= gatherer.collectives == sum(-(-n // every) for n in runs)
         q.put((rank, ok, times))
     finally:
         dist.destroy_process_group()
 
 
-def test_bench_loop_world2_gloo():
+@pytest.mark.parametrize("every", [1, 8, 4])
+def test_bench_loop_world2_gloo(every):
+    """Both cadences of the box all-gather: per step (steps of >= 2 ms: BASELINE configs[4]) and per group (sub-millisecond frames)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 3, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 3, every, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -110,7 +116,7 @@ def _worker_one(port, q):
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         from uvltrack_amd.shard import BoxGatherer
-        g = BoxGatherer(3, torch.device("cpu"))
+        g = BoxGatherer(3, torch.device("cpu"), every=1)
         ok = True
         for i in range(4):
             b = torch.stack([_boxes(s, i) for s in range(3)])
@@ -121,6 +127,14 @@ def _worker_one(port, q):
         q.put(ok)
     finally:
         dist.destroy_process_group()
+
+
+def test_gather_cadence_follows_the_step_time():
+    """one all-gather per step wherever a step is long enough for it to be free (configs[4]: ~6 ms); groups of eight only
+    for sub-millisecond frames.  The bench line reports the cadence and the worst-case lateness."""
+    from uvltrack_amd.shard import choose_every
+    assert choose_every(6.2) == 1 and choose_every(2.0) == 1
+    assert choose_every(0.73) == 8 and choose_every(1.9) == 8
 
 
 def test_gatherer_runs_the_collective_for_a_group_of_one():

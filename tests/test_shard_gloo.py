@@ -26,14 +26,15 @@ def _worker(rank, world, port, n_seq, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = BoxGatherer(n_seq, torch.device("cpu"))
+        g = BoxGatherer(n_seq, torch.device("cpu"))          # every = 1: SURVEY 8e's one all-gather per step
         lo, hi = shard_range(n_seq, rank, world)
-        ok = True
+        ok = g.every == 1 and g.lateness == 0
         for step in range(5):
             # box of sequence s at step t is a known function of (s, t)
             local = torch.stack([torch.tensor([s, step, s * step, 1.0]) for s in range(lo, hi)]) if hi > lo else torch.zeros(0, 4)
             g.submit(step, local)
-            if step >= 1:           # overlapped: read the previous step while this one is in flight
+            ok &= g.collectives == step + 1
+            if step >= 1:           # the previous step's boxes stay readable beside this step's
                 got = g.result(step - 1)
                 exp = torch.stack([torch.tensor([s, step - 1, s * (step - 1), 1.0]) for s in range(n_seq)])
                 ok &= bool(torch.equal(got, exp))
@@ -79,10 +80,18 @@ def _worker_groups(rank, world, port, n_seq, q):
                 for t in range(step - 7, step + 1):
                     ok &= bool(torch.equal(g.result(t), torch.stack([box(s, t) for s in range(n_seq)])))
         ok &= done == [7, 15] and g.collectives == 2
+        try:
+            g.result(17)                           # still in the ring: result() never communicates (a rank-local flush would deadlock the others)
+            ok = False
+        except ValueError:
+            pass
+        ok &= g.collectives == 2
+        ok &= bool(torch.equal(g.result(2), torch.stack([box(s, 2) for s in range(n_seq)])))      # the previous group stays readable
         g.drain()                                  # the three steps left in the ring travel in a third collective
         ok &= g.collectives == 3
-        for t in (16, 17, 18):
+        for t in (16, 17, 18, 9, 15):              # the last two groups
             ok &= bool(torch.equal(g.result(t), torch.stack([box(s, t) for s in range(n_seq)])))
+        ok &= g.lateness == 7
         try:
             g.result(3)                            # an earlier group's slot has been reused
             ok = False

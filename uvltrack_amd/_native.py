@@ -18,7 +18,7 @@ UVL_NFAM = 5
 EXPORTS = [
     "uvl_last_error", "uvl_version", "uvl_build_toolchain", "uvl_create", "uvl_destroy", "uvl_load_tensor", "uvl_finalize_weights",
     "uvl_workspace_bytes", "uvl_forward_test", "uvl_forward_prompt", "uvl_forward", "uvl_anno2mask", "uvl_decode", "uvl_crop_geometry_of", "uvl_sample_target", "uvl_sample_target_window", "uvl_sample_target_staged", "uvl_grounding_resize", "uvl_normalize_u8", "uvl_graph_capture", "uvl_graph_launch", "uvl_graph_release",
-    "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_debug_set", "uvl_tune_set", "uvl_tuning_init", "uvl_linear_splitk",
+    "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_profile_entry_weight_bytes", "uvl_debug_set", "uvl_tune_set", "uvl_tuning_init", "uvl_linear_splitk",
     "uvl_linear", "uvl_linear_pk", "uvl_pack_weight", "uvl_attention", "uvl_qkv_project", "uvl_qkv_project_pk", "uvl_layernorm", "uvl_f32_to_bf16", "uvl_fold_conv_bn", "uvl_conv_tower_layer",
 ]
 
@@ -96,7 +96,7 @@ def load():
     # hand-counted waits / generated K loops are only known-good for one hipcc (uvltrack_amd/build.py): refuse a library built by another
     from . import build as _build
     stamp = (lib.uvl_build_toolchain() or b"").decode()
-    if stamp != _build.TESTED_HIPCC:
+    if not _build.same_toolchain(stamp):
         msg = ("%s was built by '%s', not by the tested toolchain '%s' (hand-counted waits in the attention / GEMM kernels); rebuild with "
                "it, or set %s=1 and re-run the forced-kernel GPU tests" % (LIB_PATH, stamp, _build.TESTED_HIPCC, _build.OVERRIDE_ENV))
         if os.environ.get(_build.OVERRIDE_ENV) != "1":
@@ -130,6 +130,7 @@ def load():
     lib.uvl_profile_count.argtypes = [vp]
     lib.uvl_profile_entry.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.uvl_profile_entry_weight_bytes.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.uvl_debug_set.argtypes = [vp, C.c_char_p, i32]
     tp = C.POINTER(UvlTuning)
     lib.uvl_tune_set.argtypes = [vp, C.c_char_p, i32]

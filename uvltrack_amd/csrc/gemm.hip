@@ -1267,7 +1267,8 @@ hipError_t launch_ln_gemm_pair(const LnParams& la, const LnParams* lb, const Gem
     }
     const bool ok = bar && plain(a) && (!b || (plain(*b) && b->epi == a.epi)) && pick_plain_cfg(a) == 4 && (!b || pick_plain_cfg(*b) == 4) && ring1_depth(a) == 4 &&
                     tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0 && (a.M + 63) / 64 < 16 && (!b || (b->M + 63) / 64 < 16) && blocks <= resident_limit &&
-                    (la.D == 768 || la.D == 1024) && (!lb || lb->D == la.D) && la.nsplit <= LN_MAX_SLABS && (!lb || (lb->nsplit <= LN_MAX_SLABS && !lb->ct_x)) &&
+                    (la.D == 768 || la.D == 1024) && (!lb || lb->D == la.D) && la.nsplit <= LN_MAX_SLABS && !la.ct_self &&      // (ct_self: the direct contrast job needs ln_body's CT = 2 form; the fused kernel instantiates CT = 1)
+                    (!lb || (lb->nsplit <= LN_MAX_SLABS && !lb->ct_x)) &&
                     la.y_bf16 == a.A && (!lb || !b || lb->y_bf16 == b->A) && (lb != nullptr) == (b != nullptr);
     *fused = ok;
     if (!ok) {

@@ -203,10 +203,12 @@ __device__ unsigned long long g_dr_trace[4096 * 4];
 constexpr int DR_LDS_BIAS = 73728, DR_LDS_BYTES = DR_LDS_BIAS + 1024;       // A ring (4 x 16 KB) / epilogue slices (<= 72 KB), then the tile's bias row
 
 template <int EPI>
-__device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, char* smem) {
+__device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, char* smem, const int wave) {
     constexpr int BM = 128, BN = 256;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // `wave` arrives as an SGPR and the lane comes from the hardware: threadIdx.x itself must not live across the asm block (the pair kernel's
+    // two bodies share code, and a thread index kept for the second one was a spill = a scratch segment for every wave of the launch)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int tid = wave * 64 + lane;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
     int nt, mt;
     {   // grouped tile order cut into 8 contiguous runs, one per XCD (see gemm_glds_body)
@@ -281,7 +283,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_dr_kernel(const GemmParams p) {
     kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_dr_body<EPI>(p, blockIdx.x, smem);
+    gemm_dr_body<EPI>(p, blockIdx.x, smem, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 }
 
 template <int EPI>
@@ -317,8 +319,9 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_dr_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
     kernarg_warm<2 * sizeof(GemmParams) + 8>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x >= blocks_b) gemm_dr_body<EPI>(pa, (int)blockIdx.x - blocks_b, smem);
-    else gemm_dr_body<EPI>(pb, blockIdx.x, smem);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if ((int)blockIdx.x >= blocks_b) gemm_dr_body<EPI>(pa, (int)blockIdx.x - blocks_b, smem, wave);
+    else gemm_dr_body<EPI>(pb, blockIdx.x, smem, wave);
 }
 
 static bool dr_ok(const GemmParams& p) {

@@ -61,10 +61,11 @@ struct ConvLayerW {
 struct ProfEntry {
     std::string name, kernel;
     double ms = 0, flops = 0, bytes = 0;
+    double wbytes = 0;              // SURVEY 8(d)'s count: weights touched once, activations cache-resident (attention: q, k, v in + o out)
     int launches = 0;
 };
 struct Profiler {
-    struct Rec { hipEvent_t a, b; const char* name; const char* kernel; double flops, bytes; };
+    struct Rec { hipEvent_t a, b; const char* name; const char* kernel; double flops, bytes, wbytes; };
     std::vector<Rec> recs;
 };
 
@@ -488,7 +489,10 @@ struct Launcher {
     Profiler* prof;
     int parts = PART_ALL, cur = PART_V1;
     int err = 0;
+    double wb_next = -1;            // the weights-once byte count of the NEXT run() (GEMM / conv sites set it); < 0: the same as `bytes`
     void run(hipStream_t s, const char* what, double flops, double bytes, hipError_t (*fn)(void*, hipStream_t), void* ctx) {
+        const double wbytes = wb_next >= 0 ? wb_next : bytes;
+        wb_next = -1;
         if (err || !(parts & cur)) return;
         Profiler::Rec r{};
         if (prof) {
@@ -500,7 +504,7 @@ struct Launcher {
         if (e != hipSuccess) { err = fail(UVL_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e)); return; }
         if (prof) {
             hipEventRecord(r.b, s);
-            r.name = what; r.kernel = g_last_kernel; r.flops = flops; r.bytes = bytes;
+            r.name = what; r.kernel = g_last_kernel; r.flops = flops; r.bytes = bytes; r.wbytes = wbytes;
             prof->recs.push_back(r);
         }
     }
@@ -508,7 +512,7 @@ struct Launcher {
 template <class P_, hipError_t (*F)(const P_&, hipStream_t)>
 static hipError_t tramp(void* ctx, hipStream_t s) { return F(*(const P_*)ctx, s); }
 
-#define RUN_GEMM(L, s, p, what) (L).run((s), (what), 2.0 * (p).M * (p).N * (p).K * ((p).groups > 0 ? (p).groups : 1), \
+#define RUN_GEMM(L, s, p, what) (L).wb_next = 2.0 * (double)(p).N * (p).K * ((p).groups > 0 ? (p).groups : 1), (L).run((s), (what), 2.0 * (p).M * (p).N * (p).K * ((p).groups > 0 ? (p).groups : 1), \
     2.0 * ((double)(p).M * (p).K + (double)(p).N * (p).K * ((p).groups > 0 ? (p).groups : 1)), tramp<GemmParams, launch_gemm>, &(p))
 
 // One layer of the four conv towers (heads/utils.py:126-131 with BatchNorm folded, modality_adaptive_box_head.py:28-50): grouped
@@ -636,7 +640,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     const bool fork = !skip && !reuse && !prof && m->nf > 0 && parts == PART_ALL && !paired && m->fork_text;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
     enum { R_GEMM = 0, R_ATTN = 1, R_LN = 2 };
-    struct Rider { int kind; const char* what; double flops, bytes; GemmParams g; AttnParams a; LnParams l; int layer; };
+    struct Rider { int kind; const char* what; double flops, bytes, wbytes; GemmParams g; AttnParams a; LnParams l; int layer; };
     int rider_layer = 0;                         // BERT layer whose launches are being queued
     std::vector<Rider> riders;                   // text-branch launches waiting for a visual launch of the same kind
     size_t rider_at = 0;
@@ -675,16 +679,18 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         // algorithmic bytes: both operands once + what the epilogue moves (bf16 rows; f32 rows, read too by the in-place residual form, once per slab)
         const double out_b = (double)p.M * p.N * (p.epi == 1 ? 4.0 * (p.accumulate ? 2 : 1) * (p.splitk > 1 ? p.splitk : 1) : 2.0);
         const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K) + out_b;
-        if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.g = p; r.layer = rider_layer; riders.push_back(r); return; }
+        const double wb = 2.0 * (double)p.N * p.K;          // the weight, once
+        if (paired && is_text) { Rider r{}; r.kind = R_GEMM; r.what = what; r.flops = fl; r.bytes = by; r.wbytes = wb; r.g = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (pend_ln.on && !is_text) {
             LnGemm c{};
             c.la = pend_ln.a; c.lb = pend_ln.b; c.has_lb = pend_ln.has_b; c.ga = p; c.has_gb = false; c.bar = m->gbar; c.gen = m->gbar_gen + 1; c.base = &m->gbar_base; c.fused = false;
-            double fl2 = fl, by2 = by + pend_ln.bytes;
+            double fl2 = fl, by2 = by + pend_ln.bytes, wb2 = wb;
             if (paired && rider_at < riders.size() && riders[rider_at].kind == R_GEMM && riders[rider_at].g.epi == p.epi) {
                 const Rider& r = riders[rider_at++];
-                c.gb = r.g; c.has_gb = true; fl2 += r.flops; by2 += r.bytes;
+                c.gb = r.g; c.has_gb = true; fl2 += r.flops; by2 += r.bytes; wb2 += r.wbytes;
             }
             pend_ln.on = false;
+            L.wb_next = wb2;
             L.run(st, what, fl2, by2, [](void* cc, hipStream_t q) {
                 auto* x = (LnGemm*)cc;
                 return launch_ln_gemm_pair(x->la, x->has_lb ? &x->lb : nullptr, x->ga, x->has_gb ? &x->gb : nullptr, x->bar, x->gen, x->base, &x->fused, q);
@@ -695,15 +701,17 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_GEMM && riders[rider_at].g.epi == p.epi) {
             GemmPair gp{p, riders[rider_at].g};
             const Rider& r = riders[rider_at++];
+            L.wb_next = wb + r.wbytes;
             L.run(st, what, fl + r.flops, by + r.bytes, [](void* c, hipStream_t q) { auto* x = (GemmPair*)c; return launch_gemm_pair(x->a, x->b, q); }, &gp);
             return;
         }
+        L.wb_next = wb;
         L.run(st, what, fl, by, tramp<GemmParams, launch_gemm>, &p);
     };
     auto run_attn = [&](hipStream_t st, AttnParams& p, const char* what, double fl, double by, bool is_text) {
         p.tune = &m->tune;
         if (!is_text) flush_ln(st);
-        if (paired && is_text) { Rider r{}; r.kind = R_ATTN; r.what = what; r.flops = fl; r.bytes = by; r.a = p; r.layer = rider_layer; riders.push_back(r); return; }
+        if (paired && is_text) { Rider r{}; r.kind = R_ATTN; r.what = what; r.flops = fl; r.bytes = by; r.wbytes = by; r.a = p; r.layer = rider_layer; riders.push_back(r); return; }
         if (paired && rider_at < riders.size() && riders[rider_at].kind == R_ATTN) {
             AttnPair ap{p, riders[rider_at].a};
             const Rider& r = riders[rider_at++];
@@ -713,7 +721,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         L.run(st, what, fl, by, tramp<AttnParams, launch_attention>, &p);
     };
     auto run_ln = [&](hipStream_t st, LnParams& p, double by, bool is_text) {
-        if (paired && is_text) { Rider r{}; r.kind = R_LN; r.what = "layernorm"; r.flops = 0; r.bytes = by; r.l = p; r.layer = rider_layer; riders.push_back(r); return; }
+        if (paired && is_text) { Rider r{}; r.kind = R_LN; r.what = "layernorm"; r.flops = 0; r.bytes = by; r.wbytes = by; r.l = p; r.layer = rider_layer; riders.push_back(r); return; }
         flush_ln(st);
         if (fuse_ln && !is_text && p.y_bf16 && (L.parts & L.cur)) {      // held for the GEMM that reads p.y_bf16
             pend_ln.on = true; pend_ln.a = p; pend_ln.has_b = false; pend_ln.bytes = by;
@@ -734,7 +742,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     auto flush_riders = [&](hipStream_t st, int upto_layer = 1 << 30) {    // whatever did not find a partner runs alone, in order
         for (; rider_at < riders.size() && riders[rider_at].layer <= upto_layer; ++rider_at) {
             Rider& r = riders[rider_at];
-            if (r.kind == R_GEMM) L.run(st, r.what, r.flops, r.bytes, tramp<GemmParams, launch_gemm>, &r.g);
+            if (r.kind == R_GEMM) { L.wb_next = r.wbytes; L.run(st, r.what, r.flops, r.bytes, tramp<GemmParams, launch_gemm>, &r.g); }
             else if (r.kind == R_ATTN) L.run(st, r.what, r.flops, r.bytes, tramp<AttnParams, launch_attention>, &r.a);
             else L.run(st, r.what, 0, r.bytes, tramp<LnParams, launch_layernorm>, &r.l);
         }
@@ -1072,7 +1080,7 @@ extern "C" int uvl_forward_test_profiled(uvl_model_t* m, const uvl_inputs* in, c
         float ms = 0;
         hipEventElapsedTime(&ms, r.a, r.b);
         ProfEntry& e = agg[std::string(r.name) + "|" + r.kernel];      // one entry per (launch site, kernel instantiation)
-        e.name = r.name; e.kernel = r.kernel; e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
+        e.name = r.name; e.kernel = r.kernel; e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.wbytes += r.wbytes; e.launches += 1;
         int fam = 4;
         if (!strncmp(r.name, "gemm", 4)) fam = 0;
         else if (!strncmp(r.name, "attention", 9)) fam = 1;
@@ -1093,6 +1101,12 @@ extern "C" int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* 
     if (name && name_cap > 0) { strncpy(name, e.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
     if (kernel && name_cap > 0) { strncpy(kernel, e.kernel.c_str(), name_cap - 1); kernel[name_cap - 1] = 0; }
     if (ms) *ms = e.ms; if (flops) *flops = e.flops; if (bytes) *bytes = e.bytes; if (launches) *launches = e.launches;
+    return UVL_OK;
+}
+
+extern "C" int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes) {
+    if (!m || i < 0 || i >= (int)m->prof.size() || !bytes) return fail(UVL_EINVAL, "bad profile index");
+    *bytes = m->prof[i].wbytes;
     return UVL_OK;
 }
 

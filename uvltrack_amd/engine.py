@@ -72,7 +72,10 @@ class HipEngine:
     def tune_set(self, key: str, value: int):
         """uvl_tune_set on THIS engine's handle (there is no process-global tuning state); -1 restores the heuristic."""
         _native.check(self.lib.uvl_tune_set(self.handle, key.encode(), int(value)), "uvl_tune_set(%s)" % key)
-        self.__dict__.setdefault("_tuning", {})[key] = int(value)
+        if key == "reset":
+            self.__dict__["_tuning"] = {}                      # the handle holds heuristics only again: nothing to restore to
+        else:
+            self.__dict__.setdefault("_tuning", {})[key] = int(value)
 
     def debug_set(self, key: str, value: int):
         """uvl_debug_set on this engine's handle: A/B aids that are not launch heuristics (stop_layer, pair_text, fuse_contrast, fork_text, fuse_ln)."""
@@ -381,7 +384,10 @@ class HipEngine:
             kern = C.create_string_buffer(96)
             ms, fl, by, ln = C.c_double(), C.c_double(), C.c_double(), C.c_int()
             _native.check(self.lib.uvl_profile_entry(self.handle, k, name, kern, 96, C.byref(ms), C.byref(fl), C.byref(by), C.byref(ln)))
-            res.append(dict(site=name.value.decode(), kernel=kern.value.decode(), ms=ms.value, flops=fl.value, bytes=by.value, launches=ln.value))
+            wb = C.c_double()
+            _native.check(self.lib.uvl_profile_entry_weight_bytes(self.handle, k, C.byref(wb)))
+            res.append(dict(site=name.value.decode(), kernel=kern.value.decode(), ms=ms.value, flops=fl.value, bytes=by.value,
+                            bytes_weights=wb.value, launches=ln.value))
         return res
 
     # ------------------------------------------------------------------ hipGraph replay
