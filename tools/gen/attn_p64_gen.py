@@ -42,8 +42,11 @@ def S(par, r): return 96 + 16 * par + r
 def P(par, t2): return 128 + 8 * par + 4 * t2
 def KF(buf, k): return 144 + 16 * buf + 4 * k
 def VF(buf, f): return 176 + 16 * buf + 4 * f          # f = 2 * t2 + db
-def KA(r): return 208 + r
-def PS(x, i): return 224 + 2 * x + i
+def KA(r): return 208 + r                          # mask term of key block 0 of a masked tile, in score-register order: the C operand of its score MFMAs
+def KB(r): return 192 + r                          # the same for key block 1 (loaded while key block 0's MFMAs still read KA)
+def PS(x, i): return 224 + 2 * x + i               # (P64_OPT rsum=0 only: row sums as f32 adds)
+def PSQ(x): return 164 + 4 * x                     # row-sum accumulator quad of query block x (all four registers hold the same sum)
+V_ONES = 160                                       # v160:161 = four bf16 ones: the A operand of the row-sum MFMA
 def KOFF(kk): return 228 + kk
 def VOFF(jb, t2): return 232 + 2 * jb + t2
 def DK(i): return 236 + i
@@ -120,9 +123,9 @@ def advance_round():
 
 
 def tail_fix(a, stage, tag):
-    """Zero the V^T columns of keys >= N in this wave's own two pieces of the tail tile (NaN-proof: 0 x garbage would poison P V);
-    executed once per item, behind the wave's own vmcnt wait and in front of the barrier.  The K rows need nothing: scores of keys
-    >= N are replaced, not added to."""
+    """Zero the V^T columns AND the K rows of keys >= N in this wave's own pieces of the tail tile (NaN-proof: 0 x garbage would poison
+    P V, and a garbage K row would poison the score the -inf mask term is ADDED to -- the mask term is the C operand of the score MFMA since
+    round 5); executed once per item, behind the wave's own vmcnt wait and in front of the barrier."""
     skip = "tfx%s" % tag
     a.e("s_add_u32 %s, %s, 2" % (s("x0"), s("t")))                       # this barrier publishes tile t + 1; the tail tile is nt - 1
     a.e("s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")))
@@ -157,35 +160,66 @@ def tail_fix(a, stage, tag):
             a.e("v_or_b32 %s, %s, %s" % (v(m1), v(m1), v(m2)))
             a.e("v_and_b32 %s, %s, %s" % (v(d + e), v(d + e), v(m1)))
         a.e("ds_write_b128 %s, %s offset:%d" % (v(t1), vr(d, 4), off))
+    # K rows: piece i of this wave holds rows 8 (wave + 4 i) + (lane >> 3), 16 bytes per lane at t1 + i * 4096
+    a.e("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(m1))
+    a.e("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(m1), v(m1)))
+    a.e("v_lshrrev_b32 %s, 3, %s" % (v(m1), v(m1)))
+    a.e("s_lshl_b32 %s, %s, 3" % (s("x0"), s("wave")))
+    a.e("v_add_u32 %s, %s, %s" % (v(m1), s("x0"), v(m1)))                 # row of piece 0
+    for e in range(4):
+        a.e("v_mov_b32 %s, 0" % v(d + e))
+    for i in range(2):
+        if i:
+            a.e("v_add_u32 %s, 32, %s" % (v(m1), v(m1)))
+        a.e("v_cmp_le_i32 vcc, %s, %s" % (s("ntail"), v(m1)))              # ntail <= row: a key >= N
+        a.e("s_and_saveexec_b64 %s, vcc" % s2("x2"))
+        a.e("ds_write_b128 %s, %s offset:%d" % (v(t1), vr(d, 4), stage * STAGE + i * 4096))
+        a.e("s_mov_b64 exec, %s" % s2("x2"))
     a.e("s_waitcnt lgkmcnt(0)")
     a.label(skip)
 
 
-def ka_load(stage, jb):
-    """masked variant: this wave's copy of the tile's key_add row, the 16 values of key block jb in score-register order"""
+def ka_load(stage, jb, base):
+    """this wave's copy of the tile's key_add row, the 16 values of key block jb in score-register order, into base .. base + 15"""
     out = []
     for gq in range(4):
         off = stage * 1024 + jb * 128 + (gq >> 1) * 64 + (gq & 1) * 16
-        out.append("ds_read_b128 %s, %s offset:%d" % (vr(KA(4 * gq), 4), v(V_KAADDR), off))
+        out.append("ds_read_b128 %s, %s offset:%d" % (vr(base + 4 * gq, 4), v(V_KAADDR), off))
     return out
 
 
-def ka_scale():
-    return ["v_mul_f32 %s, 0x3fb8aa3b, %s" % (v(KA(r)), v(KA(r))) for r in range(16)]       # log2 domain
+def ka_scale(base):
+    return ["v_mul_f32 %s, 0x3fb8aa3b, %s" % (v(base + r), v(base + r)) for r in range(16)]       # log2 domain
 
 
-def mask_apply(par, jb):
-    """s = key < limit ? s + key_add : -inf   (limit = valid keys of the tile - 8 * half; 64 - 8 * half unless it is the tail)"""
+def ka_limit(base, jb):
+    """term = key < limit ? term : -inf   (limit = valid keys of the tile - 8 * half; 64 - 8 * half unless it is the tail).  Once per key
+    block and wave -- the term then enters BOTH query blocks' scores as the C operand of their first score MFMA; until round 4 it was added
+    and limited per query block behind the MFMAs (48 VALU per block and key block, plus a 48-VALU block for the pending scores)."""
     out = []
     for r in range(16):
         key = 32 * jb + 16 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3)
-        out.append("v_add_f32 %s, %s, %s" % (v(S(par, r)), v(S(par, r)), v(KA(r))))
         out.append("v_cmp_lt_i32 vcc, %d, %s" % (key, v(V_LIM)))
-        out.append("v_cndmask_b32 %s, %s, %s, vcc" % (v(S(par, r)), v(V_NEGINF), v(S(par, r))))
+        out.append("v_cndmask_b32 %s, %s, %s, vcc" % (v(base + r), v(V_NEGINF), v(base + r)))
     return out
 
 
-OPT = dict(prio=1, dma_v=0, spread=0, adv_v=0)
+def masked_tile_entry(a, st):
+    """in front of a masked tile's first M phase: the tile's key limit and the mask term of key block 0"""
+    a.e("s_add_u32 %s, %s, 1" % (s("x0"), s("t")))
+    a.e("s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")))
+    a.e("s_cselect_b32 %s, %s, 0" % (s("x0"), s("tailf")))
+    a.e("s_cmp_lg_u32 %s, 0" % s("x0"))
+    a.e("s_cselect_b32 %s, %s, 64" % (s("x0"), s("ntail")))
+    a.e("v_sub_u32 %s, %s, %s" % (v(V_LIM), s("x0"), v(V_HALF8)))
+    for t in ka_load(st, 0, KA(0)):
+        a.e(t)
+    a.e("s_waitcnt lgkmcnt(0)")
+    for t in ka_scale(KA(0)) + ka_limit(KA(0), 0):
+        a.e(t)
+
+
+OPT = dict(prio=1, dma_v=0, spread=0, adv_v=0, rsum=0)
 for _kv in os.environ.get("P64_OPT", "").split(","):
     if "=" in _kv:
         OPT[_kv.split("=")[0]] = int(_kv.split("=")[1])
@@ -196,13 +230,39 @@ SG["pmask"] = 39
 SG["ptr"] = 38
 
 
+def rowsum_mfma(x, j):
+    """Row sums on the matrix pipe (round 5): v_mfma_f32_4x4x4_16b_bf16 computes, for each of 16 blocks of four lanes, D = A B + C with 4 x 4
+    operands; with A = ones, lane l's four result registers all become C + the sum of the four bf16 values lane l itself holds in its B
+    registers.  One such instruction on an aligned pair of packed P registers replaces four v_add_f32: 8 cycles of the matrix pipe and one
+    issue slot instead of four slots of the VALU port, which is what bounds this loop at head_dim 64 (2 exponentials + 2 adds + 1 pack per
+    32-cycle MFMA; profiles/r05_attention.md).  The sum is that of the bf16-rounded P the P V MFMA multiplies -- numerator and denominator of
+    the softmax now see the same numbers."""
+    q = PSQ(x)
+    return "v_mfma_f32_4x4x4_16b_bf16 %s, %s, %s, %s" % (vr(q, 4), vr(V_ONES, 2), vr(P(x, j >> 1) + 2 * (j & 1), 2), vr(q, 4))
+
+
 def softmax_gaps(x):
-    """The 40 VALU of one query block's softmax in eight groups: exp2 pairs lead, their row-sum adds and the pack trail one group,
-    so nothing waits for the transcendental pipe"""
+    return _softmax_gaps(x, OPT["rsum"] == 1 or (OPT["rsum"] == 2 and x == 0) or (OPT["rsum"] == 3 and x == 1))
+
+
+def _softmax_gaps(x, by_mfma):
+    """One query block's softmax in groups (eight, or nine with the MFMA row sums): exp2 pairs lead, the pack (and the row-sum adds of the
+    rsum=0 form) trail one group so nothing waits for the transcendental pipe; a row-sum MFMA follows the second pack of its register pair
+    by at least two issue slots (VALU write -> MFMA read)"""
     ex = lambda r: "v_exp_f32 %s, %s" % (v(S(x, r)), v(S(x, r)))
     ad = lambda r: "v_add_f32 %s, %s, %s" % (v(PS(x, r & 1)), v(PS(x, r & 1)), v(S(x, r)))
     cv = lambda i: "v_cvt_pk_bf16_f32 %s, %s, %s" % (v(P(x, i >> 2) + (i & 3)), v(S(x, 2 * i)), v(S(x, 2 * i + 1)))
     gaps = [[] for _ in range(8)]
+    if by_mfma:
+        for i in range(8):
+            gaps[i] += [ex(2 * i), ex(2 * i + 1)]
+            if i >= 1:
+                gaps[i] += [cv(i - 1)]
+            if i in (3, 5, 7) and "norsum" not in ABL:      # packs 2 j, 2 j + 1 are in groups 2 j + 1, 2 j + 2: the MFMA rides in group 2 j + 3, behind two exponentials
+                gaps[i].insert(2, rowsum_mfma(x, (i - 3) // 2))
+        gaps[7] += [cv(7)]
+        gaps.append([rowsum_mfma(x, 3)] if "norsum" not in ABL else [])            # (its caller keeps two issue slots between the last pack and this one)
+        return gaps
     for i in range(8):
         gaps[i] += [ex(2 * i), ex(2 * i + 1)]
         if i >= 1:
@@ -245,7 +305,8 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
     for x in range(2):
         for k in range(4):
             if qk:
-                mf.append(mfma(S(x, 0), KF(0, k), Q(x, k), None if k == 0 else S(x, 0)))
+                c0 = (KA(0) if jb == 0 else KB(0)) if masked else None      # the mask term rides in as the accumulator's initial value
+                mf.append(mfma(S(x, 0), KF(0, k), Q(x, k), c0 if k == 0 else S(x, 0)))
             mf.append(mfma(O(x, k & 1, 0), VF(0, k), P(x, k >> 1), O(x, k & 1, 0)))         # fragment k = 2 t2 + db
     gaps = softmax_gaps(1)
     nA = 8 if qk else 4                             # drain: P V only, block B's softmax in the four gaps of block A's MFMAs
@@ -268,16 +329,9 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
     else:
         for i in range(8):
             fill[i * nA // 8] += gaps[i]
+        if len(gaps) > 8:                           # the last row-sum MFMA: two issue slots behind the last pack (block B's first two MFMAs)
+            fill[nA + 1] += gaps[8]
     pre = []
-    if body and jb == 0:
-        # block B's pending scores belong to tile t - 1: its mask term (if that tile carried one) is still in KA / V_LIM
-        skip = "pm%d%s" % (st, "m" if masked else "p")
-        pre.append("s_cmp_eq_u32 %s, 0" % s("pmask"))
-        pre.append("s_cbranch_scc1 %s" % a.ref(skip))
-        pre += mask_apply(1, 1)
-        pre.append("LABEL " + skip)
-    elif body and masked:
-        pre += mask_apply(1, 0)
     late = {i: [] for i in range(len(mf))}
     if body:
         rd = dma_round((st + 2) & 3)
@@ -293,15 +347,14 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
             adv = advance_round()
             late[14] += adv[0:5]
             late[15] += adv[5:11]
-        if masked:
-            # this key block's mask term for the V phase that follows (and for block B in the next M phase)
-            if jb == 0:
-                late[8] += ["s_add_u32 %s, %s, 1" % (s("x0"), s("t")), "s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")),
-                            "s_cselect_b32 %s, %s, 0" % (s("x0"), s("tailf")), "s_cmp_lg_u32 %s, 0" % s("x0"),
-                            "s_cselect_b32 %s, %s, 64" % (s("x0"), s("ntail")), "v_sub_u32 %s, %s, %s" % (v(V_LIM), s("x0"), v(V_HALF8))]
-            late[8] += ka_load(st, jb)
-            late[13] += ["s_waitcnt lgkmcnt(0)"] + ka_scale()[:8]
-            late[15] += ka_scale()[8:]
+        if masked and jb == 0:
+            # key block 1's mask term, into its own registers (block B's first score MFMA of THIS phase still reads KA), in block B's bare gaps
+            late[8] += ka_load(st, 1, KB(0))
+            sc, lm = ka_scale(KB(0)), ka_limit(KB(0), 1)
+            late[9] += ["s_waitcnt lgkmcnt(0)"] + sc[:8]
+            late[10] += sc[8:] + lm[:8]
+            late[12] += lm[8:20]
+            late[15] += lm[20:]
     for i, m in enumerate(mf):
         a.e(m)
         if i == 0:
@@ -337,9 +390,6 @@ def phase_V(a, st, jb, masked, body=True):
         a.e("ds_read_b128 %s, %s offset:%d" % (vr(VF(0, f), 4), v(VOFF(jb, f >> 1)), st * STAGE + (f & 1) * 4096))
     if body and jb == 1:
         a.e("ds_read_b32 %s, %s offset:%d" % (v(V_KACUR), v(V_KAREAD), sn * 1024))
-    if masked:
-        for t in mask_apply(0, jb):
-            a.e(t)
     extra = []
     if body and OPT["dma_v"]:
         rd = dma_round((st + 2) & 3)
@@ -348,11 +398,14 @@ def phase_V(a, st, jb, masked, body=True):
         extra += advance_round()
     grps = softmax_gaps(0)
     for i, grp in enumerate(grps):
+        if i == 8:
+            a.e("s_nop 1")                          # VALU write -> MFMA read: two wait states behind the last pack
         for t in grp:
             a.e(t)
         # the scalar / DMA extras between the VALU groups
-        for t in extra[i * len(extra) // 8:(i + 1) * len(extra) // 8]:
-            a.e(t)
+        if i < 8:
+            for t in extra[i * len(extra) // 8:(i + 1) * len(extra) // 8]:
+                a.e(t)
     if body and jb == 1:
         a.e("s_waitcnt lgkmcnt(0)")
         a.e("v_cmp_neq_f32 vcc, 0, %s" % v(V_KACUR))
@@ -362,10 +415,11 @@ def phase_V(a, st, jb, masked, body=True):
 
 
 def tile_body(a, st, masked):
+    if masked:
+        masked_tile_entry(a, st)
     for jb in range(2):
         phase_M(a, st, jb, masked)
         phase_V(a, st, jb, masked)
-    a.e("s_mov_b32 %s, %d" % (s("pmask"), 1 if masked else 0))          # block B's scores of key block 1 are still pending
     a.e("s_add_u32 %s, %s, 1" % (s("t"), s("t")))
     a.e("s_add_u32 %s, %s, 1" % (s("x0"), s("t")))
     a.e("s_cmp_eq_u32 %s, %s" % (s("x0"), s("nt")))
@@ -478,6 +532,8 @@ def lane_constants(a):
     a.e("s_lshl_b32 %s, %s, 10" % (s("x0"), s("wave")))
     a.e("s_add_u32 %s, %s, %s" % (s("wl"), s("lds"), s("x0")))            # this wave's piece 0 of stage 0
     a.e("v_mov_b32 %s, 0xff800000" % v(V_NEGINF))
+    for i in range(2):
+        a.e("v_mov_b32 %s, 0x3f803f80" % v(V_ONES + i))                   # bf16 (1, 1)
     for f in range(4):                                                    # "tile -1" runs P V against P = 0: its V^T fragments must be finite
         for r in range(4):
             a.e("v_mov_b32 %s, 0" % v(VF(1, f) + r))
@@ -520,7 +576,8 @@ def epilogue(a):
     a.e("s_lshl_b32 %s, %s, 7" % (s("x4"), s("H")))
     buf = 96                                                              # v96.. (scores, P, fragments: all dead) hold the packed rows
     for x in range(2):
-        a.e("v_add_f32 %s, %s, %s" % (v(l0), v(PS(x, 0)), v(PS(x, 1))))
+        a.e("v_add_f32 %s, %s, %s" % (v(l0), v(PS(x, 0)), v(PS(x, 1))))          # (one of the two forms stays zero)
+        a.e("v_add_f32 %s, %s, %s" % (v(l0), v(l0), v(PSQ(x))))
         a.e("v_mov_b32 %s, %s" % (v(l1), v(l0)))
         a.e("s_nop 1")
         a.e("v_permlane32_swap_b32 %s, %s" % (v(l0), v(l1)))
@@ -660,6 +717,8 @@ def generate(trace=False):
         for db in range(2):
             for r in range(16):
                 a.e("v_mov_b32 %s, 0" % v(O(x, db, r)))
+        for i in range(4):
+            a.e("v_mov_b32 %s, 0" % v(PSQ(x) + i))
         for i in range(2):
             a.e("v_mov_b32 %s, 0" % v(PS(x, i)))
         for t2 in range(2):
@@ -670,7 +729,6 @@ def generate(trace=False):
             a.e("v_mov_b32 %s, 0" % v(VF(0, f) + r))
     for r in range(16):                                                   # and block B's "pending scores" exponentiate to 0
         a.e("v_mov_b32 %s, 0xff800000" % v(S(1, r)))
-    a.e("s_mov_b32 %s, 0" % s("pmask"))
     a.e("s_waitcnt vmcnt(5)")                                             # q and round 0 have landed; round 1 flies
     a.e("s_barrier")
     for k in range(4):                                                    # K fragments of (tile 0, key block 0); mask flag of tile 0
@@ -700,11 +758,6 @@ def generate(trace=False):
     # ---- drain: block B's last scores are still pending (their mask term first), P V of the last key block
     a.label("drain")
     stamp(a, 2)
-    a.e("s_cmp_eq_u32 %s, 0" % s("pmask"))
-    a.e("s_cbranch_scc1 %s" % a.ref("dnm"))
-    for t in mask_apply(1, 1):
-        a.e(t)
-    a.label("dnm")
     phase_M(a, 0, 0, False, qk=False, body=False)
     a.e("s_nop 15")
     a.e("s_nop 3")
