@@ -20,7 +20,7 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # 8 UVLTrack-L sequences at z256/x384 (tests/test_forward_gpu.py::test_default_kernel_choice_of_a_many_sequence_frame names the same set)
 DEFAULT_PATH = [
     "gemm_dr_kernelILi0E", "gemm_dr_kernelILi2E", "gemm_dr_pair_kernelILi0E", "gemm_dr_pair_kernelILi2E",
-    "attn_p64_kernel", "attn_p64_rider_kernel", "gemm_pipe128_kernelILi1ELb1E", "gemm_pipe_pair_kernelILi128ELi1E",
+    "attn_p64_kernel", "attn_p64_rider_kernel", "gemm_pipe128_kernelILi1ELb1E", "gemm_pipe_pair_kernelILi128ELi1E",      # (every residual-window / tile-rows form)
 ]
 
 

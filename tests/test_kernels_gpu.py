@@ -199,6 +199,31 @@ def test_linear_direct_to_register_form(lib, M, N, K, mode):
         assert err < 3e-3, err
 
 
+@pytest.mark.parametrize("M,N,K", [(6984, 1024, 1024), (6664, 1024, 4096), (2100, 256, 768), (2049, 512, 832), (5000, 768, 3072), (2128, 256, 1024), (2241, 256, 768)])
+def test_residual_rows_requested_inside_the_k_loop(lib, M, N, K):
+    """The in-place f32 residual epilogue of the 128 x 256 pipelined GEMM (cfg 31; proj / fc2 of many-sequence frames, block.py:29-32,57-60) with its
+    residual rows requested INSIDE the K loop (gemm_pipe128_body PRE: one 16-byte load per lane and phase over eight K tiles, counted into the
+    loop's vmcnt waits): 12 (the minimum), 13, 16, 48 and 64 K tiles, ragged last row tile.  Against torch, and BIT-IDENTICAL to the form that
+    loads them in the epilogue (uvl_tuning.res_pre = 0) -- a mis-counted wait would show up as stale tile data in one of the two."""
+    x = _rand((M, K), 21).bfloat16()
+    w = (_rand((N, K), 22, 1.0 / math.sqrt(K)) + torch.linspace(-0.02, 0.03, N).cuda()[:, None]).bfloat16()
+    b = _rand((N,), 23, 0.5)
+    y0 = _rand((M, N), 24)
+    ref = x.float() @ w.float().t() + b + y0
+    out = {}
+    for pre in (1, 0):                             # res_pre = 2 forces the window (the default rule stops at K = 2048), 0 = the epilogue's own loads
+        for rep in range(3):                       # repeated: the window's loads race nothing
+            y = y0.clone()
+            _chk(lib.uvl_linear(_p(x), _p(w), _p(b), _p(y), M, N, K, 0, 1, 1, _tune(gemm_cfg=31, res_pre=2 * pre).ref(), _stream()), lib)
+            torch.cuda.synchronize()
+            if rep == 0:
+                out[pre] = y
+            else:
+                assert torch.equal(y, out[pre])
+    assert (out[1] - ref).abs().max().item() < 3e-3
+    assert torch.equal(out[1], out[0])
+
+
 @pytest.mark.parametrize("dr", [0, -1])
 def test_linear_heuristic_with_and_without_the_direct_to_register_form(lib, dr):
     """The un-forced choice at >= 2048 rows with a packed weight at hand: cfg 36 by default, the eight-wave tile grids with

@@ -73,8 +73,22 @@ class Asm:
     def __init__(self):
         self.lines = []
         self.nlabel = 0
+        self.in_loop = False
 
     def e(self, text):
+        # timing-only ablations (P64_ABL; results WRONG, build with -DATTN_P64_NOFALLBACK): instruction classes of the TILE LOOP dropped or replaced
+        if self.in_loop:
+            op = text.split(" ", 1)[0]
+            if "nomfma" in ABL and op.startswith("v_mfma"):
+                return
+            if "nosoftmax" in ABL and op in ("v_exp_f32", "v_cvt_pk_bf16_f32") or ("nosoftmax" in ABL and op == "v_add_f32"):
+                return
+            if "noexp" in ABL and op == "v_exp_f32":
+                text = "v_mov_b32" + text[len(op):]
+            if "nolds" in ABL and op == "ds_read_b128":
+                return
+            if "nodma" in ABL and op.startswith("global_load_lds"):
+                return
         self.lines.append(text)
 
     def label(self, name):
@@ -740,6 +754,7 @@ def generate(trace=False):
     a.e("s_cselect_b32 %s, 1, 0" % s("masked"))
     stamp(a, 1)
     # ---- tile loop, unrolled by the ring depth (a stage is an immediate offset)
+    a.in_loop = True
     a.label("tile0")
     for st in range(4):
         if st:
@@ -755,7 +770,8 @@ def generate(trace=False):
         a.label("mtile%d" % st)
         tile_body(a, st, True)
         a.e("s_branch %s" % a.ref("tile%d" % ((st + 1) & 3)))
-    # ---- drain: block B's last scores are still pending (their mask term first), P V of the last key block
+    # ---- drain: block B's last scores are still pending, P V of the last key block
+    a.in_loop = False
     a.label("drain")
     stamp(a, 2)
     phase_M(a, 0, 0, False, qk=False, body=False)

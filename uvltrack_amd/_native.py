@@ -55,7 +55,7 @@ class UvlCropGeometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("crop_sz", "x1", "y1", "x1_pad", "x2_pad", "y1_pad", "y2_pad")] + [("resize_factor", C.c_float)]
 
 
-TUNING_FIELDS = ("gemm_cfg", "gemm_gm", "gemm_prod", "gemm_big", "gemm_kxcd", "attn_cfg", "sk_k1", "sk_k4", "gemm_pipe", "ring1", "text_cfg", "res_store", "slab_store", "attn_wgs", "gemm_dr")
+TUNING_FIELDS = ("gemm_cfg", "gemm_gm", "gemm_prod", "gemm_big", "gemm_kxcd", "attn_cfg", "sk_k1", "sk_k4", "gemm_pipe", "ring1", "text_cfg", "res_store", "slab_store", "attn_wgs", "gemm_dr", "res_pre")
 
 
 class UvlTuning(C.Structure):

@@ -574,8 +574,18 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
 // may stay outstanding in every steady-state phase (derived as in gemm_pipe_body: wait in p, read in p + 1, wait placed before the
 // phase's own issue).  Epilogue, tile order, bias row in LDS: as gemm_pipe_body.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool MI16 = true>
+// PRE (round 5; the in-place f32 residual epilogue, K >= 12 tiles): the read half of the read-modify-write leaves the epilogue.  These GEMMs are
+// one-round launches (8 UVLTrack-L sequences: 220 tiles on 256 CUs, one workgroup per CU), so every tile reaches its epilogue at the same moment
+// and 2 x 28 MB of residual traffic ran with no MFMA beside it: +7 us (proj) / +8 us (fc2) over a bf16 store (profiles/r04_gemm_streamk.md).  A
+// wave's share of the residual tile is 64 x 64 f32 = sixteen 16-byte loads per lane, and the kernel has the registers for them (186 of 256):
+// they are issued ONE PER PHASE over eight K tiles, behind the phase's LDS-DMA, and stay in the counted vmcnt queue like the tile loads -- a
+// load has three phases (~1200 cycles) to land before a wait covers it.  Counted waits of the window: the steady state may leave the six
+// youngest LDS-DMA outstanding; a residual load issued in one of the last three phases is younger than the group a wait is for, so the count
+// grows by the number of such loads: 6, 7, 8, then 9 until the window ends, 9, 8, 7, 6 behind it (derivation at the phase list below).
+// Same operands, same order of additions as the epilogue's own load: bit-identical results.
+template <int EPI, bool MI16 = true, bool PRE = false>
 __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int bx, char* smem) {
+    static_assert(!PRE || EPI == EPI_F32, "the residual window belongs to the f32 epilogue");
     constexpr int BM = 128, BN = 256, NW = 8, WM = 64, WN = 64, TM = 2, TN = 2, NBUF = 3;
     constexpr int STAGE = (BM + BN) * 128;                   // 48 KB: A rows then W rows
     const int tid = threadIdx.x, lane = tid & 63;
@@ -649,7 +659,30 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 af[2][4], bl[4], bh[4];
 
-    const int nk = p.K / 64;                                 // >= 2 (launcher)
+    // residual rows of this wave's 64 x 64 block in the epilogue's write-out order: 16 lanes per row, 4 rows per instruction, 8 per 32-row block
+    constexpr int R_NIT = 8;
+    f32x4 res[PRE ? TM * R_NIT : 1];
+    int r_first[TM];
+    RowMap r_map[TM];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            r_first[i] = min(m0 + wm * WM + i * 32, p.M - 1);        // a block past M reads (and never stores) the last valid row
+            r_map[i] = rowmap_of(r_first[i], p.rpb);
+        }
+    }
+    auto res_load = [&](auto RI) __attribute__((always_inline)) {
+        constexpr int ri = decltype(RI)::value;
+        if constexpr (PRE && ri >= 0) {
+            constexpr int i = ri / R_NIT, it = ri % R_NIT;
+            const int row = m0 + wm * WM + i * 32 + it * 4 + (lane >> 4);
+            int b, rem;
+            rowmap_at(r_map[i], r_first[i], (row < p.M ? row : p.M - 1) - r_first[i], b, rem);
+            res[ri] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + ((size_t)b * p.obs + p.oro + rem) * p.ldc + n0 + wn * WN + (lane & 15) * 4);
+        }
+    };
+
+    const int nk = p.K / 64;                                 // >= 2 (launcher); PRE: >= 12
     f32x4 bias_in;
     if (wave == 0) {
         const float* bsrc = (p.bias ? p.bias + n0 : reinterpret_cast<const float*>(g_zero_page)) + lane * 4;
@@ -667,7 +700,7 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
     if (wm == 1) __builtin_amdgcn_s_barrier();               // wave group 1 runs half a phase behind group 0
 
     // H = 0: A + B-lo | H = 1: B-hi.  ISS: issue tile t + 2's share (H = 0: A, B-lo; H = 1: B-hi) into buffer nb between the MFMAs.
-    auto phase = [&](auto H, auto ISS, auto VM, int t, int cb, int nb) __attribute__((always_inline)) {
+    auto phase = [&](auto H, auto ISS, auto VM, int t, int cb, int nb, auto RI) __attribute__((always_inline)) {
         constexpr int h = decltype(H)::value;
         constexpr bool iss = decltype(ISS)::value != 0;
         constexpr int vm = decltype(VM)::value;
@@ -708,6 +741,7 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
                         if (mi == 1) issue1(I2{}, t + 2, nb, 0);
                         if (mi == 5) issue1(I2{}, t + 2, nb, 1);
                     }
+                    if (mi == 7) res_load(RI);               // behind the phase's LDS-DMA: the youngest entry of the queue
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -717,19 +751,42 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
     };
     using Y = std::integral_constant<int, 1>; using N_ = std::integral_constant<int, 0>;
     using V6 = std::integral_constant<int, 6>;
+    using NR = std::integral_constant<int, -1>;
     int cb = 0;                                              // buffer of K tile t
-    for (int t = 0; t < nk - 2; ++t) {
+    int t = 0;
+    auto tile = [&](auto VM0, auto VM1, auto R0, auto R1) __attribute__((always_inline)) {
         const int nb = cb == 0 ? 2 : cb - 1;                 // buffer of K tile t + 2 = (t + 2) % 3 = (t - 1) % 3
-        phase(I0{}, Y{}, V6{}, t, cb, nb);
-        phase(I1{}, Y{}, V6{}, t, cb, nb);
+        phase(I0{}, Y{}, VM0, t, cb, nb, R0);
+        phase(I1{}, Y{}, VM1, t, cb, nb, R1);
         cb = cb == 2 ? 0 : cb + 1;
+        ++t;
+    };
+    for (; t < nk - (PRE ? 12 : 2);) tile(V6{}, V6{}, NR{}, NR{});
+    if constexpr (PRE) {
+        // The wait of phase 0 of tile t is for B-hi of tile t (issued in phase 1 of t - 2): younger than it are the 6 LDS-DMA of tile t + 1 and the
+        // residual loads of phases (1, t - 2), (0, t - 1), (1, t - 1); the wait of phase 1 is for A / B-lo of t + 1 (phase 0 of t - 1): younger are
+        // B-hi of t + 1, A / B-lo of t + 2 and the residual loads of phases (0, t - 1), (1, t - 1), (0, t).  Window = tiles w0 .. w0 + 7, one load
+        // per phase: the counts below are 6 + the number of those phases inside the window.
+        using V7 = std::integral_constant<int, 7>; using V8 = std::integral_constant<int, 8>; using V9 = std::integral_constant<int, 9>;
+#define RI_(k) std::integral_constant<int, (k)>{}
+        tile(V6{}, V7{}, RI_(0), RI_(1));
+        tile(V8{}, V9{}, RI_(2), RI_(3));
+        tile(V9{}, V9{}, RI_(4), RI_(5));
+        tile(V9{}, V9{}, RI_(6), RI_(7));
+        tile(V9{}, V9{}, RI_(8), RI_(9));
+        tile(V9{}, V9{}, RI_(10), RI_(11));
+        tile(V9{}, V9{}, RI_(12), RI_(13));
+        tile(V9{}, V9{}, RI_(14), RI_(15));
+#undef RI_
+        tile(V9{}, V8{}, NR{}, NR{});
+        tile(V7{}, V6{}, NR{}, NR{});
     }
     {   // last two K tiles: nothing left to issue
-        phase(I0{}, N_{}, V6{}, nk - 2, cb, 0);
-        phase(I1{}, N_{}, std::integral_constant<int, 2>{}, nk - 2, cb, 0);
+        phase(I0{}, N_{}, V6{}, nk - 2, cb, 0, NR{});
+        phase(I1{}, N_{}, std::integral_constant<int, 2>{}, nk - 2, cb, 0, NR{});
         cb = cb == 2 ? 0 : cb + 1;
-        phase(I0{}, N_{}, std::integral_constant<int, 0>{}, nk - 1, cb, 0);
-        phase(I1{}, N_{}, std::integral_constant<int, -1>{}, nk - 1, cb, 0);
+        phase(I0{}, N_{}, std::integral_constant<int, 0>{}, nk - 1, cb, 0, NR{});
+        phase(I1{}, N_{}, std::integral_constant<int, -1>{}, nk - 1, cb, 0, NR{});
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();               // group 0 waits for group 1's last phase
 
@@ -740,18 +797,30 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
 #pragma unroll
         for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + (MI16 ? 16 * (q & 1) + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5)));
     static_assert(32 * (WN * 4 + 16) * NW <= NBUF * STAGE, "epilogue staging fits in the buffers");
-    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW, MI16>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v);
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW, MI16, PRE>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v, res);
 }
 
-template <int EPI, bool MI16>
+// the residual window needs the in-place form of the f32 epilogue and 12 K tiles (8 window + 2 behind it + the 2 that issue nothing).  Taken by default
+// up to K = 2048 (tools/res_epilogue_probe.py, 8 UVLTrack-L sequences, us: proj K = 1024 bf16 store 19.4 / f32 store 22.2 / rows loaded in the
+// epilogue 25.9 / in the loop 24.6, with rotating operands 28.6 -> 26.4; fc2 K = 4096 53.2 / 57.7 / 59.8 / 61.7: there the epilogue's read is 2 us of
+// a 60-us kernel and 28 MB of extra requests inside eight K tiles of a loop that already streams 2.5 TB/s cost more than that); res_pre = 2 forces it
+static bool pipe128_pre_ok(const GemmParams& p) {
+    const int want = tune_get(p.tune, &uvl_tuning::res_pre, 1);
+    return p.epi == EPI_F32 && p.accumulate && p.splitk <= 1 && p.K >= 12 * 64 && want != 0 && (p.K <= 2048 || want == 2);
+}
+
+template <int EPI, bool MI16, bool PRE = false>
 __global__ __launch_bounds__(512) void gemm_pipe128_kernel(const GemmParams p) {
     kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_pipe128_body<EPI, MI16>(p, blockIdx.x, smem);
+    gemm_pipe128_body<EPI, MI16, PRE>(p, blockIdx.x, smem);
 }
 
-template <int EPI, bool MI16 = true>
+template <int EPI, bool MI16 = true, bool PRE = false>
 static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
+    if constexpr (EPI == EPI_F32 && MI16 && !PRE) {
+        if (pipe128_pre_ok(p_in)) return launch_pipe128<EPI, MI16, true>(p_in, s);
+    }
     GemmParams p = p_in;
     if (p.N % 256 != 0 || p.K < 128 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return hipErrorInvalidValue;
     const int MT = (p.M + 127) / 128, NT = p.N / 256;
@@ -760,7 +829,7 @@ static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
     if (forced_gm > 0) p.group_m = forced_gm;
     const int nblk = 8 * ((MT * NT + 7) / 8);
     constexpr size_t lds = 3 * (size_t)(128 + 256) * 128 + 1024;      // three K-tile buffers + the tile's bias row
-    auto kern = gemm_pipe128_kernel<EPI, MI16>;
+    auto kern = gemm_pipe128_kernel<EPI, MI16, PRE>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -768,7 +837,7 @@ static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
         attr_done = true;
     }
     static char name[48];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe128_kernel<%d,%d>", EPI, (int)MI16);     // bools as 0 / 1, the way tools/make_profiles.py writes rocprofv3's names
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe128_kernel<%d,%d,%d>", EPI, (int)MI16, (int)PRE);     // bools as 0 / 1, the way tools/make_profiles.py writes rocprofv3's names
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, s, p);
     return hipGetLastError();
@@ -837,13 +906,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
 // The same for the eight-wave tiles of many-sequence frames (residual GEMMs: f32 read-modify-write epilogue): problem A on 256 x 256
 // (BMA = 256, cfg 30) or 128 x 256 tiles (cfg 31), the rider -- a few hundred text rows -- on 128 x 256 tiles behind them.  A's grid is a
 // single round of at most 256 workgroups on the shapes that take these kernels, and the rider's 9-30 tiles fit beside it.
-template <int BMA, int EPI>
+template <int BMA, int EPI, bool PRE = false>          // PRE: the visual problem's residual rows are requested inside its K loop (gemm_pipe128_body; BMA = 128 only)
 __global__ __launch_bounds__(512) void gemm_pipe_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
     kernarg_warm<2 * sizeof(GemmParams) + 8>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= blocks_b) {              // the rider's workgroups first (see gemm_dr_pair_kernel)
         if constexpr (BMA == 256) gemm_pipe_body<256, EPI, 1, true>(pa, (int)blockIdx.x - blocks_b, smem);
-        else gemm_pipe128_body<EPI, true>(pa, (int)blockIdx.x - blocks_b, smem);
+        else gemm_pipe128_body<EPI, true, PRE>(pa, (int)blockIdx.x - blocks_b, smem);
     } else {
         gemm_pipe128_body<EPI, true>(pb, blockIdx.x, smem);
     }
@@ -851,8 +920,11 @@ __global__ __launch_bounds__(512) void gemm_pipe_pair_kernel(const GemmParams pa
 
 static bool pipe_ok(const GemmParams& p) { return p.M > 0 && p.N % 256 == 0 && p.K >= 128 && p.K % 64 == 0 && p.splitk <= 1 && p.conv_F == 0 && p.groups <= 1; }
 
-template <int BMA, int EPI>
+template <int BMA, int EPI, bool PRE = false>
 static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
+    if constexpr (BMA == 128 && EPI == EPI_F32 && !PRE) {
+        if (pipe128_pre_ok(a_in)) return launch_pipe_pair<BMA, EPI, true>(a_in, b_in, s);
+    }
     GemmParams a = a_in, b = b_in;
     if (!pipe_ok(a) || !pipe_ok(b)) return hipErrorInvalidValue;
     auto grid = [](GemmParams& p, int BM) {
@@ -865,7 +937,7 @@ static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_i
     const int ba = grid(a, BMA), bb = grid(b, 128);
     constexpr size_t lds = 3 * (size_t)(128 + 256) * 128 + 1024;      // the larger of the two bodies' needs (cfg 31's three buffers)
     static_assert(lds >= 2 * (size_t)(256 + 256) * 128 + 1024, "cfg 30's two buffers fit");
-    auto kern = gemm_pipe_pair_kernel<BMA, EPI>;
+    auto kern = gemm_pipe_pair_kernel<BMA, EPI, PRE>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -873,7 +945,7 @@ static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_i
         attr_done = true;
     }
     static char name[48];
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_pair_kernel<%d,%d>", BMA, EPI);
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_pipe_pair_kernel<%d,%d,%d>", BMA, EPI, (int)PRE);
     g_last_kernel = name;
     hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(512), lds, s, a, b, bb);
     return hipGetLastError();

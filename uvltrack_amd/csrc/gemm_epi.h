@@ -32,9 +32,11 @@ __device__ __forceinline__ void gemm_bias_preload(const GemmParams& p, int colw,
 // L16: the accumulators of a 32 x 32 block were produced by 16x16x32 MFMAs -- registers 4 (2 hi + hj) .. + 3 of the block hold its 16 x 16
 // sub-block (hi, hj): lane l has row 16 hi + (l & 15) and the four consecutive columns 16 hj + 4 (l >> 4) + r; bv[j][hj] is the bias of those
 // columns.  Everything behind the staging store (row write-out, residual / table operands, V^T) is the same.
-template <int TM, int TN, int WM, int WN, int EPI, int NW, bool L16 = false>
+// PRE (f32 in-place residual form only): the residual rows were requested by the K loop (gemm_pipe128_body: sixteen 16-byte loads per lane spread
+// over eight K tiles) and arrive in `res` -- block i, row group it at res[i * (32 / RPI) + it], exactly the element the epilogue would load here.
+template <int TM, int TN, int WM, int WN, int EPI, int NW, bool L16 = false, bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
-                                                  int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4]) {
+                                                  int lane, int wave, int g, int sk, const f32x4 (&bv)[TN][4], const f32x4* res = nullptr) {
     constexpr int ES = (EPI == EPI_F32) ? 4 : 2;               // output element size
     constexpr int RS = WN * ES + 16;                            // padded LDS row stride
     constexpr int LPR = WN * ES / 16;                           // lanes per row on the way out
@@ -117,14 +119,17 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                     dst[it] = reinterpret_cast<float*>(p.C) + (size_t)sk * p.part_stride + ((size_t)b * p.obs + p.oro + rem) * p.ldc + (size_t)g * p.N + col;
                     if (p.addtab) tv[it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)(p.addtab_split ? (rem >= p.addtab_split ? 1 : 0) : rem) * p.N + col);
                 }
-                if (p.accumulate) {
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int it = 0; it < CH; ++it) ov[it] = res[i * NIT + h0 + it];
+                } else if (p.accumulate) {
 #pragma unroll
                     for (int it = 0; it < CH; ++it) ov[it] = *reinterpret_cast<const f32x4*>(dst[it]);
                 }
 #pragma unroll
                 for (int it = 0; it < CH; ++it) {
                     if (p.addtab) v[it] += tv[it];
-                    if (p.accumulate) v[it] += ov[it];
+                    if (PRE || p.accumulate) v[it] += ov[it];
                     if (inb[it]) {
                         if (p.c_store == 1) __builtin_nontemporal_store(v[it], reinterpret_cast<f32x4*>(dst[it]));
                         else if (p.c_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst[it]), "v"(v[it]) : "memory");

@@ -1115,7 +1115,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
     static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
         {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
-        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}};
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}, {"res_pre", &uvl_tuning::res_pre}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) { m->tune.*(k.field) = value < 0 ? -1 : value; return UVL_OK; }
     if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
