@@ -233,7 +233,7 @@ def masked_tile_entry(a, st):
         a.e(t)
 
 
-OPT = dict(prio=1, dma_v=0, spread=0, adv_v=0, rsum=0)
+OPT = dict(prio=1, dma_v=0, spread=0, adv_v=0, rsum=0, pure=0, rdprio=0)
 for _kv in os.environ.get("P64_OPT", "").split(","):
     if "=" in _kv:
         OPT[_kv.split("=")[0]] = int(_kv.split("=")[1])
@@ -325,7 +325,12 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
     gaps = softmax_gaps(1)
     nA = 8 if qk else 4                             # drain: P V only, block B's softmax in the four gaps of block A's MFMAs
     fill = {i: [] for i in range(len(mf))}
-    if qk and OPT["spread"]:
+    if OPT["pure"]:
+        # measured alternative: BOTH query blocks' softmax in the V phase; the M phase is 16 bare MFMAs (+ the scalar / DMA fillers).  pure = 3: the
+        # two blocks' MFMAs interleaved k step by k step (four independent accumulation chains instead of two)
+        if OPT["pure"] == 3 and qk:
+            mf = [mf[8 * x + 2 * k + h] for k in range(4) for h in range(2) for x in range(2)]
+    elif qk and OPT["spread"]:
         # block B's MFMAs reordered so that its softmax may use ten gaps: P V (t2 = 0) first, its scores (which overwrite the registers
         # the softmax reads) behind the last VALU group
         pvb = lambda k: mfma(O(1, k & 1, 0), VF(0, k), P(1, k >> 1), O(1, k & 1, 0))
@@ -379,7 +384,7 @@ def phase_M(a, st, jb, masked, qk=True, body=True):
                     a.e(t)
         for t in fill[i] + late[i]:
             a.e(t)
-    if OPT["prio"]:
+    if OPT["prio"] and not (OPT["rdprio"] and body):
         a.e("s_setprio 0")
     if body:
         pstamp(a, 1 if jb == 0 else 5)
@@ -404,6 +409,8 @@ def phase_V(a, st, jb, masked, body=True):
         a.e("ds_read_b128 %s, %s offset:%d" % (vr(VF(0, f), 4), v(VOFF(jb, f >> 1)), st * STAGE + (f & 1) * 4096))
     if body and jb == 1:
         a.e("ds_read_b32 %s, %s offset:%d" % (v(V_KACUR), v(V_KAREAD), sn * 1024))
+    if OPT["prio"] and OPT["rdprio"] and body:
+        a.e("s_setprio 0")                          # measured alternative: the next M phase's fragment reads are still issued at the M phase's priority
     extra = []
     if body and OPT["dma_v"]:
         rd = dma_round((st + 2) & 3)
@@ -411,8 +418,11 @@ def phase_V(a, st, jb, masked, body=True):
     if body and jb == 1 and OPT["adv_v"]:
         extra += advance_round()
     grps = softmax_gaps(0)
+    if OPT["pure"]:
+        gb = softmax_gaps(1)
+        grps = (gb + grps) if OPT["pure"] == 2 else (grps + gb)
     for i, grp in enumerate(grps):
-        if i == 8:
+        if grp and grp[0].startswith("v_mfma_f32_4x4x4") and len(grp) == 1:
             a.e("s_nop 1")                          # VALU write -> MFMA read: two wait states behind the last pack
         for t in grp:
             a.e(t)
