@@ -350,11 +350,13 @@ def test_attention_spike_forces_rescale(lib, B, H, N, tile):
 
 
 @pytest.mark.parametrize("B,F,cin,cout,slabs", [(1, 16, 768, 256, True), (1, 16, 768, 256, False), (16, 16, 256, 128, True), (2, 24, 1024, 256, True),
-                                                (16, 24, 128, 64, False), (1, 16, 64, 32, False), (16, 16, 64, 32, True)])
+                                                (16, 24, 128, 64, False), (1, 16, 64, 32, False), (16, 16, 64, 32, True),
+                                                (8, 24, 1024, 256, True), (7, 24, 1024, 256, False)])
 def test_conv_tower_layer(lib, B, F, cin, cout, slabs):
     """One layer of the four conv towers (implicit GEMM over NHWC tokens, zero-page padding, towers as groups, BatchNorm folded)
     against F.conv2d -> BatchNorm2d(eval) -> ReLU in fp32 (heads/utils.py:126-131) at batch 1 and 16: the one-sequence split-K
-    variant, the 64x64 and the 128x128 tile variants, and the 32-channel last layer."""
+    variant, the 64x64 and the 128x128 tile variants, the 32-channel last layer, and the first layer of 8 / 7 UVLTrack-L sequences (M = 4608 / 4032:
+    288 tiles of 128 x 128 on two workgroups per CU / the 64x64 grid)."""
     S = F * F
     first = cin in (768, 1024)                     # first layer: the four towers read the same channels
     x_ld = cin if first else 4 * cin

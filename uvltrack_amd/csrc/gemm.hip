@@ -1190,7 +1190,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.conv_F > 0) {                   // implicit GEMM over NHWC tokens, towers as groups (optionally split-K into f32 slabs)
         if (p.cin_g % 64 != 0) return hipErrorInvalidValue;
         if (p.N % 64 == 0) {
-            if (p.epi == EPI_BF16 && p.N % 128 == 0 && (long)(p.M / 128) * (p.N / 128) * (p.groups > 0 ? p.groups : 1) >= 256)
+            const long ngr = p.groups > 0 ? p.groups : 1;
+            // (round 5: 160 x 128 tiles on four waves for the first tower layer of 8 UVLTrack-L sequences -- 232 tiles instead of 288, one per CU -- measured
+            // 166 us against 145 by event pairs, frame +0.1 %: four waves alone on a CU lose what the tile count gains; not kept, profiles/r05_summary.md)
+            if (p.epi == EPI_BF16 && p.N % 128 == 0 && (long)(p.M / 128) * (p.N / 128) * ngr >= 256)
                 return launch_glds<128, 128, 2, 2, EPI_BF16, 2, true>(p, s);   // batched frames: at least one 128x128 tile per CU
             if (p.epi == EPI_BF16) return launch_glds<64, 64, 2, 2, EPI_BF16, 3, true>(p, s);
             if (p.epi == EPI_F32) return launch_glds<64, 64, 2, 2, EPI_F32, 3, true>(p, s);

@@ -260,6 +260,33 @@ struct Packer {
     }
 };
 
+// Fragment-native images of the RESIDUAL GEMMs' weights (ViT proj / fc2, BERT attention.output / output): read only when cfg 36 is forced onto the f32
+// read-modify-write epilogue (uvl_tune_set "gemm_dr" 1) or the text branch's residual GEMMs are sent there (uvl_debug_set "text_dr_res" 1) -- made on
+// the first such request (or at finalize when the request is already standing), not for every handle.  Synchronous on `s`.
+static int pack_residual_images(uvl_model* m, hipStream_t s) {
+    if (!m->finalized || (long)m->cfg.max_batch * m->nj < 2048) return UVL_OK;
+    const int D = m->D, Fn = m->ffn;
+    int err = 0;
+    auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
+        void* p = nullptr;
+        if (!src || err) return nullptr;
+        if (hipMalloc(&p, (size_t)N_ * K_ * sizeof(bf16_t) + 256) != hipSuccess) { err = fail(UVL_EHIP, "hipMalloc of a packed weight image failed"); return nullptr; }
+        m->owned.push_back(p);
+        if (launch_pack_w_dr(src, (bf16_t*)p, N_, K_, s) != hipSuccess) err = fail(UVL_EHIP, "weight packing launch failed");
+        return (bf16_t*)p;
+    };
+    for (auto& w : m->vit) {
+        if (!w.pproj) w.pproj = pack(w.wproj, D, D);
+        if (!w.pfc2) w.pfc2 = pack(w.wfc2, D, Fn);
+    }
+    for (auto& w : m->bert) {
+        if (!w.pao) w.pao = pack(w.wao, D, D);
+        if (!w.po) w.po = pack(w.wo, D, Fn);
+    }
+    if (!err && hipStreamSynchronize(s) != hipSuccess) err = fail(UVL_EHIP, "sync after weight packing failed");
+    return err ? err : UVL_OK;
+}
+
 extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
     if (!m) return fail(UVL_EINVAL, "null model");
     if (m->finalized) return UVL_OK;
@@ -300,8 +327,9 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
                 if (dst && launch_pack_w_dr(src, dst, N_, K_, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "weight packing launch failed");
                 return dst;
             };
-            w.pqkv = pack(w.wqkv, 3 * (int)D, (int)D); w.pproj = pack(w.wproj, (int)D, (int)D);
-            w.pfc1 = pack(w.wfc1, (int)Fn, (int)D); w.pfc2 = pack(w.wfc2, (int)D, (int)Fn);
+            // QKV / fc1 only: the f32 read-modify-write GEMMs (proj, fc2) stay on the tile-grid kernels by default, so their images (5 / 12 of the packed
+            // bytes: ~250 MB for UVLTrack-L) are made when a caller first asks for cfg 36 there (pack_residual_images: uvl_tune_set "gemm_dr" 1)
+            w.pqkv = pack(w.wqkv, 3 * (int)D, (int)D); w.pfc1 = pack(w.wfc1, (int)Fn, (int)D);
         }
         m->vit.push_back(w);
     }
@@ -332,8 +360,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
                 if (dst && launch_pack_w_dr(src, dst, N_, K_, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "weight packing launch failed");
                 return dst;
             };
-            w.pqkv = pack(w.wqkv, 3 * (int)D, (int)D); w.pao = pack(w.wao, (int)D, (int)D);
-            w.pi = pack(w.wi, (int)Fn, (int)D); w.po = pack(w.wo, (int)D, (int)Fn);
+            w.pqkv = pack(w.wqkv, 3 * (int)D, (int)D); w.pi = pack(w.wi, (int)Fn, (int)D);      // (pao / po: pack_residual_images, on demand)
         }
         m->bert.push_back(w);
     }
@@ -407,6 +434,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
         if (m->graph3[k]) { hipGraphDestroy(m->graph3[k]); m->graph3[k] = nullptr; }
     }
     m->finalized = true;
+    if (m->tune.gemm_dr == 1 || m->tune.gemm_cfg == 36 || m->tune.text_cfg == 36 || m->text_dr_res) return pack_residual_images(m, s);      // the request is already standing
     return UVL_OK;
 }
 
@@ -1117,7 +1145,12 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
         {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}, {"res_pre", &uvl_tuning::res_pre}};
     for (const auto& k : keys)
-        if (!strcmp(key, k.key)) { m->tune.*(k.field) = value < 0 ? -1 : value; return UVL_OK; }
+        if (!strcmp(key, k.key)) {
+            m->tune.*(k.field) = value < 0 ? -1 : value;
+            if ((!strcmp(key, "gemm_dr") && value == 1) || ((!strcmp(key, "gemm_cfg") || !strcmp(key, "text_cfg")) && value == 36))
+                return pack_residual_images(m, nullptr);          // cfg 36 on proj / fc2 too: their weight images, once
+            return UVL_OK;
+        }
     if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
     return fail(UVL_ENOTFOUND, "unknown tuning key '%s'", key);
 }
@@ -1130,7 +1163,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
-    if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return value ? pack_residual_images(m, nullptr) : UVL_OK; }
     if (!strcmp(key, "fork_text")) { m->fork_text = value ? 1 : 0; return UVL_OK; }   // 0: the text branch of multi-sequence frames runs on the caller's stream
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
 }
