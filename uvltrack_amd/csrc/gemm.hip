@@ -592,21 +592,27 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
-    int nt, mt;
+    // split-K (round 5: the text rider of the residual pair launch; f32 slabs, folded by the LayerNorm that follows): slice sk of tile (mt, nt) is
+    // workgroup sk * MT * NT + its tile index -- with one slice this is the plain map, bit for bit
+    const int nsk = p.splitk > 1 ? p.splitk : 1;
+    int nt, mt, sk;
     {
         const int xcd = bx & 7, idx = bx >> 3;
-        const int T = MT * NT, base = T >> 3, rem = T & 7;
+        const int Tt = MT * NT, T = Tt * nsk, base = T >> 3, rem = T & 7;
         const int cnt = base + (xcd < rem ? 1 : 0);
         if (idx >= cnt) return;
-        const int L = xcd * base + (xcd < rem ? xcd : rem) + idx;
+        const int L0 = xcd * base + (xcd < rem ? xcd : rem) + idx;
+        sk = L0 / Tt;
+        const int L = L0 - sk * Tt;
         const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
         const int gm = min(p.group_m, MT - gi * p.group_m);
         nt = within / gm;
         mt = gi * p.group_m + (within - nt * gm);
     }
     const int m0 = mt * BM, n0 = nt * BN;
-    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
-    const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
+    const int nk = p.K / 64 / nsk;                          // >= 2 (launcher); PRE: >= 12
+    const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda + (size_t)sk * nk * 64);
+    const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw + (size_t)sk * nk * 64);
 
     // group 0 = A (tile rows 0..127), 1 = B-lo (rows wn' * 64 + [0, 32)), 2 = B-hi; instruction n (0, 1) of a group fills 8 rows
     uint32_t loff[3][2];
@@ -682,10 +688,9 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
         }
     };
 
-    const int nk = p.K / 64;                                 // >= 2 (launcher); PRE: >= 12
     f32x4 bias_in;
     if (wave == 0) {
-        const float* bsrc = (p.bias ? p.bias + n0 : reinterpret_cast<const float*>(g_zero_page)) + lane * 4;
+        const float* bsrc = ((p.bias && sk == 0) ? p.bias + n0 : reinterpret_cast<const float*>(g_zero_page)) + lane * 4;      // the bias goes into slab 0
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_in) : "v"(bsrc) : "memory");
     }
     issue_tile(0, 0);
@@ -797,7 +802,7 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
 #pragma unroll
         for (int q = 0; q < 4; ++q) bias_v[j][q] = *reinterpret_cast<const f32x4*>(sbias + wn * WN + j * 32 + (MI16 ? 16 * (q & 1) + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5)));
     static_assert(32 * (WN * 4 + 16) * NW <= NBUF * STAGE, "epilogue staging fits in the buffers");
-    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW, MI16, PRE>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, 0, bias_v, res);
+    gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW, MI16, PRE>(p, acc, smem, m0, n0, wm, wn, lane, wave, 0, sk, bias_v, res);
 }
 
 // the residual window needs the in-place form of the f32 epilogue and 12 K tiles (8 window + 2 behind it + the 2 that issue nothing).  Taken by default
@@ -919,6 +924,11 @@ __global__ __launch_bounds__(512) void gemm_pipe_pair_kernel(const GemmParams pa
 }
 
 static bool pipe_ok(const GemmParams& p) { return p.M > 0 && p.N % 256 == 0 && p.K >= 128 && p.K % 64 == 0 && p.splitk <= 1 && p.conv_F == 0 && p.groups <= 1; }
+// the rider of a pair launch may be cut into K slices (f32 slabs): gemm_pipe128_body maps slice and tile from the workgroup index
+static bool pipe_ok_rider(const GemmParams& p) {
+    if (p.splitk <= 1) return pipe_ok(p);
+    return p.M > 0 && p.N % 256 == 0 && p.K % (64 * p.splitk) == 0 && p.K / p.splitk >= 128 && p.conv_F == 0 && p.groups <= 1 && p.epi == EPI_F32 && !p.accumulate;
+}
 
 template <int BMA, int EPI, bool PRE = false>
 static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
@@ -926,13 +936,13 @@ static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_i
         if (pipe128_pre_ok(a_in)) return launch_pipe_pair<BMA, EPI, true>(a_in, b_in, s);
     }
     GemmParams a = a_in, b = b_in;
-    if (!pipe_ok(a) || !pipe_ok(b)) return hipErrorInvalidValue;
+    if (!pipe_ok(a) || !pipe_ok_rider(b)) return hipErrorInvalidValue;
     auto grid = [](GemmParams& p, int BM) {
         const int MT = (p.M + BM - 1) / BM, NT = p.N / 256;
         p.group_m = MT >= 16 ? 8 : MT;
         const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
         if (forced_gm > 0) p.group_m = forced_gm;
-        return 8 * ((MT * NT + 7) / 8);
+        return 8 * ((MT * NT * (p.splitk > 1 ? p.splitk : 1) + 7) / 8);
     };
     const int ba = grid(a, BMA), bb = grid(b, 128);
     constexpr size_t lds = 3 * (size_t)(128 + 256) * 128 + 1024;      // the larger of the two bodies' needs (cfg 31's three buffers)
@@ -1153,10 +1163,10 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
                           tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0 && (a.M + 63) / 64 < 16 && (b.M + 63) / 64 < 16;
     if (!pairable) {
         // many-sequence frames: the visual problem on one of the large-tile kernels, the rider on the same kernel's 128 x 256 tiles
-        if (plain(a) && plain(b) && a.epi == b.epi && a.splitk == 1 && b.splitk == 1 && a.N % 256 == 0 && a.K >= 128 && tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0) {
+        if (plain(a) && plain(b) && a.epi == b.epi && a.splitk == 1 && a.N % 256 == 0 && a.K >= 128 && tune_get(a.tune, &uvl_tuning::gemm_gm, -1) < 0) {
             const int cfg = pick_plain_cfg(a);
-            if (cfg == 36 && gemm_dr_pairable(a, b)) return launch_gemm_dr_pair(a, b, s);
-            if (a.epi == EPI_F32 && pipe_ok(a) && pipe_ok(b)) {
+            if (cfg == 36 && b.splitk == 1 && gemm_dr_pairable(a, b)) return launch_gemm_dr_pair(a, b, s);
+            if (a.epi == EPI_F32 && pipe_ok(a) && pipe_ok_rider(b)) {
                 if (cfg == 30) return launch_pipe_pair<256, EPI_F32>(a, b, s);
                 if (cfg == 31) return launch_pipe_pair<128, EPI_F32>(a, b, s);
             }

@@ -22,12 +22,14 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
 
 // Two independent LayerNorm problems in one launch (batch-1 frames pair every text-branch kernel with the visual kernel
 // of the same kind, see uvl_api.hip): workgroups [0, split) work on pa, the rest on pb.
-template <int NV, bool FULL, bool SLABS, int CT>
+// SLABS_B: the RIDER alone folds split-K slabs (round 5: the text branch's output GEMM of a many-sequence frame runs as two K halves, the visual rows
+// stay in place -- the HBM-bound visual LayerNorm must not pay the slab operand slots); SLABS covers both problems otherwise.
+template <int NV, bool FULL, bool SLABS, int CT, bool SLABS_B = SLABS>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
     kernarg_warm<2 * sizeof(LnParams) + 8 + 64>();
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
     if ((int)blockIdx.x < split) ln_body<NV, FULL, SLABS, CT>(pa, (int)blockIdx.x);
-    else ln_body<NV, FULL, SLABS, 0>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
+    else ln_body<NV, FULL, SLABS_B, 0>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
 }
 
 // Rows (= waves) per workgroup.  With one memory round trip per row, one sequence of UVLTrack-B (553 rows) is 1.5-2.6 % faster in
@@ -71,6 +73,15 @@ template <int NV, bool FULL>
 static void launch_ln_pair_variant(const LnParams& a, const LnParams& b, int ga, int gb, int wpb, hipStream_t s) {
     const bool slabs = a.nsplit > 0 || b.nsplit > 0, ct = a.ct_x != nullptr;
     const bool self = ct && a.ct_self && !slabs;
+    if (NV >= 3 && FULL && a.nsplit == 0 && b.nsplit > 0 && !(ct && !a.ct_self)) {      // only the rider has slabs (names: "...,0,<ct>,b>")
+        static char nm[2][40];
+        const int c2 = (ct && a.ct_self) ? 1 : 0;
+        if (!nm[c2][0]) snprintf(nm[c2], 40, "ln_pair_kernel<%d,1,0,%d,b>", NV, c2 ? 2 : 0);
+        g_last_kernel = nm[c2];
+        if (c2) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, 2, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+        else hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, 0, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
+        return;
+    }
     g_last_kernel = ln_name(true, NV, FULL, slabs, self ? 2 : ct);
     if (self) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, 2>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
     else if (slabs && ct) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, true, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
@@ -81,7 +92,7 @@ static void launch_ln_pair_variant(const LnParams& a, const LnParams& b, int ga,
 
 hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s) {
     if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0 || a.nsplit > LN_MAX_SLABS || b.nsplit > LN_MAX_SLABS || b.ct_x ||
-        (a.ct_x && a.ct_self && (a.nsplit > 0 || b.nsplit > 0 || a.ct_x != a.x)))
+        (a.ct_x && a.ct_self && (a.nsplit > 0 || a.ct_x != a.x)))
         return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(a.M);
     const int ga = (a.M + wpb - 1) / wpb, gb = (b.M + wpb - 1) / wpb;

@@ -95,6 +95,7 @@ struct uvl_model {
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
     int prefetch_w = 1;                          // uvl_debug_set("prefetch_w", v): 0 = no next-weight requests in the GEMM launches, 1 = in frames below 2000 visual rows, 2 = always (A/B)
+    int rider_sk = 2;                            // uvl_debug_set("rider_sk", 1): the text rider's output GEMM in one K slice, in place (the round-4 form; A/B)
     int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
     int fuse_ln = 0;                             // uvl_debug_set("fuse_ln", 1): one-sequence frames launch LayerNorm + its consumer GEMM as ONE kernel behind a
                                                  // grid barrier (96 -> 72 launches; measured 3-4 % SLOWER than the two launches, so off: profiles/r03_summary.md)
@@ -813,7 +814,11 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         GemmParams p;
         p.A = A; p.lda = lda; p.W = Wt; p.Wp = Wpk; p.ldw = K; p.bias = bias; p.M = Mr; p.N = D; p.K = K; p.epi = 1; p.ldc = D;
         p.pf = pf; p.pf_bytes = (uint32_t)pf_bytes;
-        const int sk = allow_split ? choose_splitk(Mr, D, K, &m->tune) : 1;
+        // rider_sk: the text branch's OUTPUT GEMM riding in a many-sequence fc2 launch.  Its 3 x 4 tiles walk the same 64 K tiles as the visual tiles, on
+        // BERT weights nobody has read this frame: each one ran ~10 % longer than a visual tile and was the tail of the launch (+6.6 us on 12 launches
+        // of 8 UVLTrack-L sequences).  Two K halves (f32 slabs, folded by the BERT LayerNorm that follows, as in one-sequence frames) end under the visual tiles.
+        const int rsk = (is_text && paired_many && !allow_split && K >= 4096 && (K / 64) % 2 == 0 && m->rider_sk > 1) ? 2 : 1;
+        const int sk = rsk > 1 ? rsk : (allow_split ? choose_splitk(Mr, D, K, &m->tune) : 1);
         if (sk > 1) {             // slabs [sk][Mr, D], folded in by the next LayerNorm / contrast kernel
             p.C = slab; p.splitk = sk; p.part_stride = (size_t)Mr * D; p.c_store = tune_get(&m->tune, &uvl_tuning::slab_store, 2);   // write-through slabs: +1 % at one sequence (both A/B orders)
             pd.part = slab; pd.nsplit = sk; pd.rows = rpb; pd.stride = p.part_stride;
@@ -1160,6 +1165,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "stop_layer")) { m->debug_stop_layer = value; return UVL_OK; }
     if (!strcmp(key, "prefetch_w")) { m->prefetch_w = value < 0 ? 0 : (value > 2 ? 2 : value); return UVL_OK; }
     if (!strcmp(key, "fold_modal")) { m->fold_modal = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "rider_sk")) { m->rider_sk = value > 1 ? 2 : 1; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
