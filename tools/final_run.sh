@@ -8,3 +8,8 @@ python bench.py --model L --batch 32 --steps 60 --warmup 10 --no-cpu-baseline --
 STEPS=100 WARMUP=20 bash tools/profile_bench.sh gpurun_out/r05_prof > /dev/null 2>&1
 STEPS=30 WARMUP=8 bash tools/profile_bench.sh gpurun_out/r05_L8_prof --model L --batch 8 > /dev/null 2>&1
 ls gpurun_out/r05_prof gpurun_out/r05_L8_prof | head -30
+python tools/lib_compare.py cfg4 > gpurun_out/r05_lib_compare_cfg4.txt 2>&1
+python tools/attn_bench.py > gpurun_out/r05_attn_bench.txt 2>&1
+python tools/res_epilogue_probe.py > gpurun_out/r05_res_epilogue.txt 2>&1
+python bench.py --gpus 1 --dist --model L --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-batched > gpurun_out/bench_L8_dist.json 2>/dev/null
+python bench.py --gpus 1 --dist --steps 100 --warmup 20 --no-cpu-baseline --no-batched > gpurun_out/bench_b1_dist.json 2>/dev/null

@@ -13,7 +13,7 @@
 //     16-byte chunk index XORed by (row>>1)&7 -- applied to the per-lane SOURCE address (a DMA image is lane-linear)
 //     and again on the fragment reads
 //   * scores are computed TRANSPOSED, S^T = K Q^T, so lane (q = lane&31) holds 16 of the 32 keys of its query
-//     column per 32-key block: row max / row sum are lane-local plus ONE cross-half exchange (__shfl_xor 32)
+//     column per 32-key block: row max / row sum are lane-local plus ONE cross-half exchange (v_permlane32_swap: common.h::half_max / half_sum)
 //   * P^T feeds the second MFMA as the B operand with no data movement at all: the K rows are fed to the first MFMA in a
 //     permuted order (bits 2,3 of the row swapped) so that the 8 score registers a lane-half owns per 16-key step ARE
 //     8 contiguous keys; the matching V^T A-operand is then one conflict-free ds_read_b128
@@ -224,7 +224,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
                     for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
                 tmax *= CS;
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = half_max(tmax);
             if (__any(tmax > m_run + ATTN_DEFER)) {       // rare after the first tiles: raise the max, rescale l and O
                 const float m_new = fmaxf(m_run, tmax);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -282,7 +282,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
 
     bf16_t* dst = p.o + ((size_t)b * N + (qrow < N ? qrow : 0)) * (p.H * 64) + h * 64;
     if (KS == 1) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float l_tot = half_sum(l_run);
         const float inv = 1.0f / l_tot;
         if (qrow < N) {
 #pragma unroll
@@ -317,7 +317,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
             sc[w] = __builtin_amdgcn_exp2f(grp[(w * 34 + 32) * 64 + lane] - mstar);   // exp2(-inf) = 0 for a wave that saw no tile
             lsum += grp[(w * 34 + 33) * 64 + lane] * sc[w];
         }
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = half_sum(lsum);
         const float inv = 1.0f / lsum;
         // 8 groups of 4 accumulator registers (4 consecutive d of one row group); wave ks merges groups ks, ks+KS, ...
         for (int g4 = ks; g4 < 8; g4 += KS) {
@@ -347,15 +347,16 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int bx, con
 // tiles enter one L2 instead of up to eight -- +1.8 % / +0.7 % on the frame at 8 / 32 sequences.  For one sequence (a single
 // round of workgroups, all starting together) the plain order is faster (-1.3 % with the map: the 17 workgroups of a head then
 // hammer the same L2 lines at the same moment), so the launcher maps only grids of several workgroups per CU.
-__device__ __forceinline__ bool attn_decode_block(int blk, int total, int nqb, int H, bool mapped, int& qb, int& h, int& b) {
+// (fq / fh: fastdiv_of(nqb) / fastdiv_of(H) from the launcher -- AttnParams::fd_nqb / fd_h: no integer division in front of the first load)
+__device__ __forceinline__ bool attn_decode_block(int blk, int total, int nqb, int H, bool mapped, const FastDiv& fq, const FastDiv& fh, int& qb, int& h, int& b) {
     const int xcd = blk & 7, idx = blk >> 3;
     const int cnt = (total + 7) >> 3;
     const int L = mapped ? xcd * cnt + idx : blk;
     if ((mapped && idx >= cnt) || L >= total) return false;
-    qb = L % nqb;
-    const int r = L / nqb;
-    h = r % H;
-    b = r / H;
+    const int r = (int)fd_div((uint32_t)L, fq);
+    qb = L - r * nqb;
+    b = (int)fd_div((uint32_t)r, fh);
+    h = r - b * H;
     return true;
 }
 
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_kernel(c
     extern __shared__ __attribute__((aligned(16))) char smem[];      // NS * STAGE (>= the merge exchange area)
     const int nqb = (p.N + 32 * QW - 1) / (32 * QW);
     int qb, h, b;
-    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, p.fd_nqb, p.fd_h, qb, h, b)) return;
     attn_body<QW, KS, NS>(p, qb, h, b, smem);
 }
 
@@ -378,13 +379,13 @@ __global__ __launch_bounds__(64 * QW * KS, (KS == 1 ? 3 : 1)) void attn_pair_ker
     if ((int)blockIdx.x < blocks_a) {                 // blocks_a is a multiple of 8: the XCD relation of the map is preserved
         const int nqb = (pa.N + 32 * QW - 1) / (32 * QW);
         int qb, h, b;
-        if (!attn_decode_block((int)blockIdx.x, nqb * pa.H * pa.B, nqb, pa.H, pa.xcd_map != 0, qb, h, b)) return;
+        if (!attn_decode_block((int)blockIdx.x, nqb * pa.H * pa.B, nqb, pa.H, pa.xcd_map != 0, pa.fd_nqb, pa.fd_h, qb, h, b)) return;
         attn_body<QW, KS, NS>(pa, qb, h, b, smem);
     } else {
-        int id = (int)blockIdx.x - blocks_a;
-        const int nqb = (pb.N + 32 * QW - 1) / (32 * QW), qb = id % nqb;
-        id /= nqb;
-        attn_body<QW, KS, NS>(pb, qb, id % pb.H, id / pb.H, smem);
+        const int id = (int)blockIdx.x - blocks_a;
+        const int nqb = (pb.N + 32 * QW - 1) / (32 * QW);
+        const int r = (int)fd_div((uint32_t)id, pb.fd_nqb), bb = (int)fd_div((uint32_t)r, pb.fd_h);
+        attn_body<QW, KS, NS>(pb, id - r * nqb, r - bb * pb.H, bb, smem);
     }
 }
 
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nqb = (p.N + 127) / 128;
     int qb, h, b;
-    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, p.fd_nqb, p.fd_h, qb, h, b)) return;
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p)
             float tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = half_max(tmax);
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0
             m_run = m_new;
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256, 3) void attn_stream_kernel(const AttnParams p)
 #undef ATTN_GLDS
 
     if (qrow < N) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float l_tot = half_sum(l_run);
         const float inv = 1.0f / l_tot;
         bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
 #pragma unroll
@@ -665,6 +666,7 @@ static hipError_t launch_attn_stream(const AttnParams& p_in, hipStream_t s) {
     const int total = ((p_in.N + 127) / 128) * p_in.H * p_in.B;
     AttnParams p = p_in;
     p.xcd_map = total >= 400 ? 1 : 0;
+    p.fd_nqb = fastdiv_of((uint32_t)((p.N + 127) / 128)); p.fd_h = fastdiv_of((uint32_t)p.H);
     hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
     return hipGetLastError();
 }
@@ -1061,7 +1063,7 @@ __device__ __forceinline__ void attn_w64_item(const AttnParams& p, const int qb,
     if (PASS1 && active) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
+            const float l_tot = half_sum(l_run[x]);
             bad = bad || !(l_tot < 1.2676506e30f && l_tot > 7.888609e-31f);      // 2^100, 2^-100; NaN fails both
         }
         bad = __any(bad);
@@ -1129,7 +1131,7 @@ __device__ __forceinline__ void attn_w64_item(const AttnParams& p, const int qb,
                 float tmax = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[x][0][r], s[x][1][r]));
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                tmax = half_max(tmax);
                 const float m_new = fmaxf(m_run[x], tmax);
                 const float alpha = __builtin_amdgcn_exp2f(m_run[x] - m_new);      // first tile: exp2(-inf) = 0
                 m_run[x] = m_new;
@@ -1172,7 +1174,7 @@ __device__ __forceinline__ void attn_w64_item(const AttnParams& p, const int qb,
     for (int x = 0; x < 2; ++x) {
         const int qrow = q0 + 32 * x + (lane & 31);
         if (qrow < N) {
-            const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
+            const float l_tot = half_sum(l_run[x]);
             const float inv = 1.0f / l_tot;
             bf16_t* dst = p.o + ((size_t)b * N + qrow) * (p.H * 64) + h * 64;
             // 16-byte stores (guide T21): the two half-waves hold columns 8g..8g+3 / 8g+4..8g+7 of the same row; one
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(256, 2) void attn_w64_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nqb = (((p.N + 63) >> 6) + 3) >> 2;         // 256-query workgroups per head
     int qb, h, b;
-    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, qb, h, b)) return;
+    if (!attn_decode_block((int)blockIdx.x, nqb * p.H * p.B, nqb, p.H, p.xcd_map != 0, p.fd_nqb, p.fd_h, qb, h, b)) return;
     attn_w64_item<NS, true>(p, qb, h, b, smem, (int)threadIdx.x);
 }
 
@@ -1243,6 +1245,7 @@ static hipError_t launch_attn_w64(const AttnParams& p_in, hipStream_t s) {
     const int total = ((((p_in.N + 63) / 64) + 3) / 4) * p_in.H * p_in.B;
     AttnParams p = p_in;
     p.xcd_map = total >= 400 ? 1 : 0;
+    p.fd_nqb = fastdiv_of((uint32_t)((((p.N + 63) / 64) + 3) / 4)); p.fd_h = fastdiv_of((uint32_t)p.H);
     hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(256), lds, s, p);
     return hipGetLastError();
 }
@@ -1297,7 +1300,7 @@ __device__ __forceinline__ void attn_p64_walk(const AttnParams& p, const int tot
     int it = 0;
     for (int v = v0; v < 8 * cnt; v += G) {
         int qb, h, b;
-        if (!attn_decode_block(v, total, nqb, p.H, true, qb, h, b)) continue;
+        if (!attn_decode_block(v, total, nqb, p.H, true, p.fd_nqb, p.fd_h, qb, h, b)) continue;
         if ((bad >> it) & 1) attn_w64_item<4, false>(p, qb, h, b, smem, wave * 64 + attn_opaque_lane());
         ++it;
     }
@@ -1327,7 +1330,7 @@ __global__ __launch_bounds__(256, 2) void attn_p64_rider_kernel(const AttnParams
     int first = (int)gridDim.x - 1 - (int)blockIdx.x, step = (int)gridDim.x;      // round-robin from the END of the grid: the walk gives the low indices one item more
     if (tail_only) {
         int qb, h, b;
-        if (!attn_decode_block((int)blockIdx.x, total, nqb, p.H, true, qb, h, b) || qb != nqb - 1) return;
+        if (!attn_decode_block((int)blockIdx.x, total, nqb, p.H, true, p.fd_nqb, p.fd_h, qb, h, b) || qb != nqb - 1) return;
         first = h + p.H * b;
         step = p.H * p.B;
     }
@@ -1364,6 +1367,7 @@ static hipError_t launch_attn_p64(const AttnParams& p_in, hipStream_t s, const A
     auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); };
     AttnParams p = p_in;
     p.xcd_map = 1;
+    p.fd_nqb = fastdiv_of((uint32_t)(nqb)); p.fd_h = fastdiv_of((uint32_t)p.H);
     if (rider) {
         // one item per workgroup and a short last query block: the workgroups of those items have the time for the rider
         const int tail_only = (grid == 8 * cnt && nqb >= 2 && p.N - (nqb - 1) * 256 <= 160) ? 1 : 0;
@@ -1392,7 +1396,10 @@ static hipError_t launch_attn_pair_cfg(const AttnParams& a, const AttnParams& b,
     g_last_kernel = name;
     const int ta = ((a.N + 32 * QW - 1) / (32 * QW)) * a.H * a.B, ba = 8 * ((ta + 7) / 8);
     const int bb = ((b.N + 32 * QW - 1) / (32 * QW)) * b.H * b.B;
-    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(64 * QW * KS), lds, s, a, b, ba);
+    AttnParams pa = a, pb = b;
+    pa.fd_nqb = fastdiv_of((uint32_t)((a.N + 32 * QW - 1) / (32 * QW))); pa.fd_h = fastdiv_of((uint32_t)a.H);
+    pb.fd_nqb = fastdiv_of((uint32_t)((b.N + 32 * QW - 1) / (32 * QW))); pb.fd_h = fastdiv_of((uint32_t)b.H);
+    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(64 * QW * KS), lds, s, pa, pb, ba);
     return hipGetLastError();
 }
 
@@ -1414,6 +1421,7 @@ static hipError_t launch_attn_cfg(const AttnParams& p_in, hipStream_t s) {
     const int total = ((p_in.N + 32 * QW - 1) / (32 * QW)) * p_in.H * p_in.B;
     AttnParams p = p_in;
     p.xcd_map = total >= 400 ? 1 : 0;
+    p.fd_nqb = fastdiv_of((uint32_t)((p.N + 32 * QW - 1) / (32 * QW))); p.fd_h = fastdiv_of((uint32_t)p.H);
     hipLaunchKernelGGL(kern, dim3(8 * ((total + 7) / 8)), dim3(64 * QW * KS), lds, s, p);
     return hipGetLastError();
 }

@@ -34,14 +34,58 @@ __device__ __forceinline__ uint32_t sload_u32(const void* uniform_ptr) {
 }
 __device__ __forceinline__ float sload_f32(const float* uniform_ptr) { return __uint_as_float(sload_u32(uniform_ptr)); }
 
+// Wave-wide sum / maximum, every lane gets the result.  The xor butterfly 32, 16, 8, 4, 2, 1 -- the pairs (and so the bits) of the `__shfl_xor` loop this replaces
+// (round 5) -- without the LDS crossbar: v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and even rows of 16, and inside a row a rotation by
+// 8, 4, 2, 1 IS the xor exchange once the row has that period (v_add_f32_dpp row_ror).  Eight VALU instead of six ds_bpermute round trips (~60-100 cycles each,
+// each behind its own lgkmcnt wait): a LayerNorm row does two of these, the contrastive job riding on it five more.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+#if __HIP_DEVICE_COMPILE__
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));      // row_ror:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xf, 0xf, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xf, 0xf, false));
+#endif
+    return v;
+}
+// v(lane) (+ | max) v(lane ^ 32): the cross-half exchange of the attention kernels (one per key tile for the running maximum), one v_permlane32_swap instead of a
+// ds_bpermute round trip; the same two values are combined, so the same bits
+__device__ __forceinline__ float half_sum(float v) {
+#if __HIP_DEVICE_COMPILE__
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+    return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#if __HIP_DEVICE_COMPILE__
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#endif
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+#if __HIP_DEVICE_COMPILE__
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xf, 0xf, false)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xf, 0xf, false)));
+#endif
     return v;
 }
 
@@ -132,13 +176,31 @@ __device__ __forceinline__ f32x4 gelu_erf_poly4(f32x4 x) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Division by a run-time value that the HOST knows at launch (tiles per row of the grid, rows per sample, heads, ...).  hipcc compiles `x / d` on wave-uniform
+// operands as float reciprocal + v_readfirstlane + a chain of scalar fix-ups (~25 instructions, several VALU -> SALU hand-overs): the tile decode of the
+// one-sequence GEMM kernels ran up to eight of them before its first LDS-DMA could be addressed -- a few hundred cycles at the head of an 8-us kernel, ~96 times
+// per frame.  FastDiv carries m = floor(2^32 / d) from the host: q = mulhi(x, m) is floor(x / d) or one less (for every x < 2^32, d >= 1), one compare fixes it.
+struct FastDiv {
+    uint32_t d = 1u << 30, m = 4;           // (the default matches GemmParams::rpb's "no row map": 2^30 rows per sample)
+};
+static inline FastDiv fastdiv_of(uint32_t d) {
+    FastDiv f;
+    f.d = d ? d : 1u;
+    f.m = f.d == 1u ? 0xffffffffu : (uint32_t)((1ull << 32) / f.d);
+    return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t x, const FastDiv& f) {
+    const uint32_t q = __umulhi(x, f.m);
+    return (x - q * f.d >= f.d) ? q + 1 : q;
+}
+
 // Output row m -> (sample b = m / rpb, row inside the sample m % rpb) for the rows of ONE block of at most 32 consecutive rows, without a division per
 // row and lane: the block's first row is divided once (wave-uniform), a row of the block is that plus at most one wrap.  (An integer division by a
 // run-time value is ~40 VALU; the QKV-scatter and residual epilogues did one per stored row group: 4-8 us of a 45-us GEMM, tools/probes/qkv_epi_cost.py.)
 struct RowMap { int b0, rem0, rpb; };
-__device__ __forceinline__ RowMap rowmap_of(int first_row, int rpb) {
+__device__ __forceinline__ RowMap rowmap_of(int first_row, int rpb, const FastDiv& fd) {      // fd = fastdiv_of(rpb), from the launcher
     const int rf = __builtin_amdgcn_readfirstlane(first_row);
-    const int b0 = rf / rpb;
+    const int b0 = (int)fd_div((uint32_t)rf, fd);
     return RowMap{b0, rf - b0 * rpb, rpb};
 }
 // r = row - first_row, 0 <= r <= 32; exact for rpb > 32, and for any rpb through the division

@@ -102,21 +102,24 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     // Workgroup b runs on XCD b % 8 (dispatch order; affects speed only), and every XCD has its own L2.
     const int xcd = bx & 7, idx = bx >> 3;
     int nt, mt;
+    // (every division below is by a value the launcher knows: gemm_derive leaves the reciprocals in the argument block -- common.h::FastDiv)
     if (p.group_m < 0) {
         // K-SLICE map of a split-K GEMM with few M tiles (one or two sequences): the grid is 1-D over (tile, slice) and XCD x owns ONE
         // K slice (x / nparts) and one contiguous share of the N panels (x % nparts, nparts = 8 / splitk): its L2 then holds
         // A[:, slice] and its share of W[:, slice] -- with the tile map below every XCD pulls ALL of A through its L2 for every slice
         // (fc2 of UVLTrack-B at one sequence: 8 x 3.4 MB of A per launch instead of 8 x 0.85 MB)
-        const int nparts = 8 / p.splitk, NTp = NT / nparts;
-        sk = xcd / nparts;
+        const int NTp = p.ks_ntp;                            // nparts = 1 << ks_log2 = 8 / splitk
+        sk = xcd >> p.ks_log2;
         if (idx >= MT * NTp) return;
-        nt = (xcd % nparts) * NTp + idx / MT;
-        mt = idx % MT;
+        const int q = (int)fd_div((uint32_t)idx, p.fd_mt);
+        nt = (xcd & ((1 << p.ks_log2) - 1)) * NTp + q;
+        mt = idx - q * MT;
     } else if (p.group_m == 0) {
         // panel map (UVL_GEMM_GM=0 only; the default of the first builds): an XCD owns whole N panels, so every weight byte enters
         // exactly one L2 -- but XCDs get unequal shares unless N / BN is a multiple of 8, see launch_glds
-        nt = (idx / MT) * 8 + xcd;
-        mt = idx % MT;
+        const int q = (int)fd_div((uint32_t)idx, p.fd_mt);
+        nt = q * 8 + xcd;
+        mt = idx - q * MT;
         if (nt >= NT) return;
     } else {
         // Tiles are ordered in groups of group_m M-tiles x all N-tiles (M fastest) and the order is cut into 8 contiguous runs,
@@ -126,15 +129,15 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         const int cnt = base + (xcd < rem ? 1 : 0);
         if (idx >= cnt) return;
         const int L = xcd * base + (xcd < rem ? xcd : rem) + idx;
-        const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
+        const int gsz = p.group_m * NT, gi = (int)fd_div((uint32_t)L, p.fd_gsz), within = L - gi * gsz;
         const int gm = min(p.group_m, MT - gi * p.group_m);
-        nt = within / gm;
+        nt = (int)fd_div((uint32_t)within, gm == p.group_m ? p.fd_gm : p.fd_gml);
         mt = gi * p.group_m + (within - nt * gm);
     }
     const int m0 = mt * BM, n0 = nt * BN;
 
     // split-K: slice sk owns the K range [sk*K/splitk, (sk+1)*K/splitk) and writes its own f32 partial slab
-    const int kspan = p.K / p.splitk;
+    const int kspan = p.kspan;
     const int kbase = sk * kspan;
     // per-lane DMA sources: instruction i of this wave fills stage rows [8*(wave + NW*i), +8)
     const bf16_t* src[CONV ? LPT : 1];                       // conv: full per-lane pointers (the tap moves them per K tile)
@@ -332,10 +335,11 @@ __device__ unsigned int g_gemm_trace[2 * 64 * 4 * 4 + 16];
 // block cannot hide together with up to 12 fragment reads; between MFMAs it rides on the matrix pipe's own latency (+2..5 % at
 // 256 x 256, +5..9 % at 128 x 256; VAR 0 is still instantiable but has no cfg number any more: 32 / 33 are now the 32x32x16 forms).
 // position L of the grouped tile order (groups of group_m M-tiles x all N-tiles, M fastest inside a group) -> (mt, nt)
-__device__ __forceinline__ void pipe_tile_of(const int L, const int MT, const int NT, const int group_m, int& mt, int& nt) {
-    const int gsz = group_m * NT, gi = L / gsz, within = L - gi * gsz;
+__device__ __forceinline__ void pipe_tile_of(const GemmParams& p, const int L, const int MT, const int NT, int& mt, int& nt) {
+    const int group_m = p.group_m;
+    const int gsz = group_m * NT, gi = (int)fd_div((uint32_t)L, p.fd_gsz), within = L - gi * gsz;
     const int gm = min(group_m, MT - gi * group_m);
-    nt = within / gm;
+    nt = (int)fd_div((uint32_t)within, gm == group_m ? p.fd_gm : p.fd_gml);
     mt = gi * group_m + (within - nt * gm);
 }
 
@@ -557,7 +561,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, const int bx
         const int T = MT * NT, base = T >> 3, rem = T & 7;
         const int cnt = base + (xcd < rem ? 1 : 0);
         if (idx >= cnt) return;
-        pipe_tile_of(xcd * base + (xcd < rem ? xcd : rem) + idx, MT, NT, p.group_m, mt, nt);
+        pipe_tile_of(p, xcd * base + (xcd < rem ? xcd : rem) + idx, MT, NT, mt, nt);
     }
     gemm_pipe_tile<BM, EPI, VAR, MI16>(p, mt, nt, p.K / 64, smem);
 }
@@ -602,15 +606,11 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
         const int cnt = base + (xcd < rem ? 1 : 0);
         if (idx >= cnt) return;
         const int L0 = xcd * base + (xcd < rem ? xcd : rem) + idx;
-        sk = L0 / Tt;
-        const int L = L0 - sk * Tt;
-        const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
-        const int gm = min(p.group_m, MT - gi * p.group_m);
-        nt = within / gm;
-        mt = gi * p.group_m + (within - nt * gm);
+        sk = L0 >= Tt ? (nsk == 2 ? 1 : L0 / Tt) : 0;      // (one slice, or the rider's two: no division on the product path)
+        pipe_tile_of(p, L0 - sk * Tt, MT, NT, mt, nt);
     }
     const int m0 = mt * BM, n0 = nt * BN;
-    const int nk = p.K / 64 / nsk;                          // >= 2 (launcher); PRE: >= 12
+    const int nk = p.kspan >> 6;                            // K tiles of this slice: >= 2 (launcher); PRE: >= 12
     const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda + (size_t)sk * nk * 64);
     const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw + (size_t)sk * nk * 64);
 
@@ -674,7 +674,7 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             r_first[i] = min(m0 + wm * WM + i * 32, p.M - 1);        // a block past M reads (and never stores) the last valid row
-            r_map[i] = rowmap_of(r_first[i], p.rpb);
+            r_map[i] = rowmap_of(r_first[i], p.rpb, p.fd_rpb);
         }
     }
     auto res_load = [&](auto RI) __attribute__((always_inline)) {
@@ -832,6 +832,7 @@ static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
     p.group_m = MT >= 16 ? 8 : MT;
     const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
     if (forced_gm > 0) p.group_m = forced_gm;
+    gemm_derive(p, 128, 256);
     const int nblk = 8 * ((MT * NT + 7) / 8);
     constexpr size_t lds = 3 * (size_t)(128 + 256) * 128 + 1024;      // three K-tile buffers + the tile's bias row
     auto kern = gemm_pipe128_kernel<EPI, MI16, PRE>;
@@ -863,6 +864,7 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
     p.group_m = MT >= 16 ? 8 : MT;
     const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
     if (forced_gm > 0) p.group_m = forced_gm;
+    gemm_derive(p, BM, 256);
     const int nblk = 8 * ((MT * NT + 7) / 8);
 #ifdef GEMM_TRACE
     constexpr size_t lds = 2 * (size_t)(BM + 256) * 128 + 1024 + 2 * 64 * 4 * 4 * 4;
@@ -893,16 +895,17 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
 // (measured on one box: 1207 -> 1282-1290 frames/s; non-temporal on ALL weights: no gain, and 1402 -> 1273 when the text branch
 // is reused, because the nine M tiles of a visual GEMM share each weight tile through L2).
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b) {
-    kernarg_warm<2 * sizeof(GemmParams) + 16 + 64>();
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b,
+                                                                         const FastDiv fa, const FastDiv fb) {      // fa / fb = fastdiv_of(tiles_a / tiles_b)
+    kernarg_warm<2 * sizeof(GemmParams) + 16 + 16 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t pfs = prefetch_issue<64 * WGM * WGN>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);     // (the visual problem's next weight; the rider's gain nothing from it)
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
     if ((int)blockIdx.x < blocks_a) {
-        const int id = (int)blockIdx.x, sk = id / tiles_a;
+        const int id = (int)blockIdx.x, sk = (int)fd_div((uint32_t)id, fa);
         gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false>(pa, id - sk * tiles_a, sk, 0, smem);
     } else {
-        const int id = (int)blockIdx.x - blocks_a, sk = id / tiles_b;
+        const int id = (int)blockIdx.x - blocks_a, sk = (int)fd_div((uint32_t)id, fb);
         gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false, true>(pb, id - sk * tiles_b, sk, 0, smem);
     }
     prefetch_retire(pfs);
@@ -942,6 +945,7 @@ static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_i
         p.group_m = MT >= 16 ? 8 : MT;
         const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
         if (forced_gm > 0) p.group_m = forced_gm;
+        gemm_derive(p, BM, 256);
         return 8 * ((MT * NT * (p.splitk > 1 ? p.splitk : 1) + 7) / 8);
     };
     const int ba = grid(a, BMA), bb = grid(b, 128);
@@ -979,6 +983,7 @@ static hipError_t launch_glds(const GemmParams& p_in, hipStream_t s) {
     if (forced_gm >= 0) p.group_m = forced_gm;
     const bool kxcd = !CONV && forced_gm < 0 && gemm_kxcd_ok(p, MT, NT);
     if (kxcd) p.group_m = -1;
+    gemm_derive(p, BM, BN);
     const int nblk = kxcd ? 8 * MT * (NT / (8 / p.splitk)) : p.group_m ? 8 * ((MT * NT + 7) / 8) : 8 * ((NT + 7) / 8) * MT;
     const size_t lds = (size_t)NS * (BM + BN) * (BK * 2);
     auto kern = gemm_glds_kernel<BM, BN, WGM, WGN, EPI, NS, CONV, NTW, BK, PROD>;
@@ -1139,6 +1144,8 @@ static hipError_t launch_pair_epi(const GemmParams& a_in, const GemmParams& b_in
     // K-slice map: the grid of a problem is 1-D over (tile, slice); "tiles" = all its blocks makes the kernel pass the block id through
     if (gemm_kxcd_ok(a, mta, a.N / 64)) { a.group_m = -1; ba = ta = 8 * mta * ((a.N / 64) / (8 / a.splitk)); }
     if (gemm_kxcd_ok(b, mtb, b.N / 64)) { b.group_m = -1; bb = tb = 8 * mtb * ((b.N / 64) / (8 / b.splitk)); }
+    gemm_derive(a, 64, 64);
+    gemm_derive(b, 64, 64);
     constexpr size_t lds = NS * (size_t)(64 + 64) * 128;
     auto kern = gemm_glds_pair_kernel<64, 64, 2, 2, EPI, NS>;
     static bool attr_done = false;
@@ -1150,7 +1157,7 @@ static hipError_t launch_pair_epi(const GemmParams& a_in, const GemmParams& b_in
     static char name[64];
     if (!name[0]) snprintf(name, sizeof(name), "gemm_glds_pair_kernel<64,64,2,2,%d,%d>", EPI, NS);
     g_last_kernel = name;
-    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(256), lds, s, a, b, ba, ta, tb);
+    hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(256), lds, s, a, b, ba, ta, tb, fastdiv_of((uint32_t)ta), fastdiv_of((uint32_t)tb));
     return hipGetLastError();
 }
 
@@ -1304,6 +1311,8 @@ static hipError_t launch_ln_gemm_epi(const LnParams& la, const LnParams* lb, con
     const int mta = (a.M + 63) / 64, mtb = (b.M + 63) / 64;
     a.group_m = mta;
     b.group_m = mtb;
+    gemm_derive(a, 64, 64);
+    gemm_derive(b, 64, 64);
     const int ta = 8 * ((mta * (a.N / 64) + 7) / 8), tb = b_in ? 8 * ((mtb * (b.N / 64) + 7) / 8) : 0;
     const int ba = ta, bb = tb;                                   // no split-K here (QKV / fc1)
     constexpr size_t lds = NS * (size_t)(64 + 64) * 128;
@@ -1320,6 +1329,8 @@ static hipError_t launch_ln_gemm_epi(const LnParams& la, const LnParams* lb, con
     LnParams l0 = la, l1 = lb ? *lb : la;
     l0.y_wt = 1;
     l1.y_wt = 1;
+    l0.fd_rpb = fastdiv_of((uint32_t)l0.rpb);
+    l1.fd_rpb = fastdiv_of((uint32_t)l1.rpb);
     const int vba = (l0.M + 3) / 4, vbb = lb ? (l1.M + 3) / 4 : 0;
     hipLaunchKernelGGL(kern, dim3(ba + bb), dim3(256), lds, s, l0, l1, vba, vbb, a, b, ba, ta, tb ? tb : 1, bar, gen, *base);
     const hipError_t e = hipGetLastError();

@@ -54,7 +54,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
             const int rowl = m0 + ib * 16 + l15;
             if (rowl < p.M) {
                 int b, rem;
-                rowmap_at(rowmap_of(m0 + ib * 16, p.rpb), m0 + ib * 16, l15, b, rem);
+                rowmap_at(rowmap_of(m0 + ib * 16, p.rpb, p.fd_rpb), m0 + ib * 16, l15, b, rem);
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {
                     const int col = colw + 16 * jb + 4 * g;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
         const int row = m0 + i * 32 + r;
         inb = row < p.M;
         int b, rem;
-        rowmap_at(rowmap_of(rfirst, p.rpb), rfirst, inb ? row - rfirst : p.M - 1 - rfirst, b, rem);      // rows past M read the last valid one
+        rowmap_at(rowmap_of(rfirst, p.rpb, p.fd_rpb), rfirst, inb ? row - rfirst : p.M - 1 - rfirst, b, rem);      // rows past M read the last valid one
         return reinterpret_cast<float*>(p.C) + ((size_t)b * p.obs + p.oro + rem) * p.ldc + colw + (lane % LPR) * 4;
     };
     auto load_res = [&](int i) __attribute__((always_inline)) {
@@ -123,7 +123,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                     const int r = it * RPI + lane / LPR, row = m0 + i * 32 + r;
                     const int rfirst = min(m0 + i * 32, p.M - 1);
                     int bt, rem;
-                    rowmap_at(rowmap_of(rfirst, p.rpb), rfirst, (row < p.M ? row : p.M - 1) - rfirst, bt, rem);
+                    rowmap_at(rowmap_of(rfirst, p.rpb, p.fd_rpb), rfirst, (row < p.M ? row : p.M - 1) - rfirst, bt, rem);
                     tv[0][it] = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)(p.addtab_split ? (rem >= p.addtab_split ? 1 : 0) : rem) * p.N + colw + (lane % LPR) * 4);
                 }
             }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col) = v;
                     } else {
                         int b, rem;
-                        rowmap_at(rowmap_of(m0 + i * 32, p.rpb), m0 + i * 32, r, b, rem);
+                        rowmap_at(rowmap_of(m0 + i * 32, p.rpb, p.fd_rpb), m0 + i * 32, r, b, rem);
                         const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
                         const int hh = cc >> 6, dd = cc & 63;
                         *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;
@@ -217,9 +217,9 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
         const int cnt = base + (xcd < rem ? 1 : 0);
         if (idx >= cnt) return;
         const int L = xcd * base + (xcd < rem ? xcd : rem) + idx;
-        const int gsz = p.group_m * NT, gi = L / gsz, within = L - gi * gsz;
+        const int gsz = p.group_m * NT, gi = (int)fd_div((uint32_t)L, p.fd_gsz), within = L - gi * gsz;      // (reciprocals from the launcher: gemm_derive)
         const int gm = min(p.group_m, MT - gi * p.group_m);
-        nt = within / gm;
+        nt = (int)fd_div((uint32_t)within, gm == p.group_m ? p.fd_gm : p.fd_gml);
         mt = gi * p.group_m + (within - nt * gm);
     }
 #ifdef GEMM_DR_TRACE
@@ -294,6 +294,7 @@ static hipError_t launch_dr(const GemmParams& p_in, hipStream_t s) {
     p.group_m = MT >= 16 ? 8 : MT;
     const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
     if (forced_gm > 0) p.group_m = forced_gm;
+    gemm_derive(p, 128, 256);
     const int nblk = 8 * ((MT * NT + 7) / 8);
     constexpr size_t lds = DR_LDS_BYTES;
     auto kern = gemm_dr_kernel<EPI>;
@@ -333,6 +334,7 @@ static int dr_grid(GemmParams& p) {
     p.group_m = MT >= 16 ? 8 : MT;
     const int forced_gm = tune_get(p.tune, &uvl_tuning::gemm_gm, -1);
     if (forced_gm > 0) p.group_m = forced_gm;
+    gemm_derive(p, 128, 256);
     return 8 * ((MT * NT + 7) / 8);
 }
 

@@ -55,7 +55,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 const int rowl = rfirst + rl;
                 if (rowl < p.M) {
                     int b, rem;
-                    rowmap_at(rowmap_of(rfirst, p.rpb), rfirst, rl, b, rem);
+                    rowmap_at(rowmap_of(rfirst, p.rpb, p.fd_rpb), rfirst, rl, b, rem);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -107,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                 float* dst[CH];
                 bool inb[CH];
                 const int rfirst = min(m0 + wm * WM + i * 32, p.M - 1);      // a block past M reads (and never stores) the last valid row
-                const RowMap rmap = rowmap_of(rfirst, p.rpb);
+                const RowMap rmap = rowmap_of(rfirst, p.rpb, p.fd_rpb);
 #pragma unroll
                 for (int it = 0; it < CH; ++it) {
                     const int r = (h0 + it) * RPI + lane / LPR;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16 (&
                         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + (size_t)g * p.N + col) = v;
                     } else {
                         int b, rem;
-                        rowmap_at(rowmap_of(m0 + wm * WM + i * 32, p.rpb), m0 + wm * WM + i * 32, r, b, rem);
+                        rowmap_at(rowmap_of(m0 + wm * WM + i * 32, p.rpb, p.fd_rpb), m0 + wm * WM + i * 32, r, b, rem);
                         const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
                         const int hh = cc >> 6, dd = cc & 63;
                         *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;

@@ -40,7 +40,31 @@ struct GemmParams {
                                                  // (the 64 x 64-tile kernels of small frames; the large-tile kernels ignore it)
     int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)
+    // set by the launcher (gemm_derive): divisors of the tile decode and of the row map with their reciprocals -- no integer division in a kernel prologue
+    FastDiv fd_mt, fd_gsz, fd_gm, fd_gml;        // row tiles; tiles of a full group; row tiles of a full group / of the last group
+    FastDiv fd_rpb;                              // rpb
+    int ks_log2 = 0, ks_ntp = 0;                 // K-slice map (group_m < 0): log2(8 / splitk), column tiles per XCD share
+    int kspan = 0;                               // K / splitk
 };
+// fills the derived fields for a tile grid of BM x BN tiles (group_m already chosen)
+static inline void gemm_derive(GemmParams& p, int BM, int BN) {
+    const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
+    p.fd_mt = fastdiv_of((uint32_t)MT);
+    const int g = p.group_m > 0 ? p.group_m : 1;
+    p.fd_gsz = fastdiv_of((uint32_t)(g * (NT > 0 ? NT : 1)));
+    p.fd_gm = fastdiv_of((uint32_t)g);
+    p.fd_gml = fastdiv_of((uint32_t)((MT % g) ? (MT % g) : g));
+    p.fd_rpb = fastdiv_of((uint32_t)p.rpb);
+    const int sk = p.splitk > 1 ? p.splitk : 1;
+    p.kspan = p.K / sk;
+    if (p.group_m < 0) {
+        const int nparts = 8 / sk;
+        int l2 = 0;
+        while ((1 << l2) < nparts) ++l2;
+        p.ks_log2 = l2;
+        p.ks_ntp = NT / nparts;
+    }
+}
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // two independent plain GEMMs; one launch when both resolve to the batch-1 instantiation, else two launches (same results)
 hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_t s);
@@ -51,6 +75,7 @@ struct AttnParams {
     bf16_t* o = nullptr;                                      // [B*N, H*64]
     int B = 0, H = 0, N = 0, Npad = 0;
     int xcd_map = 0;                                          // set by the launcher: query blocks of a head share an XCD (see attn_decode_block)
+    FastDiv fd_nqb, fd_h;                                     // set by the launcher: query blocks per head (of the launched configuration), heads
     const uvl_tuning* tune = nullptr;                         // host side only: overrides of the launch heuristics (null = heuristics)
     int q_prescaled = 0;                                      // 1: q already carries the factor log2(e)/8 (GemmParams.q_scale of the QKV GEMM)
 };
@@ -61,6 +86,7 @@ struct LnParams {
     const float* x = nullptr;                    // input rows, f32
     int M = 0, D = 0;                            // compact row count
     int rpb = 1 << 30, xbs = 0, xro = 0;         // compact row m -> x row (m/rpb)*xbs + xro + m%rpb
+    FastDiv fd_rpb;                              // set by the launcher: fastdiv_of(rpb)
     const float* part = nullptr; int nsplit = 0, part_rows = 0; size_t part_stride = 0;   // pending split-K slabs [nsplit][B*part_rows, D]
                                                  // added to the row first and written back: x += sum_s part[s]
     const float* pre_add0 = nullptr;             // optional vector added to rows with t <  split (then written back to x)

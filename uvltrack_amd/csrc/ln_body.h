@@ -27,7 +27,7 @@ __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = bx * (int)(blockDim.x >> 6) + wave;     // one row per wave, blockDim.x / 64 rows per workgroup
     if (m >= p.M) return;
-    const int b = m / p.rpb, t = m - b * p.rpb;
+    const int b = (int)fd_div((uint32_t)m, p.fd_rpb), t = m - b * p.rpb;      // (the reciprocal of rpb comes from the launcher: no division in front of the row's loads)
     const size_t xrow = (size_t)b * p.xbs + p.xro + t;
     float* xr = const_cast<float*>(p.x) + xrow * p.D;
     const float* xin = (p.x_alt && t >= p.split) ? p.x_alt + ((size_t)b * p.x_alt_rows + (t - p.split)) * p.D : xr;

@@ -41,7 +41,10 @@ static int ln_waves_per_block(int M) { return M <= 768 ? 1 : 4; }
 static const char* ln_name(bool pair, int nv, bool full, bool slabs, int ct) {
     static char names[2][5][2][2][3][40];              // interned: the profiler keeps the pointer
     char* name = names[pair][nv & 7 ? (nv > 4 ? 4 : nv) : 0][full][slabs][ct];
-    if (!name[0]) snprintf(name, 40, "%s<%d,%d,%d,%d>", pair ? "ln_pair_kernel" : "ln_kernel", nv, (int)full, (int)slabs, (int)ct);
+    if (!name[0]) {
+        if (pair) snprintf(name, 40, "ln_pair_kernel<%d,%d,%d,%d,%d>", nv, (int)full, (int)slabs, (int)ct, (int)slabs);      // (SLABS_B defaults to SLABS)
+        else snprintf(name, 40, "ln_kernel<%d,%d,%d,%d>", nv, (int)full, (int)slabs, (int)ct);
+    }
     return name;
 }
 
@@ -57,7 +60,9 @@ static void launch_ln_variant(const LnParams& p, int grid, int wpb, hipStream_t 
     else hipLaunchKernelGGL((ln_kernel<NV, FULL, false, false>), dim3(grid), dim3(64 * wpb), 0, s, p);
 }
 
-hipError_t launch_layernorm(const LnParams& p, hipStream_t s) {
+hipError_t launch_layernorm(const LnParams& p_in, hipStream_t s) {
+    LnParams p = p_in;
+    p.fd_rpb = fastdiv_of((uint32_t)p.rpb);
     if (p.D % 4 != 0 || p.D > 1024 || p.M <= 0 || p.nsplit > LN_MAX_SLABS || (p.ct_x && p.ct_self && (p.nsplit > 0 || p.ct_x != p.x))) return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(p.M);
     const int grid = (p.M + wpb - 1) / wpb;
@@ -73,10 +78,10 @@ template <int NV, bool FULL>
 static void launch_ln_pair_variant(const LnParams& a, const LnParams& b, int ga, int gb, int wpb, hipStream_t s) {
     const bool slabs = a.nsplit > 0 || b.nsplit > 0, ct = a.ct_x != nullptr;
     const bool self = ct && a.ct_self && !slabs;
-    if (NV >= 3 && FULL && a.nsplit == 0 && b.nsplit > 0 && !(ct && !a.ct_self)) {      // only the rider has slabs (names: "...,0,<ct>,b>")
+    if (NV >= 3 && FULL && a.nsplit == 0 && b.nsplit > 0 && !(ct && !a.ct_self)) {      // only the rider has slabs (names as rocprofv3 prints them: "...,0,<ct>,1>")
         static char nm[2][40];
         const int c2 = (ct && a.ct_self) ? 1 : 0;
-        if (!nm[c2][0]) snprintf(nm[c2], 40, "ln_pair_kernel<%d,1,0,%d,b>", NV, c2 ? 2 : 0);
+        if (!nm[c2][0]) snprintf(nm[c2], 40, "ln_pair_kernel<%d,1,0,%d,1>", NV, c2 ? 2 : 0);
         g_last_kernel = nm[c2];
         if (c2) hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, 2, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
         else hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, 0, true>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
@@ -90,7 +95,10 @@ static void launch_ln_pair_variant(const LnParams& a, const LnParams& b, int ga,
     else hipLaunchKernelGGL((ln_pair_kernel<NV, FULL, false, false>), dim3(ga + gb), dim3(64 * wpb), 0, s, a, b, ga);
 }
 
-hipError_t launch_layernorm_pair(const LnParams& a, const LnParams& b, hipStream_t s) {
+hipError_t launch_layernorm_pair(const LnParams& a_in, const LnParams& b_in, hipStream_t s) {
+    LnParams a = a_in, b = b_in;
+    a.fd_rpb = fastdiv_of((uint32_t)a.rpb);
+    b.fd_rpb = fastdiv_of((uint32_t)b.rpb);
     if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0 || a.nsplit > LN_MAX_SLABS || b.nsplit > LN_MAX_SLABS || b.ct_x ||
         (a.ct_x && a.ct_self && (a.nsplit > 0 || a.ct_x != a.x)))
         return hipErrorInvalidValue;
