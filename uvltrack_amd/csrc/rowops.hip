@@ -26,10 +26,18 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
 // stay in place -- the HBM-bound visual LayerNorm must not pay the slab operand slots); SLABS covers both problems otherwise.
 template <int NV, bool FULL, bool SLABS, int CT, bool SLABS_B = SLABS>
 __global__ __launch_bounds__(256) void ln_pair_kernel(const LnParams pa, const LnParams pb, int split) {
-    kernarg_warm<2 * sizeof(LnParams) + 8 + 64>();
+    kernarg_warm<2 * sizeof(LnParams) + 8 + 64>();      // (+ 64: the kernel reads gridDim -- the first line of the hidden arguments)
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
-    if ((int)blockIdx.x < split) ln_body<NV, FULL, SLABS, CT>(pa, (int)blockIdx.x);
-    else ln_body<NV, FULL, SLABS_B, 0>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
+    if constexpr (SLABS_B && !SLABS) {
+        // the rider's rows fold slabs (more loads per row than the visual rows): its workgroups come FIRST, or they are the launch's tail
+        // (rocprofv3, 8 UVLTrack-L sequences: 14.1 us with the rider behind the visual rows against 10.2 us for the launch without slabs)
+        const int nb = (int)gridDim.x - split;
+        if ((int)blockIdx.x < nb) ln_body<NV, FULL, true, 0>(pb, (int)blockIdx.x);
+        else ln_body<NV, FULL, false, CT>(pa, (int)blockIdx.x - nb);
+    } else {
+        if ((int)blockIdx.x < split) ln_body<NV, FULL, SLABS, CT>(pa, (int)blockIdx.x);
+        else ln_body<NV, FULL, SLABS_B, 0>(pb, (int)blockIdx.x - split);      // the rider is a text-branch LayerNorm: never a contrast job
+    }
 }
 
 // Rows (= waves) per workgroup.  With one memory round trip per row, one sequence of UVLTrack-B (553 rows) is 1.5-2.6 % faster in
