@@ -233,7 +233,9 @@ int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
  * residual GEMMs run in place; logits equal within one f32 rounding).  "prefetch_w" (default 1): next-weight requests in the
  * small-tile GEMM launches -- 0 never, 1 below 2000 visual rows for models whose weights exceed the memory-side cache, 2 always.  "fork_text" (default 1): 0 runs the
  * text branch of multi-sequence frames on the caller's stream.  "fuse_ln" (default 0): 1 launches LayerNorm and the GEMM that
- * consumes it as one kernel behind a grid barrier in one-sequence frames (96 -> 72 launches, same bits, measured slower). */
+ * consumes it as one kernel behind a grid barrier in one-sequence frames (96 -> 72 launches, same bits, measured slower).  "rider_sk" (default 2): 1 runs
+ * the text rider of a many-sequence fc2 launch in one K slice, in place (the round-4 form).  "rider_first" (default 1): 0 puts the text rider's tiles of a
+ * one-sequence pair GEMM launch behind the visual tiles. */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
 /* Overrides of the launch heuristics, for tools and tests (not part of the product path).  There is NO process-global tuning

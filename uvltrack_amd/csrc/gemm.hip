@@ -894,6 +894,8 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
 // weights are read once, by one CU each, so taking them out of the allocation stream leaves the rest resident across frames
 // (measured on one box: 1207 -> 1282-1290 frames/s; non-temporal on ALL weights: no gain, and 1402 -> 1273 when the text branch
 // is reused, because the nine M tiles of a visual GEMM share each weight tile through L2).
+// (Round 5, measured and not kept for the rider of THIS kernel: its whole weight panel requested up front, one dword per line, before the first LDS-DMA: -5 % on
+// the one-sequence frame; the rider on 128 x 32 tiles -- half the panel per CU, twice the workgroups: -2.5..3 %.  profiles/r05_summary.md)
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b,
                                                                          const FastDiv fa, const FastDiv fb) {      // fa / fb = fastdiv_of(tiles_a / tiles_b)
@@ -901,11 +903,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t pfs = prefetch_issue<64 * WGM * WGN>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);     // (the visual problem's next weight; the rider's gain nothing from it)
     // two calls, not a selected reference: selecting between the two by-value argument blocks would copy one into scratch
-    if ((int)blockIdx.x < blocks_a) {
-        const int id = (int)blockIdx.x, sk = (int)fd_div((uint32_t)id, fa);
+    // rider_first (round 5): the rider's workgroups take the FIRST block indices.  Its tiles stream BERT weights nobody has read this frame (HBM latency per
+    // K tile) while the visual tiles' weights sit in the memory-side cache: dispatched behind the visual tiles they were the tail of every pair launch
+    // (rocprofv3, one UVLTrack-B sequence: pair launches 9.3 / 10.8 / 10.5 us against 8.1 / 9.2 / 8.9 us for the same visual problem alone).
+    const int blocks_b = (int)gridDim.x - blocks_a;
+    const int bid = pb.rider_first ? ((int)blockIdx.x >= blocks_b ? (int)blockIdx.x - blocks_b : (int)blockIdx.x + blocks_a) : (int)blockIdx.x;      // -> [A | B] index
+    if (bid < blocks_a) {
+        const int id = bid, sk = (int)fd_div((uint32_t)id, fa);
         gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false>(pa, id - sk * tiles_a, sk, 0, smem);
     } else {
-        const int id = (int)blockIdx.x - blocks_a, sk = (int)fd_div((uint32_t)id, fb);
+        const int id = bid - blocks_a, sk = (int)fd_div((uint32_t)id, fb);
         gemm_glds_body<BM, BN, WGM, WGN, EPI, NS, false, true>(pb, id - sk * tiles_b, sk, 0, smem);
     }
     prefetch_retire(pfs);

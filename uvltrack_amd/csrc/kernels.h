@@ -45,6 +45,7 @@ struct GemmParams {
     FastDiv fd_rpb;                              // rpb
     int ks_log2 = 0, ks_ntp = 0;                 // K-slice map (group_m < 0): log2(8 / splitk), column tiles per XCD share
     int kspan = 0;                               // K / splitk
+    int rider_first = 1;                         // pair launches of one-sequence frames (gemm_glds_pair_kernel): this problem, as the RIDER, takes the first block indices
 };
 // fills the derived fields for a tile grid of BM x BN tiles (group_m already chosen)
 static inline void gemm_derive(GemmParams& p, int BM, int BN) {
