@@ -894,8 +894,9 @@ static hipError_t launch_pipe(const GemmParams& p_in, hipStream_t s) {
 // weights are read once, by one CU each, so taking them out of the allocation stream leaves the rest resident across frames
 // (measured on one box: 1207 -> 1282-1290 frames/s; non-temporal on ALL weights: no gain, and 1402 -> 1273 when the text branch
 // is reused, because the nine M tiles of a visual GEMM share each weight tile through L2).
-// (Round 5, measured and not kept for the rider of THIS kernel: its whole weight panel requested up front, one dword per line, before the first LDS-DMA: -5 % on
-// the one-sequence frame; the rider on 128 x 32 tiles -- half the panel per CU, twice the workgroups: -2.5..3 %.  profiles/r05_summary.md)
+// (Round 5, measured and not kept for the rider of THIS kernel: its whole weight panel requested up front before the first LDS-DMA -- non-temporal, one dword per
+// line: -5 % on the one-sequence frame; plain, both halves of every line: -5..7 % (the BERT weights then displace the ViT weights from the memory-side cache) -- and
+// the rider on 128 x 32 tiles -- half the panel per CU, twice the workgroups: -2.5..3 %.  profiles/r05_summary.md)
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const GemmParams pa, const GemmParams pb, int blocks_a, int tiles_a, int tiles_b,
                                                                          const FastDiv fa, const FastDiv fb) {      // fa / fb = fastdiv_of(tiles_a / tiles_b)
