@@ -169,6 +169,9 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
             else loff[i] = (uint32_t)(r - BM) * (uint32_t)p.ldw * 2u + (uint32_t)chunk * 16u;
         }
     }
+    // (named OUTSIDE the lambda: a lambda is implicitly host-device, and a static device variable it names is "used by host code" -- hipcc then externalises it
+    // and every kernel of this file reaches it through a GOT load, a dependent scalar round trip in front of the bias loads and the first LDS-DMA)
+    const bf16_t* const zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
     auto issue = [&](int kt, bool do_a = true, bool do_w = true) __attribute__((always_inline)) {
         char* st = smem + (kt % NS) * STAGE;
         if constexpr (CONV) {
@@ -183,7 +186,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
                 if (i < LPT_A) {
                     const int ii = a_i[i] + tap_di, jj = a_j[i] + tap_dj;
                     const bool ok = (unsigned)ii < (unsigned)convF && (unsigned)jj < (unsigned)convF;
-                    gp = ok ? src[i] + (size_t)(ii * convF + jj) * lda + c0 : reinterpret_cast<const bf16_t*>(g_zero_page);
+                    gp = ok ? src[i] + (size_t)(ii * convF + jj) * lda + c0 : zero_page;
                 } else {
                     gp = src[i] + kt * BK;
                 }
