@@ -25,11 +25,6 @@ __device__ __forceinline__ float4 sel4(bool c, const float4& a) { return c ? a :
 template <int NV, bool FULL, bool SLABS, int CT>
 __device__ __forceinline__ void ln_body(const LnParams& p, int bx) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // every argument the row's addresses depend on is requested HERE, in one batch of scalar loads behind one wait: hipcc loads a field where it is first
-    // used, and this prologue's branches cut that into six dependent load -> wait steps in front of the row's first global load (round 5)
-    asm volatile("" ::"s"(p.M), "s"(p.rpb), "s"(p.fd_rpb.d), "s"(p.fd_rpb.m), "s"(p.xbs), "s"(p.xro), "s"(p.x), "s"(p.D), "s"(p.x_alt), "s"(p.split),
-                 "s"(p.x_alt_rows), "s"(p.pre_add0), "s"(p.pre_add1), "s"(p.part), "s"(p.nsplit), "s"(p.part_rows), "s"(p.part_stride), "s"(p.gamma), "s"(p.beta),
-                 "s"((int)blockDim.x));
     const int m = bx * (int)(blockDim.x >> 6) + wave;     // one row per wave, blockDim.x / 64 rows per workgroup
     if (m >= p.M) return;
     const int b = (int)fd_div((uint32_t)m, p.fd_rpb), t = m - b * p.rpb;      // (the reciprocal of rpb comes from the launcher: no division in front of the row's loads)
