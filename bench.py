@@ -217,11 +217,27 @@ def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmu
             return times
 
 
+def pick_gather_every(step_fn, sync, env, forced: int = 0) -> int:
+    """Steps per box all-gather (uvltrack_amd/shard.py::choose_every) from a few untimed steps: the SLOWEST rank's step time decides, so that every rank builds
+    the same groups (a rank that disagreed would wait in a collective the others never issue).  tests/test_bench_loop_gloo.py drives it over gloo with stub steps."""
+    from uvltrack_amd.shard import choose_every
+    if forced > 0:
+        return forced
+    for _ in range(3):
+        step_fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step_fn()
+    sync()
+    return choose_every(env.max_over_ranks((time.perf_counter() - t0) / 5) * 1e3)
+
+
 def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_text, use_graph, steps, warmup, blocks, seed):
     """Build an engine for `spec`, run the timed blocks; returns (times, engine, targs, outs, step description)."""
     from uvltrack_amd import weightgen as wg
     from uvltrack_amd.engine import HipEngine
-    from uvltrack_amd.shard import BoxGatherer, choose_every
+    from uvltrack_amd.shard import BoxGatherer
     flags = [flag_val] * B
     eng = HipEngine(spec, dev, max_batch=max(B, 1))
     for kv in args.tune:
@@ -245,16 +261,7 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     # few untimed steps, the slowest rank's figure, so that every rank builds the same groups
     gatherer = None
     if isinstance(env, DistEnv):                      # also with ONE rank under torch.distributed.run
-        every = int(getattr(args, "gather_every", 0) or 0)
-        if every <= 0:
-            for _ in range(3):
-                step_fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                step_fn()
-            torch.cuda.synchronize()
-            every = choose_every(env.max_over_ranks((time.perf_counter() - t0) / 5) * 1e3)
+        every = pick_gather_every(step_fn, torch.cuda.synchronize, env, int(getattr(args, "gather_every", 0) or 0))
         gatherer = BoxGatherer(env.world * B, dev, every=every)
     times = timed_blocks(lambda i: step_fn(), lambda: outs["pred_boxes"].view(B, 4), gatherer, env, torch.cuda.synchronize, steps, warmup, blocks)
     finite = bool(torch.isfinite(outs["bbox_map"]).all().item()) and bool(torch.isfinite(outs["logits"]).all().item())

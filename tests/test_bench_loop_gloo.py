@@ -129,6 +129,39 @@ def _worker_one(port, q):
         dist.destroy_process_group()
 
 
+def _worker_cadence(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        env = bench.DistEnv(dist, torch.device("cpu"))
+        # rank 0 steps in 0.2 ms, rank 1 in 3 ms: alone rank 0 would group eight steps, rank 1 would not -- the slowest rank decides for both
+        slow = bench.pick_gather_every(lambda: time.sleep(0.0002 if rank == 0 else 0.003), lambda: None, env)
+        fast = bench.pick_gather_every(lambda: time.sleep(0.0002), lambda: None, env)
+        forced = bench.pick_gather_every(lambda: None, lambda: None, env, forced=4)
+        q.put((rank, slow, fast, forced))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_gather_cadence_world2_gloo():
+    """bench.pick_gather_every: the cadence comes from the slowest rank's step time (max over ranks), so the ranks cannot build different groups."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_cadence, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1:] for r in res] == [(1, 8, 4), (1, 8, 4)], res
+
+
 def test_gather_cadence_follows_the_step_time():
     """one all-gather per step wherever a step is long enough for it to be free (configs[4]: ~6 ms); groups of eight only
     for sub-millisecond frames.  The bench line reports the cadence and the worst-case lateness."""
