@@ -68,8 +68,24 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 // issues it ~55 cycles, half of what a consumer of the 128x128 tile issues per K step (profiles/r02_gemm_structure.md, probe 5).
 // PRE (the fused LayerNorm + GEMM launch): 1 = request the WEIGHT halves of the first NS - 1 K tiles and return (they do not depend on
 // the LayerNorm and fly under it and the grid barrier); 2 = the rest of the tile: the activation halves, then the usual loop.
+// Development builds only (tools/glds_trace.py; the product library defines none of these): GLDS_TRACE = wave 0 of every workgroup stamps the 100 MHz clock at
+// the seams of gemm_glds_body; GLDS_ABL = timing ablations of its K loop (results are wrong): 1 no MFMA, 2 no fragment reads, 4 no LDS-DMA inside the loop,
+// 8 no barrier; GLDS_ORDER=0 = the round-1..4 order of the 64 x 64 loop (LDS-DMA requested before the fragment reads).
+#ifndef GLDS_ABL
+#define GLDS_ABL 0
+#endif
+#ifndef GLDS_ORDER
+#define GLDS_ORDER 1
+#endif
+#ifdef GLDS_TRACE
+__device__ unsigned long long g_glds_trace[2048 * 8];
+#define GLDS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048) g_glds_trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GLDS_STAMP(k) do { } while (0)
+#endif
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0, int PRE = 0>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk_in, const int g, char* smem) {
+    GLDS_STAMP(0);
     int sk = sk_in;
     static_assert(PRE == 0 || (!CONV && !PROD && NS == 4), "split prologue: plain four-stage tiles only");
     static_assert(BK == 64 || (BK == 32 && !CONV), "K extent of a stage");
@@ -224,6 +240,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
             if (t < nk_) issue(t, false, true);
         return;
     }
+    GLDS_STAMP(1);
     f32x4 bias_v[TN][4];
     gemm_bias_preload<TN>(p, n0 + wn * WN, lane, g, sk, bias_v);     // older than every DMA: retired by the first tile wait
 
@@ -256,6 +273,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         __builtin_amdgcn_s_barrier();                        // the epilogue's "every wave has finished reading the ring"
         return;
     }
+    GLDS_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
         if (!PROD) {
             // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight
@@ -270,29 +288,58 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
             else if (NS > 3 && ahead == 1) wait_vmcnt<LPT>();
             else wait_vmcnt<0>();
         }
-        __builtin_amdgcn_s_barrier();
-        if (!PROD && kt + NS - 1 < nk) issue(kt + NS - 1);            // its stage was last read in iteration kt-1
+        if (!(GLDS_ABL & 8)) __builtin_amdgcn_s_barrier();
+        if (kt == 0) GLDS_STAMP(3);
+        if (kt == 1) GLDS_STAMP(4);
         const char* sA = smem + (kt % NS) * STAGE;
         const char* sB = sA + BM * RB;
+        // One 32 x 32 block per wave (the 64 x 64 tile of one-sequence frames: one wave per SIMD, nothing else to run under a stall): the stage's fragment reads
+        // go out FIRST, the LDS-DMA of tile kt + NS - 1 is requested under their round trip (an LDS-DMA instruction holds the issuing wave ~55 cycles), then the
+        // MFMAs.  tools/glds_trace.py, QKV GEMM of a UVLTrack-B sequence (360 x 2304 x 768, 216 workgroups): K loop 3.39 -> 2.96 us per workgroup, launch
+        // 7.17 -> 6.63 us back to back; fc2 slabs (K = 3072 in 4 slices) 8.9 -> 8.5 us; proj slabs 5.45 -> 5.30 us.  (Measured beside it and not kept: the second
+        // half of the LDS-DMA behind the MFMAs, +0.2 us; the four waves splitting K with the partial tiles summed through the ring -- a stage is then read from
+        // LDS once instead of twice: loop -0.4 us, accumulator set-up and the sum +0.45 us; eight waves, the upper four on k steps 2-3: loop -0.15 us,
+        // prologue and hand-over +0.3 us.  profiles/r05_glds_loop.md)
+        if constexpr (GLDS_ORDER && !CONV && !PROD && TM * TN == 1 && GLDS_ABL == 0) {
+            bf16x8 af[KS], bfr[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int chunk = ks * 2 + (lane >> 5);
+                af[ks] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * WM + (lane & 31), chunk));
+                bfr[ks] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * WN + (lane & 31), chunk));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NS - 1 < nk) issue(kt + NS - 1);                 // its stage was last read in iteration kt-1
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks], af[ks], acc[0][0], 0, 0, 0);
+            continue;
+        }
+        if (!(GLDS_ABL & 4) && !PROD && kt + NS - 1 < nk) issue(kt + NS - 1);            // its stage was last read in iteration kt-1
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8 af[TM], bfr[TN];
             const int chunk = ks * 2 + (lane >> 5);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * WM + i * 32 + (lane & 31), chunk));
+                if (GLDS_ABL & 2) asm volatile("; frag" : "=v"(af[i]));
+                else af[i] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * WM + i * 32 + (lane & 31), chunk));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * WN + j * 32 + (lane & 31), chunk));
+                if (GLDS_ABL & 2) asm volatile("; frag" : "=v"(bfr[j]));
+                else bfr[j] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * WN + j * 32 + (lane & 31), chunk));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue_lds
+                    if (GLDS_ABL & 1) asm volatile("; use" :: "v"(bfr[j]), "v"(af[i]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue_lds
         }
     }
+    GLDS_STAMP(5);
     static_assert(32 * (WN * 4 + 16) * NW <= NS * STAGE, "epilogue staging fits in the ring");
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
+    GLDS_STAMP(6);
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
@@ -1207,6 +1254,9 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
     return hipErrorInvalidValue;
 }
 
+#ifdef GLDS_TRACE
+extern "C" int uvl_debug_glds_trace(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(uvl::g_glds_trace), (size_t)n * 8 * sizeof(unsigned long long)); }
+#endif
 #ifdef GEMM_TRACE
 extern "C" int uvl_debug_gemm_trace(unsigned int* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), (2 * 64 * 4 * 4 + 16) * sizeof(unsigned int)); }
 #endif
