@@ -40,12 +40,11 @@ def main():
     sk = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].isdigit() else 0
     sys.path.insert(0, ROOT)
     from uvltrack_amd import _native
-    if "--ksw" in sys.argv:                       # the K-split-waves form beside the 2 x 2-wave form (uvl_tuning.ksw), product loop
+    if "--orders" in sys.argv:                    # loop orders of the 64 x 64 tile (-DGLDS_ORDER), product loop otherwise
         for rep in range(2):
             for abl in ABLS:
-                for ksw in (0, 1):
-                    print("--- order %d ksw %d" % (abl // 100, ksw))
-                    one(torch, C.CDLL(LIBF % abl), M, N, K, sk, _native.UvlTuning(gemm_cfg=4, ksw=ksw))
+                print("--- order %d" % (abl // 100))
+                one(torch, C.CDLL(LIBF % abl), M, N, K, sk, _native.UvlTuning(gemm_cfg=4))
         return
     for abl in ABLS:
         print("--- ablation %d (1 no MFMA, 2 no fragment reads, 4 no LDS-DMA in the loop, 8 no barrier)" % abl)

@@ -297,9 +297,11 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         // go out FIRST, the LDS-DMA of tile kt + NS - 1 is requested under their round trip (an LDS-DMA instruction holds the issuing wave ~55 cycles), then the
         // MFMAs.  tools/glds_trace.py, QKV GEMM of a UVLTrack-B sequence (360 x 2304 x 768, 216 workgroups): K loop 3.39 -> 2.96 us per workgroup, launch
         // 7.17 -> 6.63 us back to back; fc2 slabs (K = 3072 in 4 slices) 8.9 -> 8.5 us; proj slabs 5.45 -> 5.30 us.  (Measured beside it and not kept: the second
-        // half of the LDS-DMA behind the MFMAs, +0.2 us; the four waves splitting K with the partial tiles summed through the ring -- a stage is then read from
+        // half of the LDS-DMA behind the MFMAs, or LDS-DMA instructions between the MFMAs, +0.2..0.4 us (an LDS-DMA issued while the wave's MFMAs are in flight is slow); the four waves splitting K with the partial tiles summed through the ring -- a stage is then read from
         // LDS once instead of twice: loop -0.4 us, accumulator set-up and the sum +0.45 us; eight waves, the upper four on k steps 2-3: loop -0.15 us,
-        // prologue and hand-over +0.3 us.  profiles/r05_glds_loop.md)
+        // prologue and hand-over +0.3 us; four PRODUCER waves beside the four consumers (PROD = 4, three or four stages): -0.5 us per launch back to back in
+        // isolation, nothing in the frame -- rocprofv3 averages of the frame's GEMM launches 144.7 ms / 145.5 ms per 321 frames, frames/s equal within the
+        // repeats.  profiles/r05_glds_loop.md)
         if constexpr (GLDS_ORDER && !CONV && !PROD && TM * TN == 1 && GLDS_ABL == 0) {
             bf16x8 af[KS], bfr[KS];
 #pragma unroll
