@@ -32,9 +32,54 @@ def build():
         print("built", LIBF % abl)
 
 
+def frame(model):
+    """The same stamps INSIDE the frame: every workgroup of every gemm_glds launch adds its phase times to per-epilogue accumulators (g_glds_acc) over 50 replays of one
+    sequence's frame (order 1 library = the product loop); the 0-order library beside it."""
+    import torch
+    from uvltrack_amd import _native
+    import bench
+    from uvltrack_amd import weightgen as wg
+    names = ["decode", "issue", "tile0", "tile1", "loop", "epilogue"]
+    for abl in (100, 0):
+        _native.LIB_PATH = LIBF % abl
+        _native._lib = None
+        from uvltrack_amd.engine import HipEngine
+        dev = torch.device("cuda:0")
+        spec = bench.build_spec(model, 128, 256)
+        eng = HipEngine(spec, dev, max_batch=1)
+        lib = eng.lib
+        assert os.path.samefile(lib._name, LIBF % abl), (lib._name, LIBF % abl)
+        lib.uvl_debug_glds_acc.argtypes = [C.c_void_p, C.c_int]
+        eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
+        inp = wg.make_inputs(spec, batch=1, seed=1, flags=[2])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        eng.capture(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
+        for _ in range(10):
+            eng.replay()
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 64)()
+        assert lib.uvl_debug_glds_acc(buf, 1) == 0
+        n = 50
+        for _ in range(n):
+            eng.replay()
+        torch.cuda.synchronize()
+        assert lib.uvl_debug_glds_acc(buf, 1) == 0
+        a = np.frombuffer(buf, dtype=np.uint64).astype(np.float64).reshape(8, 8)
+        print("--- loop order %d, UVLTrack-%s x 1, per workgroup of the frame's 64 x 64 GEMM launches (us; 100 MHz ticks summed over every workgroup, %d frames)" % (abl // 100, model, n))
+        for row, lab in ((0, "bf16/GELU epilogue"), (1, "f32 slabs"), (2, "QKV scatter"), (4, "rider bf16"), (5, "rider f32"), (6, "rider QKV")):
+            if a[row, 6] == 0:
+                continue
+            per = a[row, :6] / a[row, 6] / 100.0
+            print("   %-20s %6.0f workgroups/frame, %4.1f K tiles each: " % (lab, a[row, 6] / n, a[row, 7] / a[row, 6]) + "  ".join("%s %.2f" % (nm, v) for nm, v in zip(names, per)) + "   | total %.2f" % per.sum())
+        eng.close()
+        del eng
+
+
 def main():
     if "--build" in sys.argv:
         return build()
+    if "--frame" in sys.argv:
+        return frame("L" if "L" in sys.argv else "B")
     import torch
     M, N, K = (int(a) for a in sys.argv[1:4])
     sk = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].isdigit() else 0

@@ -79,12 +79,16 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 #endif
 #ifdef GLDS_TRACE
 __device__ unsigned long long g_glds_trace[2048 * 8];
-#define GLDS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048) g_glds_trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_glds_acc[8 * 8];     // [4 * NTW + EPI][phase 0..5 ticks summed over every workgroup of every launch, 6: workgroups, 7: K tiles]: the loop inside a whole frame
+#define GLDS_STAMP(k) do { gl_t[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GLDS_STAMP(k) do { } while (0)
 #endif
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0, int PRE = 0>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk_in, const int g, char* smem) {
+#ifdef GLDS_TRACE
+    unsigned long long gl_t[7] = {};      // (scalar registers: the stamps cost the loop nothing but the s_memrealtime itself; everything is written out behind the last one)
+#endif
     GLDS_STAMP(0);
     int sk = sk_in;
     static_assert(PRE == 0 || (!CONV && !PROD && NS == 4), "split prologue: plain four-stage tiles only");
@@ -302,7 +306,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         // prologue and hand-over +0.3 us; four PRODUCER waves beside the four consumers (PROD = 4, three or four stages): -0.5 us per launch back to back in
         // isolation, nothing in the frame -- rocprofv3 averages of the frame's GEMM launches 144.7 ms / 145.5 ms per 321 frames, frames/s equal within the
         // repeats.  profiles/r05_glds_loop.md)
-        if constexpr (GLDS_ORDER && !CONV && !PROD && TM * TN == 1 && GLDS_ABL == 0) {
+        // (Not for the text-branch tiles, NTW: 40 rows against weights nobody has read this frame -- their loop waits for HBM, and a request issued later lands later:
+        // tools/glds_trace.py --frame, rider workgroups of one UVLTrack-B sequence 6.4 -> 7.3 us with the reads first.  A deeper ring for the rider's tiles alone,
+        // 5 / 6 stages beside the visual tiles' 4: 0 / -3 % in the frame.)
+        if constexpr (GLDS_ORDER && !CONV && !PROD && !NTW && TM * TN == 1 && GLDS_ABL == 0) {
             bf16x8 af[KS], bfr[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -342,6 +349,17 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     static_assert(32 * (WN * 4 + 16) * NW <= NS * STAGE, "epilogue staging fits in the ring");
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
     GLDS_STAMP(6);
+#ifdef GLDS_TRACE
+    if (threadIdx.x == 0) {
+        if (nk < 2) gl_t[4] = gl_t[3];
+        if (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048)
+            for (int k = 0; k < 7; ++k) g_glds_trace[blockIdx.x * 8 + k] = gl_t[k];
+        unsigned long long* a = &g_glds_acc[(4 * (int)NTW + EPI) * 8];
+        for (int k = 0; k < 6; ++k) atomicAdd(a + k, gl_t[k + 1] - gl_t[k]);
+        atomicAdd(a + 6, 1ull);
+        atomicAdd(a + 7, (unsigned long long)nk);
+    }
+#endif
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
@@ -1257,6 +1275,11 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
 }
 
 #ifdef GLDS_TRACE
+extern "C" int uvl_debug_glds_acc(unsigned long long* dst, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(uvl::g_glds_acc), sizeof(unsigned long long) * 64);
+    if (e == hipSuccess && reset) { static unsigned long long z[64]; e = hipMemcpyToSymbol(HIP_SYMBOL(uvl::g_glds_acc), z, sizeof(z)); }
+    return (int)e;
+}
 extern "C" int uvl_debug_glds_trace(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(uvl::g_glds_trace), (size_t)n * 8 * sizeof(unsigned long long)); }
 #endif
 #ifdef GEMM_TRACE
