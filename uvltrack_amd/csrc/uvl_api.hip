@@ -95,6 +95,7 @@ struct uvl_model {
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
     int prefetch_w = 1;                          // uvl_debug_set("prefetch_w", v): 0 = no next-weight requests in the GEMM launches, 1 = in frames below 2000 visual rows, 2 = always (A/B)
+    int text_nt = 15;                            // uvl_debug_set("text_nt", mask): which text-branch GEMMs load their weights non-temporal (1 QKV, 2 attention output, 4 intermediate, 8 output)
     int rider_first = 1;                         // uvl_debug_set("rider_first", 0): the text rider's tiles of a one-sequence pair GEMM launch behind the visual tiles (the round-4 order; A/B)
     int rider_sk = 2;                            // uvl_debug_set("rider_sk", 1): the text rider's output GEMM in one K slice, in place (the round-4 form; A/B)
     int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
@@ -705,7 +706,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         else if (is_text && text_dr && p.Wp) { m->tune_text = m->tune; m->tune_text.gemm_cfg = 36; p.tune = &m->tune_text; }
         // BERT weights are read once per frame: up to four sequences (<= 3 M tiles share a weight tile through L2) they are loaded
         // non-temporal so that they do not displace the ViT weights from the Infinity Cache (+2-3 % at 2-4 sequences, -0.5 % from 8 on)
-        if (is_text && p.M <= 192) p.w_stream = 1;
+        if (is_text && p.M <= 192) {
+            const int bit = !strcmp(what, "gemm.bert_qkv") ? 1 : !strcmp(what, "gemm.bert_ao") ? 2 : !strcmp(what, "gemm.bert_i") ? 4 : 8;
+            p.w_stream = (m->text_nt & bit) ? 1 : 0;
+        }
         p.rider_first = m->rider_first;
         // algorithmic bytes: both operands once + what the epilogue moves (bf16 rows; f32 rows, read too by the in-place residual form, once per slab)
         const double out_b = (double)p.M * p.N * (p.epi == 1 ? 4.0 * (p.accumulate ? 2 : 1) * (p.splitk > 1 ? p.splitk : 1) : 2.0);
@@ -1168,6 +1172,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "prefetch_w")) { m->prefetch_w = value < 0 ? 0 : (value > 2 ? 2 : value); return UVL_OK; }
     if (!strcmp(key, "fold_modal")) { m->fold_modal = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "rider_first")) { m->rider_first = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "text_nt")) { m->text_nt = value & 15; return UVL_OK; }
     if (!strcmp(key, "rider_sk")) { m->rider_sk = value > 1 ? 2 : 1; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
