@@ -268,6 +268,9 @@ __device__ __forceinline__ void gemm_dr_body(const GemmParams& p, const int bx, 
     const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#ifdef DR_NOEPI          // timing probe (tools/probes/dr_epi_probe.py): the tile ends behind its K loop, nothing is stored
+    if (p.M > 0) { asm volatile("" :: "a"(accv[0]), "a"(accv[7])); return; }
+#endif
     if (EPI == EPI_BF16 && p.act == 1) gemm_epilogue_dr<EPI, 1>(p, accv, smem, sbias, m0, n0, lane_e, wave);
     else if (EPI == EPI_BF16 && p.act == 2) gemm_epilogue_dr<EPI, 2>(p, accv, smem, sbias, m0, n0, lane_e, wave);
     else gemm_epilogue_dr<EPI, 0>(p, accv, smem, sbias, m0, n0, lane_e, wave);
