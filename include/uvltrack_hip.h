@@ -235,7 +235,8 @@ int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
  * text branch of multi-sequence frames on the caller's stream.  "fuse_ln" (default 0): 1 launches LayerNorm and the GEMM that
  * consumes it as one kernel behind a grid barrier in one-sequence frames (96 -> 72 launches, same bits, measured slower).  "rider_sk" (default 2): 1 runs
  * the text rider of a many-sequence fc2 launch in one K slice, in place (the round-4 form).  "rider_first" (default 1): 0 puts the text rider's tiles of a
- * one-sequence pair GEMM launch behind the visual tiles. */
+ * one-sequence pair GEMM launch behind the visual tiles.  "text_nt" (default 15): which text-branch GEMMs of frames of up to four sequences load their
+ * weights non-temporal -- bit 0 QKV, 1 attention output, 2 intermediate, 3 output (0: none; two UVLTrack-B sequences lose 3.5 % with it, one is level). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
 /* Overrides of the launch heuristics, for tools and tests (not part of the product path).  There is NO process-global tuning
