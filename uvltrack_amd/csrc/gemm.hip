@@ -81,8 +81,10 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 __device__ unsigned long long g_glds_trace[2048 * 8];
 __device__ unsigned long long g_glds_acc[8 * 8];     // [4 * NTW + EPI][phase 0..5 ticks summed over every workgroup of every launch, 6: workgroups, 7: K tiles]: the loop inside a whole frame
 #define GLDS_STAMP(k) do { gl_t[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GLDS_TRACE_FLUSH() do { if (threadIdx.x == 0) { if (nk < 2) gl_t[4] = gl_t[3]; if (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048) for (int k = 0; k < 7; ++k) g_glds_trace[blockIdx.x * 8 + k] = gl_t[k]; unsigned long long* a = &g_glds_acc[(4 * (int)NTW + EPI) * 8]; for (int k = 0; k < 6; ++k) atomicAdd(a + k, gl_t[k + 1] - gl_t[k]); atomicAdd(a + 6, 1ull); atomicAdd(a + 7, (unsigned long long)nk); } } while (0)
 #else
 #define GLDS_STAMP(k) do { } while (0)
+#define GLDS_TRACE_FLUSH() do { } while (0)
 #endif
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0, int PRE = 0>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk_in, const int g, char* smem) {
@@ -347,19 +349,13 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     }
     GLDS_STAMP(5);
     static_assert(32 * (WN * 4 + 16) * NW <= NS * STAGE, "epilogue staging fits in the ring");
+    // (Round 5, measured and not kept: the split-K slabs of the one-sequence tile stored straight from the accumulator registers -- a lane's register quad is four
+    // consecutive columns = a 16-byte store, lanes l / l + 32 the halves of a 32-byte piece -- instead of through this staging: epilogue 0.96 -> 0.43-0.59 us per workgroup in
+    // isolation (tools/glds_trace.py), and the one-sequence frame 1422-1449 -> 1351-1377 frames/s, UVLTrack-L x 1 466 -> 456: four 32-byte write-through pieces per line
+    // instead of one whole line, and the text rider's K loop beside them went from 4.2 to 6.7 us.  Whole lines per store instruction matter to the OTHER workgroups.)
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
     GLDS_STAMP(6);
-#ifdef GLDS_TRACE
-    if (threadIdx.x == 0) {
-        if (nk < 2) gl_t[4] = gl_t[3];
-        if (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048)
-            for (int k = 0; k < 7; ++k) g_glds_trace[blockIdx.x * 8 + k] = gl_t[k];
-        unsigned long long* a = &g_glds_acc[(4 * (int)NTW + EPI) * 8];
-        for (int k = 0; k < 6; ++k) atomicAdd(a + k, gl_t[k + 1] - gl_t[k]);
-        atomicAdd(a + 6, 1ull);
-        atomicAdd(a + 7, (unsigned long long)nk);
-    }
-#endif
+    GLDS_TRACE_FLUSH();
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0>
