@@ -454,9 +454,13 @@ static int choose_splitk(int M, int N, int K, const uvl_tuning* tune) {
     if (forced > 0 && (K / 64) % forced == 0 && forced <= cap) return forced;
     const long tiles = (long)((M + 63) / 64) * (N / 64);
     const int nk = K / 64;
-    // measured (tools/gemm_bench.py): with ~100 tiles, K=768 likes 2 splits and K=3072 likes 4; nothing above ~250 tiles
+    // One more halving of K while the grid still fits one workgroup per CU -- or, from a grid that does, if the halves are still 24 K tiles long.  Rounds 1-4 split
+    // while tiles * sk < 256 (fc2 of one UVLTrack-B sequence: 108 tiles x 4 slices of 12 K tiles).  Round 5, interleaved tools/ab_tune.py sk_k4 / sk_k1 on one box
+    // (frames/s, this rule / the old one): fc2 of one UVLTrack-B sequence as 2 slices 1372-1386 / 1361-1372, UVLTrack-L x 1 448.5 / 444.6; proj of two UVLTrack-B
+    // sequences (216 tiles, 12 K tiles) unsplit 2042-2049 / 2019-2027, proj of one UVLTrack-L sequence (224 tiles, 16 K tiles) unsplit 459.8 / 455.6; fc2 of two
+    // UVLTrack-B sequences keeps its 2 slices (2018-2037 against 1958-1981 unsplit and 1941-1945 with 4).
     int sk = 1;
-    while (sk * 2 <= cap && tiles * sk < 256 && nk % (sk * 2) == 0 && nk / (sk * 2) >= 6) sk *= 2;
+    while (sk * 2 <= cap && nk % (sk * 2) == 0 && nk / (sk * 2) >= 6 && (tiles * sk * 2 <= 256 || (tiles * sk < 256 && nk / (sk * 2) >= 24))) sk *= 2;
     return sk;
 }
 
