@@ -258,8 +258,8 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   gemm_dr    the direct-to-register GEMM (cfg 36, gemm_dr.hip; needs the packed weight image): 0 = never, 1 = wherever it applies,
  *              default = frames of >= 2048 rows, bf16-type epilogues (bias / GELU / QKV scatter); the f32 read-modify-write epilogue stays with cfg 30 / 31
  *   res_pre    0 = the in-place f32 residual GEMMs of many-sequence frames load their residual rows in the epilogue (the round-4 form); default:
- *              up to K = 2048 the rows are requested inside the K loop, one 16-byte load per lane and phase over eight K tiles (gemm.hip::gemm_pipe128_body,
- *              PRE); 2 = at every K
+ *              up to K = 2048 -- and at every K where the launch is a single round of tiles -- the rows are requested inside the K loop, one 16-byte load per lane
+ *              and phase over eight K tiles (gemm.hip::gemm_pipe128_body, PRE); 2 = at every K
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
     int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_dr, res_pre;

@@ -110,8 +110,9 @@ def test_text_riders_of_a_many_sequence_frame_match_reference_fixture(forms):
         assert "gemm_dr_pair_kernel<2>" in by_site["gemm.qkv"] and "gemm_dr_pair_kernel<0>" in by_site["gemm.fc1"], by_site
     else:
         # (cfg 31's visual problem requests its residual rows inside the K loop from 12 K tiles on: the third template argument)
-        # (third template argument: cfg 31's visual problem requests its residual rows inside the K loop -- proj, K = D; fc2's K = 4 D stays with the epilogue's loads)
-        want = ("gemm_pipe_pair_kernel<128,1,1>", "gemm_pipe_pair_kernel<128,1,0>") if forms["gemm_cfg"] == 31 else ("gemm_pipe_pair_kernel<256,1,0>",) * 2
+        # (third template argument: cfg 31's visual problem requests its residual rows inside the K loop -- proj, K = D, always; fc2, K = 4 D, where the launch is a
+        # single round of tiles, which this frame's is)
+        want = ("gemm_pipe_pair_kernel<128,1,1>", "gemm_pipe_pair_kernel<128,1,1>") if forms["gemm_cfg"] == 31 else ("gemm_pipe_pair_kernel<256,1,0>",) * 2
         assert any(k.startswith(want[0]) for k in by_site["gemm.proj"]) and any(k.startswith(want[1]) for k in by_site["gemm.fc2"]), by_site
     if "attn_cfg" in forms:
         assert "attn_p64_rider_kernel" in by_site["attention"], by_site["attention"]

@@ -877,7 +877,11 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
 // a 60-us kernel and 28 MB of extra requests inside eight K tiles of a loop that already streams 2.5 TB/s cost more than that); res_pre = 2 forces it
 static bool pipe128_pre_ok(const GemmParams& p) {
     const int want = tune_get(p.tune, &uvl_tuning::res_pre, 1);
-    return p.epi == EPI_F32 && p.accumulate && p.splitk <= 1 && p.K >= 12 * 64 && want != 0 && (p.K <= 2048 || want == 2);
+    // ... and at every K where the launch is a single round of tiles (fc2 of 8 UVLTrack-L sequences: 220 tiles): in the FRAME its operand arrives cold, the loop is slower than
+    // in the probe above and the window pays -- same box, interleaved tools/ab_tune.py res_pre -1 2: 1333.7 -> 1338.2 and 1266.3 -> 1273.1 frames/s (+0.3 / +0.5 %) on two
+    // boxes; many-round launches stay with K <= 2048 (32 UVLTrack-L sequences 1489.1 -> 1488.2, 32 UVLTrack-B sequences 6691 -> 6679).
+    const long tiles = (long)((p.M + 127) / 128) * (p.N / 256);
+    return p.epi == EPI_F32 && p.accumulate && p.splitk <= 1 && p.K >= 12 * 64 && want != 0 && (p.K <= 2048 || want == 2 || tiles <= 256);
 }
 
 template <int EPI, bool MI16, bool PRE = false>
