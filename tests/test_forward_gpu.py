@@ -111,8 +111,8 @@ def test_text_riders_of_a_many_sequence_frame_match_reference_fixture(forms):
     else:
         # (cfg 31's visual problem requests its residual rows inside the K loop from 12 K tiles on: the third template argument)
         # (third template argument: cfg 31's visual problem requests its residual rows inside the K loop -- proj, K = D, always; fc2, K = 4 D, where the launch is a
-        # single round of tiles, which this frame's is)
-        want = ("gemm_pipe_pair_kernel<128,1,1>", "gemm_pipe_pair_kernel<128,1,1>") if forms["gemm_cfg"] == 31 else ("gemm_pipe_pair_kernel<256,1,0>",) * 2
+        # single round of tiles, which this frame's is: the same code under the symbol with a 2)
+        want = ("gemm_pipe_pair_kernel<128,1,1>", "gemm_pipe_pair_kernel<128,1,2>") if forms["gemm_cfg"] == 31 else ("gemm_pipe_pair_kernel<256,1,0>",) * 2
         assert any(k.startswith(want[0]) for k in by_site["gemm.proj"]) and any(k.startswith(want[1]) for k in by_site["gemm.fc2"]), by_site
     if "attn_cfg" in forms:
         assert "attn_p64_rider_kernel" in by_site["attention"], by_site["attention"]

@@ -875,26 +875,31 @@ __device__ __forceinline__ void gemm_pipe128_body(const GemmParams& p, const int
 // up to K = 2048 (tools/res_epilogue_probe.py, 8 UVLTrack-L sequences, us: proj K = 1024 bf16 store 19.4 / f32 store 22.2 / rows loaded in the
 // epilogue 25.9 / in the loop 24.6, with rotating operands 28.6 -> 26.4; fc2 K = 4096 53.2 / 57.7 / 59.8 / 61.7: there the epilogue's read is 2 us of
 // a 60-us kernel and 28 MB of extra requests inside eight K tiles of a loop that already streams 2.5 TB/s cost more than that); res_pre = 2 forces it
-static bool pipe128_pre_ok(const GemmParams& p) {
+// (returns the PRE template value of the kernel WRAPPERS: 1, or 2 for K > 2048 -- the same code under a second symbol, so that rocprofv3 and bench.py keep telling
+// proj from fc2)
+static int pipe128_pre_ok(const GemmParams& p) {
     const int want = tune_get(p.tune, &uvl_tuning::res_pre, 1);
     // ... and at every K where the launch is a single round of tiles (fc2 of 8 UVLTrack-L sequences: 220 tiles): in the FRAME its operand arrives cold, the loop is slower than
     // in the probe above and the window pays -- same box, interleaved tools/ab_tune.py res_pre -1 2: 1333.7 -> 1338.2 and 1266.3 -> 1273.1 frames/s (+0.3 / +0.5 %) on two
     // boxes; many-round launches stay with K <= 2048 (32 UVLTrack-L sequences 1489.1 -> 1488.2, 32 UVLTrack-B sequences 6691 -> 6679).
     const long tiles = (long)((p.M + 127) / 128) * (p.N / 256);
-    return p.epi == EPI_F32 && p.accumulate && p.splitk <= 1 && p.K >= 12 * 64 && want != 0 && (p.K <= 2048 || want == 2 || tiles <= 256);
+    const bool ok = p.epi == EPI_F32 && p.accumulate && p.splitk <= 1 && p.K >= 12 * 64 && want != 0 && (p.K <= 2048 || want == 2 || tiles <= 256);
+    return ok ? (p.K > 2048 ? 2 : 1) : 0;
 }
 
-template <int EPI, bool MI16, bool PRE = false>
+template <int EPI, bool MI16, int PRE = 0>
 __global__ __launch_bounds__(512) void gemm_pipe128_kernel(const GemmParams p) {
     kernarg_warm<sizeof(GemmParams)>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_pipe128_body<EPI, MI16, PRE>(p, blockIdx.x, smem);
+    gemm_pipe128_body<EPI, MI16, PRE != 0>(p, blockIdx.x, smem);
 }
 
-template <int EPI, bool MI16 = true, bool PRE = false>
+template <int EPI, bool MI16 = true, int PRE = 0>
 static hipError_t launch_pipe128(const GemmParams& p_in, hipStream_t s) {
     if constexpr (EPI == EPI_F32 && MI16 && !PRE) {
-        if (pipe128_pre_ok(p_in)) return launch_pipe128<EPI, MI16, true>(p_in, s);
+        const int pre = pipe128_pre_ok(p_in);
+        if (pre == 1) return launch_pipe128<EPI, MI16, 1>(p_in, s);
+        if (pre == 2) return launch_pipe128<EPI, MI16, 2>(p_in, s);
     }
     GemmParams p = p_in;
     if (p.N % 256 != 0 || p.K < 128 || p.splitk > 1 || p.conv_F != 0 || p.groups > 1) return hipErrorInvalidValue;
@@ -992,13 +997,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_pair_kernel(const Ge
 // The same for the eight-wave tiles of many-sequence frames (residual GEMMs: f32 read-modify-write epilogue): problem A on 256 x 256
 // (BMA = 256, cfg 30) or 128 x 256 tiles (cfg 31), the rider -- a few hundred text rows -- on 128 x 256 tiles behind them.  A's grid is a
 // single round of at most 256 workgroups on the shapes that take these kernels, and the rider's 9-30 tiles fit beside it.
-template <int BMA, int EPI, bool PRE = false>          // PRE: the visual problem's residual rows are requested inside its K loop (gemm_pipe128_body; BMA = 128 only)
+template <int BMA, int EPI, int PRE = 0>               // PRE: the visual problem's residual rows are requested inside its K loop (gemm_pipe128_body; BMA = 128 only; 2 = the K > 2048 symbol)
 __global__ __launch_bounds__(512) void gemm_pipe_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
     kernarg_warm<2 * sizeof(GemmParams) + 8>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= blocks_b) {              // the rider's workgroups first (see gemm_dr_pair_kernel)
         if constexpr (BMA == 256) gemm_pipe_body<256, EPI, 1, true>(pa, (int)blockIdx.x - blocks_b, smem);
-        else gemm_pipe128_body<EPI, true, PRE>(pa, (int)blockIdx.x - blocks_b, smem);
+        else gemm_pipe128_body<EPI, true, PRE != 0>(pa, (int)blockIdx.x - blocks_b, smem);
     } else {
         gemm_pipe128_body<EPI, true>(pb, blockIdx.x, smem);
     }
@@ -1011,10 +1016,12 @@ static bool pipe_ok_rider(const GemmParams& p) {
     return p.M > 0 && p.N % 256 == 0 && p.K % (64 * p.splitk) == 0 && p.K / p.splitk >= 128 && p.conv_F == 0 && p.groups <= 1 && p.epi == EPI_F32 && !p.accumulate;
 }
 
-template <int BMA, int EPI, bool PRE = false>
+template <int BMA, int EPI, int PRE = 0>
 static hipError_t launch_pipe_pair(const GemmParams& a_in, const GemmParams& b_in, hipStream_t s) {
     if constexpr (BMA == 128 && EPI == EPI_F32 && !PRE) {
-        if (pipe128_pre_ok(a_in)) return launch_pipe_pair<BMA, EPI, true>(a_in, b_in, s);
+        const int pre = pipe128_pre_ok(a_in);
+        if (pre == 1) return launch_pipe_pair<BMA, EPI, 1>(a_in, b_in, s);
+        if (pre == 2) return launch_pipe_pair<BMA, EPI, 2>(a_in, b_in, s);
     }
     GemmParams a = a_in, b = b_in;
     if (!pipe_ok(a) || !pipe_ok_rider(b)) return hipErrorInvalidValue;
