@@ -236,7 +236,9 @@ int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
  * consumes it as one kernel behind a grid barrier in one-sequence frames (96 -> 72 launches, same bits, measured slower).  "rider_sk" (default 2): 1 runs
  * the text rider of a many-sequence fc2 launch in one K slice, in place (the round-4 form).  "rider_first" (default 1): 0 puts the text rider's tiles of a
  * one-sequence pair GEMM launch behind the visual tiles.  "text_nt" (default 15): which text-branch GEMMs of frames of up to four sequences load their
- * weights non-temporal -- bit 0 QKV, 1 attention output, 2 intermediate, 3 output (0: none; two UVLTrack-B sequences lose 3.5 % with it, one is level). */
+ * weights non-temporal -- bit 0 QKV, 1 attention output, 2 intermediate, 3 output (0: none; two UVLTrack-B sequences lose 3.5 % with it, one is level).
+ * "bf16_store" (default 3): which bf16 activations of frames of >= 2048 rows are stored write-through -- bit 0 the fc1 output, 1 the q / k rows of QKV, 2 LayerNorm's
+ * rows (0: plain stores, the round-4 form: 8 UVLTrack-L sequences lose 2.2 %). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
 /* Overrides of the launch heuristics, for tools and tests (not part of the product path).  There is NO process-global tuning

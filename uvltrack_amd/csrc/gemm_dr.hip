@@ -155,13 +155,18 @@ __device__ __forceinline__ void gemm_epilogue_dr(const GemmParams& p, f32x16 (&a
                 const u32x4 v = *reinterpret_cast<const u32x4*>(cw + r * RS + c16 * 16);
                 if (row < p.M) {
                     if (EPI == EPI_BF16) {
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col) = v;
+                        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col);
+                        if (p.c_store == 1) __builtin_nontemporal_store(v, dst);
+                        else if (p.c_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                        else *dst = v;
                     } else {
                         int b, rem;
                         rowmap_at(rowmap_of(m0 + i * 32, p.rpb, p.fd_rpb), m0 + i * 32, r, b, rem);
                         const int which = col >= p.D ? 1 : 0, cc = col - which * p.D;
                         const int hh = cc >> 6, dd = cc & 63;
-                        *reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd) = v;
+                        u32x4* dst = reinterpret_cast<u32x4*>((which ? p.k : p.q) + (((size_t)b * p.H + hh) * p.Npad + rem) * 64 + dd);
+                        if (p.c_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                        else *dst = v;
                     }
                 }
             }

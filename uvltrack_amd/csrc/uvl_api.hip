@@ -95,6 +95,7 @@ struct uvl_model {
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
     int prefetch_w = 1;                          // uvl_debug_set("prefetch_w", v): 0 = no next-weight requests in the GEMM launches, 1 = in frames below 2000 visual rows, 2 = always (A/B)
+    int bf16_store = 3;                          // uvl_debug_set("bf16_store", mask): which bf16 activations of many-sequence frames are stored write-through (sc1), see run_gemm
     int text_nt = 15;                            // uvl_debug_set("text_nt", mask): which text-branch GEMMs load their weights non-temporal (1 QKV, 2 attention output, 4 intermediate, 8 output)
     int rider_first = 1;                         // uvl_debug_set("rider_first", 0): the text rider's tiles of a one-sequence pair GEMM launch behind the visual tiles (the round-4 order; A/B)
     int rider_sk = 2;                            // uvl_debug_set("rider_sk", 1): the text rider's output GEMM in one K slice, in place (the round-4 form; A/B)
@@ -715,6 +716,13 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             p.w_stream = (m->text_nt & bit) ? 1 : 0;
         }
         p.rider_first = m->rider_first;
+        // The bf16 rows gemm_dr_kernel stores (fc1: 57 MB per launch at 8 UVLTrack-L sequences; the q / k rows of QKV) go out write-through (sc1): nothing of them is left
+        // dirty in the L2s for the end-of-kernel write-back, and the next kernel reads them from memory anyway (another XCD's L2 at best).  Same box, interleaved
+        // tools/ab_tune.py debug.bf16_store 0 1 / 1 3 / 0 3: fc1 alone 1272 -> 1298 frames/s (+2.1 %; non-temporal instead: +1.9 %), the q / k rows +0.2 % more; 8 / 32
+        // UVLTrack-B sequences +1.0 / +0.95 %, 4 UVLTrack-L sequences +1.0 %, 32 level.  Not for: LayerNorm's bf16 rows (bit 2: 0), the attention output (generator
+        // option osc1: -1.6 %), V^T (2-byte scattered stores).
+        if (!is_text && p.epi == 0 && (m->bf16_store & 1)) p.c_store = 2;
+        if (!is_text && p.epi == 2 && (m->bf16_store & 2)) p.c_store = 2;
         // algorithmic bytes: both operands once + what the epilogue moves (bf16 rows; f32 rows, read too by the in-place residual form, once per slab)
         const double out_b = (double)p.M * p.N * (p.epi == 1 ? 4.0 * (p.accumulate ? 2 : 1) * (p.splitk > 1 ? p.splitk : 1) : 2.0);
         const double fl = 2.0 * p.M * p.N * p.K, by = 2.0 * ((double)p.M * p.K + (double)p.N * p.K) + out_b;
@@ -947,7 +955,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 p.split = nv;
             }
             if (reuse && i == m->nf) { p.x_alt = w.TxtSnap + (size_t)(m->nf - 1) * B * T * D; p.x_alt_rows = T; }   // text rows kept from the last full frame
-            p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
+            p.gamma = vw.ln1g; p.beta = vw.ln1b; p.eps = 1e-6f; p.y_bf16 = w.Xn; p.y_wt = (m->bf16_store & 4) ? 1 : 0;
             if (fused_ct >= 0 && direct_ct) {
                 // the logits of layer `fused_ct` ride on THIS launch: it leaves the rows the job reads untouched (no slabs, no pre-add on visual rows;
                 // the text token of a pre-fusion layer comes from the text branch's snapshot), so no copy of the layer's output is kept
@@ -982,7 +990,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             LnParams p;
             p.x = w.X; p.M = M; p.D = D; p.rpb = N; p.xbs = nj; p.xro = 0;
             consume(p, pend_v);
-            p.gamma = vw.ln2g; p.beta = vw.ln2b; p.eps = 1e-6f; p.y_bf16 = w.Xn;
+            p.gamma = vw.ln2g; p.beta = vw.ln2b; p.eps = 1e-6f; p.y_bf16 = w.Xn; p.y_wt = (m->bf16_store & 4) ? 1 : 0;
             if (fused_ct >= 0) {                 // logits of layer `fused_ct` ride on this launch (rows come from the snapshot)
                 if (!skip) L.cur = PART_V2;
                 p.ct_x = w.XSnap; p.ct_nz = nz; p.ct_nv = nv; p.ct_nx = nx; p.ct_T = T; p.ct_skip_text = skip;
@@ -1177,6 +1185,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "fold_modal")) { m->fold_modal = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "rider_first")) { m->rider_first = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "text_nt")) { m->text_nt = value & 15; return UVL_OK; }
+    if (!strcmp(key, "bf16_store")) { m->bf16_store = value; return UVL_OK; }
     if (!strcmp(key, "rider_sk")) { m->rider_sk = value > 1 ? 2 : 1; return UVL_OK; }
     if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
