@@ -233,7 +233,8 @@ int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
  * residual GEMMs run in place; logits equal within one f32 rounding).  "prefetch_w" (default 1): next-weight requests in the
  * small-tile GEMM launches -- 0 never, 1 below 2000 visual rows for models whose weights exceed the memory-side cache, 2 always.  "fork_text" (default 1): 0 runs the
  * text branch of multi-sequence frames on the caller's stream.  "fuse_ln" (default 0): 1 launches LayerNorm and the GEMM that
- * consumes it as one kernel behind a grid barrier in one-sequence frames (96 -> 72 launches, same bits, measured slower).  "rider_sk" (default 2): 1 runs
+ * consumes it as one kernel behind a grid barrier in one-sequence frames (96 -> 72 launches, same bits, measured slower).  "fold_ln" (default 1): 0 keeps the
+ * LayerNorm launches and split-K slabs of rounds 1-5 in one-sequence frames (1: the LayerNorm-free schedule, see uvl_linear_fin below).  "rider_sk" (default 2): 1 runs
  * the text rider of a many-sequence fc2 launch in one K slice, in place (the round-4 form).  "rider_first" (default 1): 0 puts the text rider's tiles of a
  * one-sequence pair GEMM launch behind the visual tiles.  "text_nt" (default 15): which text-branch GEMMs of frames of up to four sequences load their
  * weights non-temporal -- bit 0 QKV, 1 attention output, 2 intermediate, 3 output (0: none; two UVLTrack-B sequences lose 3.5 % with it, one is level).
@@ -262,9 +263,11 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *   res_pre    0 = the in-place f32 residual GEMMs of many-sequence frames load their residual rows in the epilogue (the round-4 form); default:
  *              up to K = 2048 -- and at every K where the launch is a single round of tiles -- the rows are requested inside the K loop, one 16-byte load per lane
  *              and phase over eight K tiles (gemm.hip::gemm_pipe128_body, PRE); 2 = at every K
+ *   fin_w      tile of the finishing residual GEMMs of LayerNorm-free frames (gemm_fin.hip): 0 = 64 x 64 on two wave groups, 1 = 64 x 32 on four; default: 64 x 32 while
+ *              its tiles are at most one workgroup per CU
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
-    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_dr, res_pre;
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_dr, res_pre, fin_w;
 } uvl_tuning;
 void uvl_tuning_init(uvl_tuning* t);
 int uvl_tune_set(uvl_model_t* m, const char* key, int value);
@@ -325,6 +328,26 @@ int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_ld, const i
  * d_x [M,D] f32 -> d_y_bf16 [M,D] bf16 (may be NULL) and d_y_f32 [M,D] f32 (may be NULL, may alias d_x). */
 int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
                   void* d_y_bf16, float* d_y_f32, int M, int D, void* stream);
+
+/* ---- the LayerNorm-free forms one- / two-sequence frames run (uvl_debug_set "fold_ln", default 1) ---------------------------------------------
+ * A `norm -> Linear` pair (block.py:30-31 -> attn.qkv / mlp.fc1; BertLayerNorm -> query/key/value / intermediate.dense, bert_backbone.py:335-339,366,376-380)
+ * runs as ONE GEMM on the UN-normalised rows rounded to bf16:  y = rstd (a~ W'^T - mean colsum(W')) + b'  with W' = bf16(W gamma), b' = b + W beta, mean / rstd
+ * of the f32 rows a, a~ = bf16(a).  The rows' statistics travel as per-32-column partials  stats[(row * K/32 + j) * 2 + {0,1}] = (sum, sum of squares) of
+ * the f32 values of columns [32 j, 32 j + 32) (before their rounding to bf16), written by whoever writes the bf16 row.
+ * uvl_fold_ln_linear: d_w [N,K] f32, d_bias [N] (or NULL), gamma / beta [K] -> d_w_folded bf16 [N,K], d_bias_folded [N], d_colsum [N] (row sums of the ROUNDED W').
+ * uvl_linear_fin:  x (+)= a W^T + b finished inside the launch (block.py:29-32 residual adds; no split-K slabs): one eight-wave workgroup per 64 x 64 tile, its two
+ *   wave groups on the two K halves.  d_a [M,K] bf16, d_w [N,K] bf16, d_x [M,N] f32 in/out (accumulate != 0 adds), d_xn [M,N] bf16 = bf16(x) and d_stats
+ *   [M, N/32, 2] = its partials (both optional).  d_res_stats != NULL: post-LayerNorm residual (bert_backbone.py:335-339) -- d_x holds PRE-norm rows u, d_res_stats
+ *   the partials of u, and the residual added is LayerNorm(u; gamma, beta, res_eps); d_res_copy (optional) receives those normalised rows.  N % 64 == 0, K % 128 == 0.
+ * uvl_linear_lnf / uvl_qkv_project_lnf: the consumer GEMMs (epilogues of uvl_linear / uvl_qkv_project), d_a = bf16 rows + d_stats.  K % 128 == 0, K <= 1024. */
+int uvl_fold_ln_linear(const float* d_w, const float* d_bias, const float* d_gamma, const float* d_beta, void* d_w_folded, float* d_bias_folded, float* d_colsum,
+                       int N, int K, void* stream);
+int uvl_linear_fin(const void* d_a, const void* d_w, const float* d_bias, float* d_x, void* d_xn, float* d_stats, int M, int N, int K, int accumulate,
+                   const float* d_res_stats, const float* d_res_gamma, const float* d_res_beta, float res_eps, float* d_res_copy, const uvl_tuning* tune, void* stream);
+int uvl_linear_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps, void* d_y,
+                   int M, int N, int K, int act, void* stream);
+int uvl_qkv_project_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps,
+                        void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream);
 
 /* f32 -> bf16 (round to nearest even) helper for tests. */
 int uvl_f32_to_bf16(const float* d_in, void* d_out, size_t n, void* stream);

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "ln_body.h"
 #include "gemm_epi.h"
+#include "fold.h"
 
 namespace uvl {
 
@@ -86,7 +87,10 @@ __device__ unsigned long long g_glds_acc[8 * 8];     // [4 * NTW + EPI][phase 0.
 #define GLDS_STAMP(k) do { } while (0)
 #define GLDS_TRACE_FLUSH() do { } while (0)
 #endif
-template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0, int PRE = 0>
+// LNF (round 6, LayerNorm-free one-sequence frames): A holds the UN-normalised rows rounded to bf16, W / bias are the LayerNorm-folded weight (W gamma, b + W beta),
+// p.st_in the rows' partial statistics, p.colsum the folded weight's row sums: the epilogue turns the product into  rstd (acc - mean colsum) + bias  = LayerNorm(a~) W'^T + b'
+// (fold.h).  The partials of a lane's row (the transposed tile: lane = row) are requested with the bias, before the first LDS-DMA; nothing is added to the K loop.
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS, bool CONV, bool NTW = false, int BK = 64, int PROD = 0, int PRE = 0, bool LNF = false>
 __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx, const int sk_in, const int g, char* smem) {
 #ifdef GLDS_TRACE
     unsigned long long gl_t[7] = {};      // (scalar registers: the stamps cost the loop nothing but the s_memrealtime itself; everything is written out behind the last one)
@@ -249,6 +253,20 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     GLDS_STAMP(1);
     f32x4 bias_v[TN][4];
     gemm_bias_preload<TN>(p, n0 + wn * WN, lane, g, sk, bias_v);     // older than every DMA: retired by the first tile wait
+    f32x4 lnf_cs[LNF ? 4 : 1], lnf_st[LNF ? 8 : 1];
+    if constexpr (LNF) {
+        static_assert(TM * TN == 1 && !CONV && !PROD, "LayerNorm-folded form: the 64 x 64 tile");
+        const float* cp = p.colsum + n0 + wn * WN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lnf_cs[q] = *reinterpret_cast<const f32x4*>(cp + 8 * q + 4 * (lane >> 5));
+        // lane l owns row l & 31 of the wave's block; its half (l >> 5) of the row's np partial pairs = np floats = np / 4 loads of 16 bytes (np = K / 32 <= 32)
+        const int np = p.K >> 5, n4 = np >> 2;
+        int row = m0 + wm * WM + (lane & 31);
+        row = row < p.M ? row : p.M - 1;
+        const float* sp = p.st_in + ((size_t)row * np + (size_t)(lane >> 5) * (np >> 1)) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lnf_st[i] = *reinterpret_cast<const f32x4*>(i < n4 ? sp + 4 * i : reinterpret_cast<const float*>(g_zero_page));
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -353,6 +371,23 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     // consecutive columns = a 16-byte store, lanes l / l + 32 the halves of a 32-byte piece -- instead of through this staging: epilogue 0.96 -> 0.43-0.59 us per workgroup in
     // isolation (tools/glds_trace.py), and the one-sequence frame 1422-1449 -> 1351-1377 frames/s, UVLTrack-L x 1 466 -> 456: four 32-byte write-through pieces per line
     // instead of one whole line, and the text rider's K loop beside them went from 4.2 to 6.7 us.  Whole lines per store instruction matter to the OTHER workgroups.)
+    if constexpr (LNF) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += lnf_st[i][0] + lnf_st[i][2]; s2 += lnf_st[i][1] + lnf_st[i][3]; }
+        s1 = half_sum(s1);
+        s2 = half_sum(s2);
+        float mean, rstd;
+        st_finish(s1, s2, p.K, p.ln_eps, mean, rstd);
+        const float nrm = -rstd * mean;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0][4 * q + e] = rstd * acc[0][0][4 * q + e] + (nrm * lnf_cs[q][e] + bias_v[0][q][e]);
+                bias_v[0][q][e] = 0.f;
+            }
+    }
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
     GLDS_STAMP(6);
     GLDS_TRACE_FLUSH();
@@ -1279,6 +1314,86 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
         case EPI_QKV * 8 + 5: return launch_pair_epi<EPI_QKV, 5>(a, b, s);
     }
     return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm-folded consumer GEMMs of the LayerNorm-free one- / two-sequence frame (round 6): QKV and fc1 (and the text branch's QKV / intermediate as the
+// rider) on the 64 x 64 tiles, A = the un-normalised bf16 rows a finishing GEMM (gemm_fin.hip), the patch embedding or the prologue left, with their partial
+// statistics.  The launch may also carry the contrastive logits of the previous layer as its FIRST workgroups (one wave per search row, fold.h::ct_job_block): the
+// job used to ride on LayerNorm launches that no longer exist, its rows are complete when this launch starts and nothing of this launch depends on it.
+// Block order: [logits job | rider tiles | visual tiles]; the first two counts are multiples of 8, so every tile keeps its workgroup -> XCD relation.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_lnf_kernel(const GemmParams p, const CtJob ct, const int blocks_ct) {
+    kernarg_warm<sizeof(GemmParams) + sizeof(CtJob) + 8 + 64>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < blocks_ct) { ct_job_block(ct, (int)blockIdx.x, g_zero_row); return; }
+    const uint32_t pfs = prefetch_issue<256>(p.pf, p.pf_bytes, blockIdx.x, gridDim.x);
+    gemm_glds_body<64, 64, 2, 2, EPI, 4, false, false, 64, 0, 0, true>(p, (int)blockIdx.x - blocks_ct, 0, 0, smem);
+    prefetch_retire(pfs);
+}
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_lnf_pair_kernel(const GemmParams pa, const GemmParams pb, const CtJob ct, const int blocks_ct, const int blocks_b) {
+    kernarg_warm<2 * sizeof(GemmParams) + sizeof(CtJob) + 8 + 64>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = (int)blockIdx.x - blocks_ct;
+    if (bid < 0) { ct_job_block(ct, (int)blockIdx.x, g_zero_row); return; }
+    const uint32_t pfs = prefetch_issue<256>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
+    if (bid < blocks_b) gemm_glds_body<64, 64, 2, 2, EPI, 4, false, true, 64, 0, 0, true>(pb, bid, 0, 0, smem);       // the rider first: its weight tiles come from HBM (non-temporal)
+    else gemm_glds_body<64, 64, 2, 2, EPI, 4, false, false, 64, 0, 0, true>(pa, bid - blocks_b, 0, 0, smem);
+    prefetch_retire(pfs);
+}
+
+static bool lnf_ok(const GemmParams& p) {
+    return p.M > 0 && p.conv_F == 0 && p.groups <= 1 && p.N % 64 == 0 && p.K % 128 == 0 && p.K <= 1024 && p.splitk <= 1 && p.st_in && p.colsum &&
+           (p.epi == EPI_BF16 || p.epi == EPI_QKV) && (p.M + 63) / 64 < 64;
+}
+template <int EPI>
+static hipError_t launch_lnf_epi(const GemmParams& a_in, const GemmParams* b_in, const CtJob* ct, hipStream_t s) {
+    auto prep = [](GemmParams& p) {
+        const int MT = (p.M + 63) / 64;
+        p.group_m = MT;                       // N-major runs per XCD (few M tiles: the M tiles of a weight panel share an L2)
+        gemm_derive(p, 64, 64);
+        return 8 * ((MT * (p.N / 64) + 7) / 8);
+    };
+    GemmParams a = a_in;
+    const int ba = prep(a);
+    CtJob job = ct ? *ct : CtJob();
+    const int bc = ct ? 8 * ((((job.B * job.nx + 3) / 4) + 7) / 8) : 0;
+    constexpr size_t lds = 4 * (size_t)(64 + 64) * 128;
+    if (!b_in) {
+        auto kern = gemm_lnf_kernel<EPI>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        static char name[40];
+        if (!name[0]) snprintf(name, sizeof(name), "gemm_lnf_kernel<%d>", EPI);
+        g_last_kernel = name;
+        hipLaunchKernelGGL(kern, dim3(bc + ba), dim3(256), lds, s, a, job, bc);
+        return hipGetLastError();
+    }
+    GemmParams b = *b_in;
+    const int bb = prep(b);
+    auto kern = gemm_lnf_pair_kernel<EPI>;
+    static bool attr_done2 = false;
+    if (!attr_done2) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done2 = true;
+    }
+    static char name2[40];
+    if (!name2[0]) snprintf(name2, sizeof(name2), "gemm_lnf_pair_kernel<%d>", EPI);
+    g_last_kernel = name2;
+    hipLaunchKernelGGL(kern, dim3(bc + bb + ba), dim3(256), lds, s, a, b, job, bc, bb);
+    return hipGetLastError();
+}
+hipError_t launch_gemm_lnf(const GemmParams& a, const GemmParams* b, const CtJob* ct, hipStream_t s) {
+    if (!lnf_ok(a) || (b && (!lnf_ok(*b) || b->epi != a.epi))) return hipErrorInvalidValue;
+    if (ct && (!ct->x || !ct->logits || !ct->flag || !ct->logit_scale || ct->D % 4 != 0 || ct->D > 1024 || ct->nx <= 0)) return hipErrorInvalidValue;
+    return a.epi == EPI_QKV ? launch_lnf_epi<EPI_QKV>(a, b, ct, s) : launch_lnf_epi<EPI_BF16>(a, b, ct, s);
 }
 
 #ifdef GLDS_TRACE

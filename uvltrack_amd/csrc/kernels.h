@@ -46,7 +46,49 @@ struct GemmParams {
     int ks_log2 = 0, ks_ntp = 0;                 // K-slice map (group_m < 0): log2(8 / splitk), column tiles per XCD share
     int kspan = 0;                               // K / splitk
     int rider_first = 1;                         // pair launches of one-sequence frames (gemm_glds_pair_kernel): this problem, as the RIDER, takes the first block indices
+    // ---- LayerNorm-free frames (round 6; gemm_fin.hip and the LNF forms of gemm.hip) -------------------------------------------------------------------
+    // Row statistics travel as PARTIALS: st[(row * np + j) * 2 + {0, 1}] = (sum, sum of squares) of the f32 values of columns [32 j, 32 j + 32) of
+    // a row (taken before the row is rounded to bf16), np = D / 32.  Whoever writes a bf16 row that a LayerNorm-folded GEMM will read leaves them; that GEMM adds them up (mean / rstd per row).
+    // Producer side (launch_gemm_fin: x (+)= A W^T + b finished in the launch, no slabs):
+    bf16_t* xn = nullptr; int xn_bs = 0, xn_ro = 0;   // bf16 copy of the finished rows: GEMM row (b, t) -> xn row b * xn_bs + xn_ro + t, [., N]
+    float* st_out = nullptr;                     // partials of those rows, indexed like xn
+    // post-LN residual (bert_backbone.py:335-339,376-380): the residual operand is LayerNorm(row of C) -- C holds the PRE-norm rows u; res_st = partials of
+    // u indexed like xn, res_g / res_b / res_eps the LayerNorm; res_copy (optional, [M, N] compact) receives the normalised rows (the text snapshot)
+    const float* res_st = nullptr; const float *res_g = nullptr, *res_b = nullptr; float res_eps = 0.f; float* res_copy = nullptr;
+    // Consumer side (launch_gemm_lnf: y = act(LayerNorm(a) W^T + b) on A = bf16(a) UN-normalised): W = bf16(W gamma), bias = b + W beta, colsum[n] = sum_k W[n, k]
+    // (of the rounded weight), st_in = partials of A's rows (compact index m): y = rstd (acc - mean colsum) + bias
+    const float* st_in = nullptr; const float* colsum = nullptr; float ln_eps = 0.f;
 };
+// The contrastive logits of one layer (extractor.py:85-93) as extra workgroups of a GEMM launch (LayerNorm-free frames: the job has no LayerNorm launch to ride on):
+// one wave per search row; the rows are complete in x when the hosting launch starts.
+struct CtJob {
+    const float* x = nullptr; int xbs = 0, D = 0, B = 0;       // residual stream [B, xbs, D]
+    int nz = 0, nv = 0, nx = 0, skip_text = 0;
+    const float* txt = nullptr; int txt_bs = 0;                // text token rows: sample b at txt + b * txt_bs * D (null: row nv of x)
+    const float *txt_g = nullptr, *txt_b = nullptr; float txt_eps = 0.f;   // non-null: the text row is PRE-norm, the job normalises it (bert_backbone.py:376-380)
+    const float* txt_st = nullptr; int txt_st_bs = 0;          // ... with the partial statistics of its bf16 copy: sample b's row at txt_st + b * txt_st_bs * (D/32) * 2
+    const float *sub_vis = nullptr, *sub_txt = nullptr;        // the next fusion layer's modal embedding, already added to x by the fc2 epilogue: taken off again
+    const int64_t* flag = nullptr; const float* logit_scale = nullptr; float* logits = nullptr; int slot = 0, ncont = 0;
+};
+// Text rows entering the first fusion layer of a LayerNorm-free frame (extractor.py:62-63, mae_vit.py:196): x_text = LayerNorm(u) (the last BERT layer's
+// output LayerNorm, or rows kept from an earlier frame) -> snapshot, + modal_embed[1] -> residual stream, bf16 copy + partials for the first joint QKV GEMM.
+struct TextJoinParams {
+    float* x = nullptr; int xbs = 0, xro = 0;                  // residual stream rows (b * xbs + xro + t): in (pre-norm u) and out
+    const float* alt = nullptr;                                // non-null: already-normalised rows [B*T, D] to use instead (text reuse); no LayerNorm
+    const float *gamma = nullptr, *beta = nullptr; float eps = 1e-12f;
+    float* snap = nullptr;                                     // optional [B*T, D]: the normalised rows
+    const float* add = nullptr;                                // optional [D] vector added after the snapshot (modal_embed[1])
+    bf16_t* xn = nullptr; int xn_bs = 0, xn_ro = 0; float* st = nullptr;
+    int B = 0, T = 0, D = 0;
+};
+hipError_t launch_text_join(const TextJoinParams& p, hipStream_t s);
+// W' = bf16(W gamma), b' = b + W beta, colsum = row sums of W' (one nn.Linear whose input is a LayerNorm: block.py:30-31 -> :42 / mlp.fc1; bert_backbone.py)
+hipError_t launch_fold_ln_linear(const float* W, const float* bias, const float* gamma, const float* beta, bf16_t* Wf, float* bf, float* colsum, int N, int K, hipStream_t s);
+// x (+)= A W^T + b finished inside the launch: one eight-wave workgroup per 64 x 64 tile, the two K halves on its two wave groups (gemm_fin.hip); b = optional rider
+hipError_t launch_gemm_fin(const GemmParams& a, const GemmParams* b, hipStream_t s);
+bool gemm_fin_ok(const GemmParams& p);
+// LayerNorm-folded consumer GEMM on the 64 x 64 tiles (EPI_BF16 / EPI_QKV); b = optional rider (plain or folded: b->st_in), ct = optional logits job
+hipError_t launch_gemm_lnf(const GemmParams& a, const GemmParams* b, const CtJob* ct, hipStream_t s);
 // fills the derived fields for a tile grid of BM x BN tiles (group_m already chosen)
 static inline void gemm_derive(GemmParams& p, int BM, int BN) {
     const int MT = (p.M + BM - 1) / BM, NT = p.N / BN;
@@ -135,6 +177,11 @@ struct PrologueParams {
     const float *z = nullptr, *ximg = nullptr; bf16_t* patches = nullptr; int Hz = 0, Hx = 0;
     int skip_text = 0, setup_what = 3;           // as launch_setup; ids == nullptr: no embedding workgroups
     int n_setup = 0, n_embed = 0;                // filled by the launcher
+    // LayerNorm-free frames (fold.h): the [cls] row also as bf16 + partials (row b * cls_xn_bs of cls_xn / cls_st: the first QKV GEMM reads it un-normalised);
+    // embed_raw: the BERT embedding row is left PRE-norm (f32 row, bf16 copy in tn, partials in embed_st [B*T, D/32, 2]) -- its LayerNorm (emb_g / emb_b, eps 1e-12)
+    // is folded into the first QKV GEMM and applied to the residual by the first attention.output GEMM
+    bf16_t* cls_xn = nullptr; int cls_xn_bs = 0; float* cls_st = nullptr;
+    int embed_raw = 0; float* embed_st = nullptr;
 };
 hipError_t launch_prologue(const PrologueParams& p, hipStream_t s);
 

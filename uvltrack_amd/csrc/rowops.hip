@@ -6,6 +6,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "ln_body.h"
+#include "fold.h"
 
 namespace uvl {
 
@@ -174,7 +175,7 @@ __device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids,
                                                 const float* __restrict__ pos, const float* __restrict__ type0,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                 float* __restrict__ x, int xbs, int xro, bf16_t* __restrict__ y,
-                                                int B, int T, int D, int vocab, int bx) {
+                                                int B, int T, int D, int vocab, int bx, float* __restrict__ raw_st = nullptr) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = bx * 4 + wave;
     if (m >= B * T) return;
@@ -208,6 +209,25 @@ __device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids,
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    float* xr = x + ((size_t)b * xbs + xro + t) * D;
+    if (raw_st) {
+        // LayerNorm-free frame: the row stays pre-norm (f32 row, bf16 copy, per-32-column partials: lanes 8 j .. 8 j + 7 of chunk i hold block j + 8 i)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            const uint32_t lo = pack_bf16x2(v[i].x, v[i].y), hi = pack_bf16x2(v[i].z, v[i].w);
+            float s1, s2;
+            st_of4(v[i].x, v[i].y, v[i].z, v[i].w, s1, s2);
+            s1 = oct_sum(s1);
+            s2 = oct_sum(s2);
+            if (ok[i]) {
+                *reinterpret_cast<float4*>(xr + c) = v[i];
+                *reinterpret_cast<uint2*>(y + (size_t)m * D + c) = uint2{lo, hi};
+                if ((lane & 7) == 0) *reinterpret_cast<float2*>(raw_st + ((size_t)m * (D >> 5) + (c >> 5)) * 2) = float2{s1, s2};
+            }
+        }
+        return;
+    }
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
@@ -218,7 +238,6 @@ __device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids,
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-12f);
-    float* xr = x + ((size_t)b * xbs + xro + t) * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -266,7 +285,8 @@ hipError_t launch_bert_embed(const int64_t* ids, const float* word, const float*
 __device__ __forceinline__ void setup_body(const uint8_t* __restrict__ tmask, const int64_t* __restrict__ flag,
                                            const float* __restrict__ cls_token, float* __restrict__ x,
                                            float* __restrict__ key_add, float* __restrict__ bert_add,
-                                           int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what, int b) {
+                                           int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what, int b,
+                                           bf16_t* __restrict__ cls_xn = nullptr, int cls_xn_bs = 0, float* __restrict__ cls_st = nullptr) {
     const int fl = (int)sload_u32(flag + b);                          // low word of the int64 flag
     // the text mask is read unconditionally at a clamped index (no branch around the load, no wait per key group)
     const uint8_t* tm = skip_text ? reinterpret_cast<const uint8_t*>(g_zero_row) : tmask + (size_t)b * T;
@@ -288,6 +308,20 @@ __device__ __forceinline__ void setup_body(const uint8_t* __restrict__ tmask, co
         key_add[(size_t)b * npad + i] = a;
     }
     for (int c = threadIdx.x; c < D; c += 256) x[(size_t)b * nj * D + c] = cls_token[c];
+    if (cls_xn) {                          // LayerNorm-free frame: the row as the first QKV GEMM reads it (bf16, un-normalised) + its partials (fold.h); D <= 1024
+        const int c = threadIdx.x * 4;
+        const bool ok = c < D;
+        const float4 v = ok ? *reinterpret_cast<const float4*>(cls_token + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
+        float s1, s2;
+        st_of4(v.x, v.y, v.z, v.w, s1, s2);
+        s1 = oct_sum(s1);
+        s2 = oct_sum(s2);
+        if (ok) {
+            *reinterpret_cast<uint2*>(cls_xn + (size_t)b * cls_xn_bs * D + c) = uint2{lo, hi};
+            if ((threadIdx.x & 7) == 0) *reinterpret_cast<float2*>(cls_st + ((size_t)b * cls_xn_bs * (D >> 5) + (c >> 5)) * 2) = float2{s1, s2};
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void setup_kernel(const uint8_t* __restrict__ tmask, const int64_t* __restrict__ flag,
@@ -304,9 +338,9 @@ __global__ __launch_bounds__(256) void prologue_kernel(const PrologueParams p) {
     kernarg_warm<sizeof(PrologueParams)>();
     const int bx = blockIdx.x;
     if (bx < p.n_setup) {
-        setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, p.skip_text, p.setup_what, bx);
+        setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, p.skip_text, p.setup_what, bx, p.cls_xn, p.cls_xn_bs, p.cls_st);
     } else if (bx < p.n_setup + p.n_embed) {
-        bert_embed_body<NV>(p.ids, p.word, p.pos, p.type0, p.emb_g, p.emb_b, p.x, p.nj, p.nv, p.tn, p.B, p.T, p.D, p.vocab, bx - p.n_setup);
+        bert_embed_body<NV>(p.ids, p.word, p.pos, p.type0, p.emb_g, p.emb_b, p.x, p.nj, p.nv, p.tn, p.B, p.T, p.D, p.vocab, bx - p.n_setup, p.embed_raw ? p.embed_st : nullptr);
     } else {
         im2row_body(p.z, p.ximg, p.patches, p.B, p.Hz, p.Hx, bx - p.n_setup - p.n_embed);
     }
@@ -983,6 +1017,102 @@ hipError_t launch_fold_conv_bn(const float* w, const float* b, const float* bn_w
     size_t blocks = ((size_t)Co * 9 * Ci + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(fold_conv_bn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, b, bn_w, bn_b, bn_mean, bn_var, w_out, b_out, Co, Ci);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm-free frames (round 6, fold.h).
+// fold_ln_linear: one nn.Linear that reads a LayerNorm (block.py:30-31 -> attn.qkv / mlp.fc1; bert_backbone.py:376-380 -> the next layer's query/key/value,
+// :335-339 -> intermediate.dense; the embedding LayerNorm :260-274 -> layer 0's query/key/value) with the LayerNorm's affine part folded in:
+//   W'[n, k] = bf16(W[n, k] gamma[k]),  b'[n] = b[n] + sum_k W[n, k] beta[k]  (f32 weights),  colsum[n] = sum_k W'[n, k]  (of the ROUNDED values: the
+//   consumer's  acc - mean colsum  then cancels the row mean exactly).  One wave per output row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_ln_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ Wf, float* __restrict__ bf, float* __restrict__ colsum, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float cs = 0.f, bs = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (size_t)n * K + k);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + k), be = *reinterpret_cast<const float4*>(beta + k);
+        const uint32_t lo = pack_bf16x2(w.x * g.x, w.y * g.y), hi = pack_bf16x2(w.z * g.z, w.w * g.w);
+        *reinterpret_cast<uint2*>(Wf + (size_t)n * K + k) = uint2{lo, hi};
+        cs += (__uint_as_float(lo << 16) + __uint_as_float(lo & 0xffff0000u)) + (__uint_as_float(hi << 16) + __uint_as_float(hi & 0xffff0000u));
+        bs += (w.x * be.x + w.y * be.y) + (w.z * be.z + w.w * be.w);
+    }
+    cs = wave_sum(cs);
+    bs = wave_sum(bs);
+    if (lane == 0) { colsum[n] = cs; bf[n] = (bias ? bias[n] : 0.f) + bs; }
+}
+hipError_t launch_fold_ln_linear(const float* W, const float* bias, const float* gamma, const float* beta, bf16_t* Wf, float* bf, float* colsum, int N, int K, hipStream_t s) {
+    if (!W || !gamma || !beta || !Wf || !bf || !colsum || N <= 0 || K <= 0 || K % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_ln_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, bias, gamma, beta, Wf, bf, colsum, N, K);
+    return hipGetLastError();
+}
+
+// Text rows entering the first fusion layer (kernels.h::TextJoinParams): one wave per row, the row in registers (D <= 1024).
+__global__ __launch_bounds__(256) void text_join_kernel(const TextJoinParams p) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= p.B * p.T) return;
+    const int b = m / p.T, t = m - b * p.T, D = p.D;
+    float* xr = p.x + ((size_t)b * p.xbs + p.xro + t) * D;
+    const float* src = p.alt ? p.alt + (size_t)m * D : xr;
+    const float* ad = p.add ? p.add : g_zero_row;
+    float4 v[4], g[4], be[4], a4[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = (lane + 64 * i) * 4;
+        ok[i] = c0 < D;
+        const int c = ok[i] ? c0 : 0;
+        v[i] = *reinterpret_cast<const float4*>(src + c);
+        g[i] = *reinterpret_cast<const float4*>(p.gamma + c);
+        be[i] = *reinterpret_cast<const float4*>(p.beta + c);
+        a4[i] = *reinterpret_cast<const float4*>(ad + c);
+    }
+    if (!p.alt) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = sel4(ok[i], v[i]); sum += v[i].x + v[i].y + v[i].z + v[i].w; }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ok[i]) {
+                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                sq += dx * dx + dy * dy + dz * dz + dw * dw;
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + p.eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i].x = (v[i].x - mean) * rstd * g[i].x + be[i].x; v[i].y = (v[i].y - mean) * rstd * g[i].y + be[i].y;
+            v[i].z = (v[i].z - mean) * rstd * g[i].z + be[i].z; v[i].w = (v[i].w - mean) * rstd * g[i].w + be[i].w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (ok[i] && p.snap) *reinterpret_cast<float4*>(p.snap + (size_t)m * D + c) = v[i];
+        if (p.add) { v[i].x += a4[i].x; v[i].y += a4[i].y; v[i].z += a4[i].z; v[i].w += a4[i].w; }
+        const uint32_t lo = pack_bf16x2(v[i].x, v[i].y), hi = pack_bf16x2(v[i].z, v[i].w);
+        float s1, s2;
+        st_of4(v[i].x, v[i].y, v[i].z, v[i].w, s1, s2);
+        s1 = oct_sum(s1);
+        s2 = oct_sum(s2);
+        if (ok[i]) {
+            *reinterpret_cast<float4*>(xr + c) = v[i];
+            const size_t nrow = (size_t)b * p.xn_bs + p.xn_ro + t;
+            if (p.xn) *reinterpret_cast<uint2*>(p.xn + nrow * D + c) = uint2{lo, hi};
+            if (p.st && (lane & 7) == 0) *reinterpret_cast<float2*>(p.st + (nrow * (D >> 5) + (c >> 5)) * 2) = float2{s1, s2};
+        }
+    }
+}
+hipError_t launch_text_join(const TextJoinParams& p, hipStream_t s) {
+    if (!p.x || !p.gamma || !p.beta || p.D % 32 != 0 || p.D > 1024 || p.B <= 0 || p.T <= 0) return hipErrorInvalidValue;
+    g_last_kernel = "text_join_kernel";
+    hipLaunchKernelGGL(text_join_kernel, dim3((p.B * p.T + 3) / 4), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

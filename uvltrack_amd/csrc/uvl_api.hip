@@ -45,12 +45,17 @@ struct VitBlockW {
     const float *ln1g, *ln1b, *ln2g, *ln2b, *bqkv, *bproj, *bfc1, *bfc2;
     bf16_t *wqkv, *wproj, *wfc1, *wfc2;
     bf16_t *pqkv, *pproj, *pfc1, *pfc2;          // the same weights in the fragment-native layout of gemm_dr_kernel (null: frames of this handle never reach 2048 rows)
+    // LayerNorm-free frames (fold.h): attn.qkv with norm1 and mlp.fc1 with norm2 folded in -- bf16(W gamma), b + W beta, row sums of the folded weight
+    bf16_t *fqkv, *ffc1; float *fbqkv, *fbfc1, *csqkv, *csfc1;
 };
 struct BertLayerW {
     const float *bao, *bi, *bo, *ln1g, *ln1b, *ln2g, *ln2b;
     float* bqkv;
     bf16_t *wqkv, *wao, *wi, *wo;
     bf16_t *pqkv, *pao, *pi, *po;                // fragment-native images for gemm_dr_kernel (null: see VitBlockW)
+    // LayerNorm-free frames: query/key/value with the LayerNorm in front of them folded in (layer 0: the embedding LayerNorm; layer l: output.LayerNorm of l - 1),
+    // intermediate.dense with this layer's attention.output.LayerNorm
+    bf16_t *fqkv, *fi; float *fbqkv, *fbi, *csqkv, *csi;
 };
 struct ConvLayerW {
     bf16_t* w;      // [4][Cout][9*Cin]
@@ -100,6 +105,7 @@ struct uvl_model {
     int rider_first = 1;                         // uvl_debug_set("rider_first", 0): the text rider's tiles of a one-sequence pair GEMM launch behind the visual tiles (the round-4 order; A/B)
     int rider_sk = 2;                            // uvl_debug_set("rider_sk", 1): the text rider's output GEMM in one K slice, in place (the round-4 form; A/B)
     int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
+    int fold_ln = 1;                             // uvl_debug_set("fold_ln", 0): one-sequence frames keep their LayerNorm launches and split-K slabs (the round-1..5 schedule; A/B)
     int fuse_ln = 0;                             // uvl_debug_set("fuse_ln", 1): one-sequence frames launch LayerNorm + its consumer GEMM as ONE kernel behind a
                                                  // grid barrier (96 -> 72 launches; measured 3-4 % SLOWER than the two launches, so off: profiles/r03_summary.md)
     unsigned* gbar = nullptr;                    // 4 KB of counters for the fused launches' grid barrier (monotonic: never reset)
@@ -125,7 +131,7 @@ extern "C" void uvl_tuning_init(uvl_tuning* t) {
     for (size_t i = 0; i < sizeof(uvl_tuning) / sizeof(int32_t); ++i) f[i] = -1;
 }
 extern "C" const char* uvl_last_error(void) { return g_err; }
-extern "C" int uvl_version(void) { return 2; }
+extern "C" int uvl_version(void) { return 3; }
 #ifndef UVL_BUILD_TOOLCHAIN
 #define UVL_BUILD_TOOLCHAIN "unknown"
 #endif
@@ -325,6 +331,17 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
         w.wproj = P.bf16(b + "attn.proj.weight", D * D); w.bproj = P.f32(b + "attn.proj.bias", D);
         w.wfc1 = P.bf16(b + "mlp.fc1.weight", Fn * D); w.bfc1 = P.f32(b + "mlp.fc1.bias", Fn);
         w.wfc2 = P.bf16(b + "mlp.fc2.weight", D * Fn); w.bfc2 = P.f32(b + "mlp.fc2.bias", D);
+        {   // LayerNorm-folded images for the LayerNorm-free one- / two-sequence frame (from the f32 weights, before they are dropped)
+            w.fqkv = P.alloc<bf16_t>(3 * D * D); w.fbqkv = P.alloc<float>(3 * D); w.csqkv = P.alloc<float>(3 * D);
+            w.ffc1 = P.alloc<bf16_t>(Fn * D); w.fbfc1 = P.alloc<float>(Fn); w.csfc1 = P.alloc<float>(Fn);
+            const float* wq = P.f32(b + "attn.qkv.weight", 3 * D * D);
+            const float* w1 = P.f32(b + "mlp.fc1.weight", Fn * D);
+            if (wq && w1 && w.fqkv && w.fbqkv && w.csqkv && w.ffc1 && w.fbfc1 && w.csfc1 && w.ln1g && w.ln1b && w.ln2g && w.ln2b && w.bqkv && w.bfc1) {
+                if (launch_fold_ln_linear(wq, w.bqkv, w.ln1g, w.ln1b, w.fqkv, w.fbqkv, w.csqkv, 3 * (int)D, (int)D, s) != hipSuccess ||
+                    launch_fold_ln_linear(w1, w.bfc1, w.ln2g, w.ln2b, w.ffc1, w.fbfc1, w.csfc1, (int)Fn, (int)D, s) != hipSuccess)
+                    if (!P.err) P.err = fail(UVL_EHIP, "LayerNorm fold launch failed");
+            }
+        }
         if ((long)m->cfg.max_batch * m->nj >= 2048) {          // many-sequence frames: second image of the weights for the direct-to-register GEMM
             auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
                 bf16_t* dst = src ? P.alloc<bf16_t>((size_t)N_ * K_) : nullptr;
@@ -358,6 +375,22 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
         w.wi = P.bf16(b + "intermediate.dense.weight", Fn * D); w.bi = P.f32(b + "intermediate.dense.bias", Fn);
         w.wo = P.bf16(b + "output.dense.weight", D * Fn); w.bo = P.f32(b + "output.dense.bias", D);
         w.ln2g = P.f32(b + "output.LayerNorm.weight", D); w.ln2b = P.f32(b + "output.LayerNorm.bias", D);
+        {   // LayerNorm-folded images (see VitBlockW): query/key/value read the LayerNorm in FRONT of this layer, intermediate.dense this layer's attention.output.LayerNorm
+            w.fqkv = P.alloc<bf16_t>(3 * D * D); w.fbqkv = P.alloc<float>(3 * D); w.csqkv = P.alloc<float>(3 * D);
+            w.fi = P.alloc<bf16_t>(Fn * D); w.fbi = P.alloc<float>(Fn); w.csi = P.alloc<float>(Fn);
+            const float* pg = i == 0 ? m->emb_g : m->bert[i - 1].ln2g;
+            const float* pb = i == 0 ? m->emb_b : m->bert[i - 1].ln2b;
+            bool okf = w.fqkv && w.fbqkv && w.csqkv && w.fi && w.fbi && w.csi && pg && pb && w.ln1g && w.ln1b && w.bi;
+            for (int k = 0; k < 3 && okf; ++k) {
+                const float* wk = P.f32(b + "attention.self." + nm[k] + ".weight", D * D);
+                const float* bk = P.f32(b + "attention.self." + nm[k] + ".bias", D);
+                if (!wk || !bk) { okf = false; break; }
+                if (launch_fold_ln_linear(wk, bk, pg, pb, w.fqkv + (size_t)k * D * D, w.fbqkv + (size_t)k * D, w.csqkv + (size_t)k * D, (int)D, (int)D, s) != hipSuccess && !P.err)
+                    P.err = fail(UVL_EHIP, "LayerNorm fold launch failed");
+            }
+            const float* wi32 = okf ? P.f32(b + "intermediate.dense.weight", Fn * D) : nullptr;
+            if (wi32 && launch_fold_ln_linear(wi32, w.bi, w.ln1g, w.ln1b, w.fi, w.fbi, w.csi, (int)Fn, (int)D, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "LayerNorm fold launch failed");
+        }
         if ((long)m->cfg.max_batch * m->nj >= 2048) {          // the text branch of many-sequence frames runs on gemm_dr_kernel too (see run_gemm)
             auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
                 bf16_t* dst = src ? P.alloc<bf16_t>((size_t)N_ * K_) : nullptr;
@@ -472,6 +505,7 @@ struct Workspace {
     bf16_t *Tn, *Tq, *Tk, *Tvt, *To, *Th;
     float *key_add, *bert_add, *cont, *bbox, *Part, *PartT, *TxtSnap, *ConvPart, *XSnap;
     bf16_t *G0, *G1, *G2, *G3, *G4;
+    float *St, *StT0, *StT1;            // LayerNorm-free frames: partial row statistics (fold.h) of the visual / joint rows and, ping-pong, of the text rows
     size_t total;
 };
 static Workspace carve(const uvl_model* m, int B, char* base) {
@@ -507,6 +541,9 @@ static Workspace carve(const uvl_model* m, int B, char* base) {
     w.G2 = (bf16_t*)take(B * S * 2 * C * 2);
     w.G3 = (bf16_t*)take(B * S * C * 2);
     w.G4 = (bf16_t*)take(B * S * (C / 2) * 2);
+    w.St = (float*)take(B * nj * (D / 32) * 2 * 4);
+    w.StT0 = (float*)take(B * T * (D / 32) * 2 * 4);
+    w.StT1 = (float*)take(B * T * (D / 32) * 2 * 4);
     w.total = off;
     return w;
 }
@@ -665,6 +702,14 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // the LayerNorm rows in ln_pair_kernel; in-place residual epilogue for the text rows (no split-K slabs).
     const bool paired = text_rides(m, B, skip, reuse);
     const bool paired_many = paired && B > 1;
+    // LayerNorm-free frame (round 6; fold.h, gemm_fin.hip): one or two sequences whose residual GEMMs are at most one eight-wave workgroup per CU.  No LayerNorm launch,
+    // no split-K slabs: the residual GEMMs finish x in the launch and leave bf16 rows + partial statistics, QKV / fc1 (and the text riders' query/key/value and
+    // intermediate GEMMs) run on the un-normalised rows with the LayerNorm folded into their weights, the logits ride on the next QKV launch, and ONE small launch
+    // normalises the text rows where they join the visual rows.  96 -> 72 launches for one UVLTrack-B sequence.  Needs the single-stream frame (riders, or no text
+    // branch), the 'cls' text token, a fusion tail (0 < nf < depth); tests cut below the first fusion layer on the LayerNorm-kernel schedule.
+    const bool fold = m->fold_ln && B == 1 && (paired || skip || reuse) && !m->cfg.txt_token_mean && m->fuse_contrast && m->nf > 0 && m->nf < m->depth &&
+                      m->D % 128 == 0 && (m->debug_stop_layer < 0 || m->debug_stop_layer >= m->nf) && !m->fuse_ln &&
+                      (long)((B * m->nj + 63) / 64) * (m->D / 64) <= 256 && m->tune.gemm_cfg < 0 && m->tune.text_cfg < 0 && !m->vit.empty() && m->vit[0].fqkv;
     // The text branch of a many-sequence frame (B x T rows: 320 at 8 sequences) overlaps the visual layers on the second stream, and what it
     // costs the frame is the CU time of its workgroups: as 64 x 64 tiles (240 workgroups of ~6 us per GEMM at ~15 % MFMA efficiency) that was
     // 8 % of the UVLTrack-L x 8 frame (1241 against 1351 frames/s without the branch).  On gemm_dr_kernel's 128 x 256 tiles the same GEMM is
@@ -814,6 +859,10 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         pro.ids = paired ? in->d_text_ids : nullptr; pro.skip_text = skip; pro.setup_what = skip ? 1 : 3; pro.word = m->word; pro.pos = m->pos; pro.type0 = m->type0; pro.emb_g = m->emb_g; pro.emb_b = m->emb_b;
         pro.tn = w.Tn; pro.vocab = m->cfg.vocab;
         pro.z = in->d_template; pro.ximg = in->d_search; pro.patches = w.P; pro.Hz = m->cfg.template_size; pro.Hx = m->cfg.search_size;
+        if (fold) {         // the [cls] row as layer 0's QKV GEMM reads it; the embedding rows stay pre-norm (their LayerNorm is folded into the first query/key/value GEMM)
+            pro.cls_xn = w.Xn; pro.cls_xn_bs = nv; pro.cls_st = w.St;
+            pro.embed_raw = paired ? 1 : 0; pro.embed_st = w.StT0;
+        }
         L.run(s, "prologue", 0, 0, tramp<PrologueParams, launch_prologue>, &pro);
     } else
     L.run(s, "setup", 0, 0, setup_fn, &sc);
@@ -910,7 +959,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         L.cur = saved_part;
     };
     if (last_bert < 0 && fork && hipEventRecord(m->ev_join, sa) != hipSuccess) return fail(UVL_EHIP, "join record failed");
-    if (paired) {                                // parameters of the whole text branch, in order; launched as riders below
+    if (paired && !fold) {                       // parameters of the whole text branch, in order; launched as riders below
         for (int i = 0; i <= last_bert; ++i) { rider_layer = i; text_layer(i); }
         if (text_err) return text_err;
     }
@@ -922,7 +971,13 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         p.A = w.P; p.lda = 768; p.W = m->w_patch; p.ldw = 768; p.bias = m->b_patch;
         p.M = B * (nz + nx); p.N = D; p.K = 768; p.epi = 1; p.C = w.X; p.ldc = D;
         p.rpb = nz + nx; p.obs = nj; p.oro = 1; p.addtab = m->pos_tab; p.tune = &m->tune;
-        if (pfw && m->depth > 0) { p.pf = m->vit[0].wqkv; p.pf_bytes = (uint32_t)((size_t)3 * D * D * 2); }
+        if (pfw && m->depth > 0) { p.pf = fold ? m->vit[0].fqkv : m->vit[0].wqkv; p.pf_bytes = (uint32_t)((size_t)3 * D * D * 2); }
+        if (fold) {         // finished in the launch, + the bf16 rows and partial statistics layer 0's QKV GEMM reads (its norm1 is folded into that GEMM)
+            p.xn = w.Xn; p.xn_bs = nv; p.xn_ro = 1; p.st_out = w.St;
+            L.wb_next = 2.0 * (double)p.N * p.K;
+            L.run(s, "gemm.patch", 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K) + 6.0 * p.M * p.N,
+                  [](void* c, hipStream_t q) { return launch_gemm_fin(*(const GemmParams*)c, nullptr, q); }, &p);
+        } else
         RUN_GEMM(L, s, p, "gemm.patch");
     }
     int cont_slot = 0;
@@ -931,6 +986,166 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     bool direct_ct = false;                      // ... or the next layer's LayerNorm-1 (many-sequence frames, see below)
     bool modal_folded = false;                   // the last fc2 epilogue has added the next (fusion) layer's modal embedding
     Pending pend_v;                              // split-K slabs not yet folded into the residual stream (visual/joint rows)
+    if (fold) {
+        // ---- the LayerNorm-free layer walk: per ViT block QKV (folded norm1) -> attention -> proj (finishes x) -> fc1 (folded norm2) -> fc2 (finishes x), five
+        //      launches; BERT layer i's five GEMM / attention kernels ride in ViT block i's launches of the same kind (block.py:29-32, bert_backbone.py:390-394)
+        struct FinCtx { GemmParams a, b; bool has_b; };
+        struct LnfCtx { GemmParams a, b; CtJob ct; bool has_b, has_ct; };
+        auto cost = [](const GemmParams& p, double& fl, double& by, double& wb) {
+            fl += 2.0 * p.M * p.N * p.K;
+            wb += 2.0 * (double)p.N * p.K;
+            by += 2.0 * ((double)p.M * p.K + (double)p.N * p.K) + (double)p.M * p.N * (p.epi == 1 ? (p.accumulate ? 8.0 : 4.0) + (p.xn ? 2.0 : 0.0) : 2.0);
+        };
+        auto run_fin = [&](const char* what, GemmParams& a, GemmParams* b) {
+            a.tune = &m->tune;
+            if (b) b->tune = &m->tune;
+            FinCtx c{a, b ? *b : a, b != nullptr};
+            double fl = 0, by = 0, wb = 0;
+            cost(a, fl, by, wb);
+            if (b) cost(*b, fl, by, wb);
+            L.wb_next = wb;
+            L.run(s, what, fl, by, [](void* cc, hipStream_t q) { auto* x = (FinCtx*)cc; return launch_gemm_fin(x->a, x->has_b ? &x->b : nullptr, q); }, &c);
+        };
+        auto run_lnf = [&](const char* what, GemmParams& a, GemmParams* b, const CtJob* ct) {
+            a.tune = &m->tune;
+            LnfCtx c{a, b ? *b : a, ct ? *ct : CtJob(), b != nullptr, ct != nullptr};
+            double fl = 0, by = 0, wb = 0;
+            cost(a, fl, by, wb);
+            if (b) cost(*b, fl, by, wb);
+            L.wb_next = wb;
+            L.run(s, what, fl, by, [](void* cc, hipStream_t q) { auto* x = (LnfCtx*)cc; return launch_gemm_lnf(x->a, x->has_b ? &x->b : nullptr, x->has_ct ? &x->ct : nullptr, q); }, &c);
+        };
+        const int tl = paired ? last_bert : -1;              // BERT layers [0, tl] ride on ViT blocks [0, tl]
+        const int Mt = B * T;
+        // partial statistics of the text rows' current bf16 copy: StT0 after the embedding and after every output GEMM (pre-norm u2), StT1 after attention.output (u1)
+        CtJob ctj;
+        bool have_ct = false;
+        for (int i = 0; i < m->depth; ++i) {
+            const bool joint = i >= m->nf;
+            const int N = (joint && !skip) ? nj : nv;
+            const int M = B * N;
+            const VitBlockW& vw = m->vit[i];
+            const bool last = (i == m->depth - 1) || (m->debug_stop_layer == i);
+            const bool rider = i <= tl;
+            const bool next_joint = !last && i + 1 >= m->nf;
+            const int Nn = (next_joint && !skip) ? nj : nv;      // rows per sample of the NEXT block: the row pitch of the bf16 copy fc2 leaves for its QKV GEMM
+            if (joint && i == m->nf && !skip) {
+                // the text rows join (extractor.py:62-63): output.LayerNorm of the last BERT layer (or the rows a previous frame kept), snapshot for the logits / for
+                // frames that reuse the branch, + modal_embed[1] (mae_vit.py:196), bf16 copy + partials beside the visual rows'
+                L.cur = PART_V2;
+                TextJoinParams tj;
+                tj.x = w.X; tj.xbs = nj; tj.xro = nv; tj.B = B; tj.T = T; tj.D = D;
+                tj.alt = reuse ? w.TxtSnap + (size_t)(m->nf - 1) * Mt * D : nullptr;
+                tj.gamma = m->bert[m->nf - 1].ln2g; tj.beta = m->bert[m->nf - 1].ln2b; tj.eps = 1e-12f;
+                tj.snap = reuse ? nullptr : w.TxtSnap + (size_t)(m->nf - 1) * Mt * D;
+                tj.add = m->modal + D; tj.xn = w.Xn; tj.xn_bs = nj; tj.xn_ro = nv; tj.st = w.St;
+                L.run(s, "layernorm", 0, (double)Mt * D * 14, tramp<TextJoinParams, launch_text_join>, &tj);
+            }
+            const BertLayerW* bw = rider ? &m->bert[i] : nullptr;
+            {   // attn.qkv on norm1(x) (block.py:30,49): norm1 folded into the weight, the rows' statistics from the partials
+                GemmParams p;
+                p.A = w.Xn; p.lda = D; p.W = vw.fqkv; p.ldw = D; p.bias = vw.fbqkv; p.colsum = vw.csqkv; p.st_in = w.St; p.ln_eps = 1e-6f; p.M = M; p.N = 3 * D; p.K = D;
+                p.epi = 2; p.rpb = N; p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.H = H; p.Npad = npad; p.D = D; p.q_scale = UVL_QSCALE;
+                if (pfw) { p.pf = vw.wproj; p.pf_bytes = (uint32_t)((size_t)D * D * 2); }
+                GemmParams t;
+                if (rider) {
+                    t.A = w.Tn; t.lda = D; t.W = bw->fqkv; t.ldw = D; t.bias = bw->fbqkv; t.colsum = bw->csqkv; t.st_in = w.StT0; t.ln_eps = 1e-12f; t.M = Mt; t.N = 3 * D; t.K = D;
+                    t.epi = 2; t.rpb = T; t.q = w.Tq; t.k = w.Tk; t.vt = w.Tvt; t.H = H; t.Npad = 64; t.D = D; t.q_scale = UVL_QSCALE;
+                }
+                run_lnf("gemm.qkv", p, rider ? &t : nullptr, have_ct ? &ctj : nullptr);
+                have_ct = false;
+            }
+            {
+                AttnParams p;
+                p.q = w.Q; p.k = w.K; p.vt = w.Vt; p.key_add = w.key_add; p.key_add_stride = npad; p.o = w.O; p.B = B; p.H = H; p.N = N; p.Npad = npad; p.q_prescaled = 1; p.tune = &m->tune;
+                const double fl = 4.0 * N * (double)N * D * B, by = 8.0 * M * D;
+                if (rider) {
+                    AttnPair ap;
+                    ap.a = p;
+                    ap.b.q = w.Tq; ap.b.k = w.Tk; ap.b.vt = w.Tvt; ap.b.key_add = w.bert_add; ap.b.key_add_stride = 64; ap.b.o = w.To; ap.b.B = B; ap.b.H = H; ap.b.N = T; ap.b.Npad = 64;
+                    ap.b.q_prescaled = 1; ap.b.tune = &m->tune;
+                    L.run(s, "attention", fl + 4.0 * T * (double)T * D * B, by + 8.0 * Mt * D, [](void* c, hipStream_t q) { auto* x = (AttnPair*)c; return launch_attention_pair(x->a, x->b, q); }, &ap);
+                } else {
+                    L.run(s, "attention", fl, by, tramp<AttnParams, launch_attention>, &p);
+                }
+            }
+            {   // x += attn.proj(o) (block.py:29-30,44), finished in the launch; rider: u1 = LayerNorm_prev(u) + attention.output.dense(o) (bert_backbone.py:335-339)
+                GemmParams p;
+                p.A = w.O; p.lda = D; p.W = vw.wproj; p.ldw = D; p.bias = vw.bproj; p.M = M; p.N = D; p.K = D; p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1;
+                p.rpb = N; p.obs = nj; p.oro = 0; p.xn = w.Xn; p.xn_bs = N; p.xn_ro = 0; p.st_out = w.St;
+                if (pfw) { p.pf = vw.ffc1; p.pf_bytes = (uint32_t)((size_t)Fn * D * 2); }
+                GemmParams t;
+                if (rider) {
+                    t.A = w.To; t.lda = D; t.W = bw->wao; t.ldw = D; t.bias = bw->bao; t.M = Mt; t.N = D; t.K = D; t.epi = 1; t.C = w.X; t.ldc = D; t.accumulate = 1;
+                    t.rpb = T; t.obs = nj; t.oro = nv; t.xn = w.Tn; t.xn_bs = T; t.xn_ro = 0; t.st_out = w.StT1;
+                    // the residual is the LayerNorm in front of this layer applied to the stored pre-norm rows: the embedding LayerNorm (layer 0) or output.LayerNorm of layer i - 1
+                    t.res_st = w.StT0; t.res_g = i == 0 ? m->emb_g : m->bert[i - 1].ln2g; t.res_b = i == 0 ? m->emb_b : m->bert[i - 1].ln2b; t.res_eps = 1e-12f;
+                    if (i > 0 && is_cont_layer(i - 1) && out->d_logits) t.res_copy = w.TxtSnap + (size_t)(i - 1) * Mt * D;      // layer i - 1's text rows, for frames that reuse the branch
+                }
+                run_fin("gemm.proj", p, rider ? &t : nullptr);
+            }
+            {   // mlp.fc1 on norm2(x) + GELU (block.py:31, backbones/utils.py:58-60); rider: intermediate.dense on attention.output.LayerNorm(u1) (bert_backbone.py:366)
+                GemmParams p;
+                p.A = w.Xn; p.lda = D; p.W = vw.ffc1; p.ldw = D; p.bias = vw.fbfc1; p.colsum = vw.csfc1; p.st_in = w.St; p.ln_eps = 1e-6f; p.M = M; p.N = Fn; p.K = D;
+                p.epi = 0; p.C = w.Hb; p.ldc = Fn; p.act = 1;
+                if (pfw) { p.pf = vw.wfc2; p.pf_bytes = (uint32_t)((size_t)Fn * D * 2); }
+                GemmParams t;
+                if (rider) {
+                    t.A = w.Tn; t.lda = D; t.W = bw->fi; t.ldw = D; t.bias = bw->fbi; t.colsum = bw->csi; t.st_in = w.StT1; t.ln_eps = 1e-12f; t.M = Mt; t.N = Fn; t.K = D;
+                    t.epi = 0; t.C = w.Th; t.ldc = Fn; t.act = 1;
+                }
+                run_lnf("gemm.fc1", p, rider ? &t : nullptr, nullptr);
+            }
+            {   // x += mlp.fc2(h) (block.py:31-32), finished in the launch, + the NEXT fusion layer's modal embedding (mae_vit.py:196: a permanent change of the stream);
+                // rider: u2 = attention.output.LayerNorm(u1) + output.dense(h) (bert_backbone.py:376-380)
+                GemmParams p;
+                p.A = w.Hb; p.lda = Fn; p.W = vw.wfc2; p.ldw = Fn; p.bias = vw.bfc2; p.M = M; p.N = D; p.K = Fn; p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1;
+                p.rpb = N; p.obs = nj; p.oro = 0;
+                if (!last) { p.xn = w.Xn; p.xn_bs = Nn; p.xn_ro = 0; p.st_out = w.St; }
+                if (next_joint) { p.addtab = m->modal; p.addtab_split = nv; }
+                if (pfw) {
+                    p.pf = (i + 1 < m->depth && !last) ? (const void*)m->vit[i + 1].fqkv : (const void*)m->conv[0].w;
+                    p.pf_bytes = (uint32_t)((i + 1 < m->depth && !last) ? (size_t)3 * D * D * 2 : (size_t)4 * m->conv[0].cout * 9 * m->conv[0].cin * 2);
+                }
+                GemmParams t;
+                if (rider) {
+                    t.A = w.Th; t.lda = Fn; t.W = bw->wo; t.ldw = Fn; t.bias = bw->bo; t.M = Mt; t.N = D; t.K = Fn; t.epi = 1; t.C = w.X; t.ldc = D; t.accumulate = 1;
+                    t.rpb = T; t.obs = nj; t.oro = nv; t.xn = w.Tn; t.xn_bs = T; t.xn_ro = 0; t.st_out = w.StT0;
+                    t.res_st = w.StT1; t.res_g = bw->ln1g; t.res_b = bw->ln1b; t.res_eps = 1e-12f;
+                }
+                run_fin("gemm.fc2", p, rider ? &t : nullptr);
+            }
+            // ---- contrastive logits of this layer (extractor.py:64-65,85-93): on the next block's QKV launch, or in the head prologue for the last layer ----
+            if (is_cont_layer(i)) {
+                if (out->d_logits && last && joint && i == m->depth - 1 && m->debug_stop_layer < 0) {
+                    head_ct_slot = cont_slot;
+                } else if (out->d_logits && !last) {
+                    ctj = CtJob();
+                    ctj.x = w.X; ctj.xbs = nj; ctj.D = D; ctj.B = B; ctj.nz = nz; ctj.nv = nv; ctj.nx = nx; ctj.skip_text = skip;
+                    if (next_joint) { ctj.sub_vis = m->modal; ctj.sub_txt = m->modal + D; }     // fc2 above has added them; this layer's output is without
+                    if (!skip && !joint) {
+                        if (i == m->nf - 1 || reuse) { ctj.txt = w.TxtSnap + (size_t)i * Mt * D; ctj.txt_bs = T; }       // normalised rows: the text join's / an earlier frame's snapshot
+                        else {                 // the pre-norm rows the output GEMM has just left, normalised by the job (the same bits the snapshot will hold)
+                            ctj.txt = w.X + (size_t)nv * D; ctj.txt_bs = nj; ctj.txt_g = m->bert[i].ln2g; ctj.txt_b = m->bert[i].ln2b; ctj.txt_eps = 1e-12f;
+                            ctj.txt_st = w.StT0; ctj.txt_st_bs = T;
+                        }
+                    }
+                    ctj.flag = in->d_flag; ctj.logit_scale = m->logit_scale_bb; ctj.logits = out->d_logits; ctj.slot = cont_slot; ctj.ncont = m->cfg.n_cont;
+                    have_ct = true;
+                } else if (out->d_logits) {        // a frame cut at this (fusion) layer: x is complete and carries no later layer's embedding -- the stand-alone kernel
+                    ContrastParams p;
+                    L.cur = PART_V2;
+                    p.x = w.X; p.nj = nj; p.nz = nz; p.nx = nx; p.nv = nv; p.D = D; p.T = T; p.B = B;
+                    p.text_mask = in->d_text_mask; p.flag = in->d_flag; p.logit_scale = m->logit_scale_bb;
+                    p.mean_mode = 0; p.skip_text = skip; p.logits = out->d_logits; p.slot = cont_slot; p.n_cont = m->cfg.n_cont;
+                    L.run(s, "contrast", 0, 0, tramp<ContrastParams, launch_contrast>, &p);
+                }
+                ++cont_slot;
+            }
+            if (m->debug_stop_layer == i) break;
+        }
+        if (have_ct) return fail(UVL_ESTATE, "internal: logits job left unlaunched");
+    } else
     for (int i = 0; i < m->depth; ++i) {
         const bool joint = i >= m->nf;
         const int N = (joint && !skip) ? nj : nv;
@@ -1166,7 +1381,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
     static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
         {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
-        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}, {"res_pre", &uvl_tuning::res_pre}};
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}, {"res_pre", &uvl_tuning::res_pre}, {"fin_w", &uvl_tuning::fin_w}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) {
             m->tune.*(k.field) = value < 0 ? -1 : value;
@@ -1190,6 +1405,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "pair_text")) { m->pair_text = value < 0 ? 0 : (value > 3 ? 3 : value); return UVL_OK; }
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "fold_ln")) { m->fold_ln = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return value ? pack_residual_images(m, nullptr) : UVL_OK; }
     if (!strcmp(key, "fork_text")) { m->fork_text = value ? 1 : 0; return UVL_OK; }   // 0: the text branch of multi-sequence frames runs on the caller's stream
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
@@ -1477,6 +1693,44 @@ extern "C" int uvl_qkv_project_pk(const void* d_x, const void* d_w, const void* 
 extern "C" int uvl_qkv_project(const void* d_x, const void* d_w, const float* d_bias, void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale,
                                const uvl_tuning* tune, void* stream) {
     return uvl_qkv_project_pk(d_x, d_w, nullptr, d_bias, d_q, d_k, d_vt, B, N, Npad, D, q_scale, tune, stream);
+}
+
+/* ---- LayerNorm-free forms (round 6; the kernels of one- / two-sequence frames, fold.h / gemm_fin.hip) ---- */
+extern "C" int uvl_fold_ln_linear(const float* d_w, const float* d_bias, const float* d_gamma, const float* d_beta, void* d_w_folded, float* d_bias_folded, float* d_colsum,
+                                  int N, int K, void* stream) {
+    if (!d_w || !d_gamma || !d_beta || !d_w_folded || !d_bias_folded || !d_colsum || N <= 0 || K <= 0 || K % 4 != 0) return fail(UVL_EINVAL, "uvl_fold_ln_linear: bad argument");
+    HIPCHK(launch_fold_ln_linear(d_w, d_bias, d_gamma, d_beta, (bf16_t*)d_w_folded, d_bias_folded, d_colsum, N, K, (hipStream_t)stream));
+    return UVL_OK;
+}
+extern "C" int uvl_linear_fin(const void* d_a, const void* d_w, const float* d_bias, float* d_x, void* d_xn, float* d_stats, int M, int N, int K, int accumulate,
+                              const float* d_res_stats, const float* d_res_gamma, const float* d_res_beta, float res_eps, float* d_res_copy, const uvl_tuning* tune, void* stream) {
+    if (!d_a || !d_w || !d_x || M <= 0) return fail(UVL_EINVAL, "uvl_linear_fin: null pointer");
+    GemmParams p;
+    p.tune = tune;
+    p.A = (const bf16_t*)d_a; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K; p.epi = 1; p.C = d_x; p.ldc = N; p.accumulate = accumulate ? 1 : 0;
+    p.xn = (bf16_t*)d_xn; p.xn_bs = 0; p.xn_ro = 0; p.st_out = d_stats;
+    p.res_st = d_res_stats; p.res_g = d_res_gamma; p.res_b = d_res_beta; p.res_eps = res_eps; p.res_copy = d_res_copy;
+    if (!gemm_fin_ok(p)) return fail(UVL_EINVAL, "uvl_linear_fin: need N %% 64 == 0, K %% 128 == 0 (and gamma / beta / accumulate with d_res_stats)");
+    HIPCHK(launch_gemm_fin(p, nullptr, (hipStream_t)stream));
+    return UVL_OK;
+}
+extern "C" int uvl_linear_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps, void* d_y,
+                              int M, int N, int K, int act, void* stream) {
+    if (!d_a || !d_stats || !d_w_folded || !d_bias_folded || !d_colsum || !d_y) return fail(UVL_EINVAL, "uvl_linear_lnf: null pointer");
+    GemmParams p;
+    p.A = (const bf16_t*)d_a; p.lda = K; p.W = (const bf16_t*)d_w_folded; p.ldw = K; p.bias = d_bias_folded; p.colsum = d_colsum; p.st_in = d_stats; p.ln_eps = eps;
+    p.M = M; p.N = N; p.K = K; p.epi = 0; p.C = d_y; p.ldc = N; p.act = act;
+    if (launch_gemm_lnf(p, nullptr, nullptr, (hipStream_t)stream) != hipSuccess) return fail(UVL_EINVAL, "uvl_linear_lnf: need N %% 64 == 0, K %% 128 == 0, K <= 1024 (or the launch failed: %s)", hipGetErrorString(hipGetLastError()));
+    return UVL_OK;
+}
+extern "C" int uvl_qkv_project_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps,
+                                   void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream) {
+    if (!d_a || !d_stats || !d_w_folded || !d_bias_folded || !d_colsum || !d_q || !d_k || !d_vt || D % 64 != 0) return fail(UVL_EINVAL, "uvl_qkv_project_lnf: bad argument");
+    GemmParams p;
+    p.A = (const bf16_t*)d_a; p.lda = D; p.W = (const bf16_t*)d_w_folded; p.ldw = D; p.bias = d_bias_folded; p.colsum = d_colsum; p.st_in = d_stats; p.ln_eps = eps;
+    p.M = B * N; p.N = 3 * D; p.K = D; p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale;
+    if (launch_gemm_lnf(p, nullptr, nullptr, (hipStream_t)stream) != hipSuccess) return fail(UVL_EINVAL, "uvl_qkv_project_lnf: need D %% 128 == 0, D <= 1024 (or the launch failed: %s)", hipGetErrorString(hipGetLastError()));
+    return UVL_OK;
 }
 
 extern "C" int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float eps, void* d_y_bf16, float* d_y_f32, int M, int D, void* stream) {
