@@ -154,6 +154,14 @@ class DistEnv:
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def gather_floats(self, x: float):
+        """One value per rank, in rank order, on every rank (outside the timed blocks: the per-rank step times of the line)."""
+        import torch
+        mine = torch.tensor([x], device=self.device, dtype=torch.float64)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [float(t.item()) for t in out]
+
 
 class NoDist:
     world = 1
@@ -164,13 +172,38 @@ class NoDist:
     def max_over_ranks(self, seconds: float) -> float:
         return seconds
 
+    def gather_floats(self, x: float):
+        return [x]
 
-def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmup: int, blocks: int, on_result=None):
+
+def throughput(world: int, per_rank_units: int, steps: int, block_seconds) -> float:
+    """`value` of the line: the units ALL ranks processed in a block / the block's time -- which is the maximum over ranks (timed_blocks), so a
+    straggler rank lowers the whole job's figure.  Median over the blocks."""
+    return world * per_rank_units * steps / float(np.median(block_seconds))
+
+
+def rank_step_times(env, step_fn, sync, n: int = 10):
+    """Per-rank step time (ms): every rank runs `n` steps on its own -- no collective in them, so a rank cannot hide behind the others' wait -- and the figures are
+    gathered with ONE all_gather outside the timed blocks.  A straggler GPU shows up in the one line (min / median / max, the slowest rank's index, the spread);
+    `value` of the line follows the slowest rank (throughput())."""
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step_fn()
+    sync()
+    mine = (time.perf_counter() - t0) / n * 1e3
+    per = env.gather_floats(mine)
+    return {"per_rank": [round(x, 4) for x in per], "min": min(per), "median": float(np.median(per)), "max": max(per), "slowest_rank": int(np.argmax(per)),
+            "spread": (max(per) - min(per)) / max(min(per), 1e-9), "steps": n}
+
+
+def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmup: int, blocks: int, on_result=None, local_times=None):
     """THE loop of this benchmark -- also what tests/test_bench_loop_gloo.py drives with a stub step over gloo.
     step_fn(i) enqueues one frame of this rank's sequences; local_boxes_fn() is the [n_local, 4] tensor it leaves; gatherer
     (uvltrack_amd.shard.BoxGatherer, or None for one process) all-gathers them, a group of steps per collective.  on_result(i, boxes)
     is called on every rank, in step order, with the gathered boxes of step i once its group is complete (and at the end of a run).  Returns the list of block times (seconds, maximum over ranks), `blocks`
-    entries (0 = choose from the first block: about three seconds in total, 3..400)."""
+    entries (0 = choose from the first block: about three seconds in total, 3..400).  local_times (a list, optional) receives THIS rank's own time of every
+    block: from the common start to the end of its own work, before the closing barrier."""
     counter = [0]
     delivered = [-1]
 
@@ -208,6 +241,8 @@ def timed_blocks(step_fn, local_boxes_fn, gatherer, env, sync, steps: int, warmu
         t0 = time.perf_counter()
         run(steps)
         sync()
+        if local_times is not None:
+            local_times.append(time.perf_counter() - t0)
         env.barrier()
         sync()
         times.append(env.max_over_ranks(time.perf_counter() - t0))
@@ -233,20 +268,21 @@ def pick_gather_every(step_fn, sync, env, forced: int = 0) -> int:
     return choose_every(env.max_over_ranks((time.perf_counter() - t0) / 5) * 1e3)
 
 
-def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_text, use_graph, steps, warmup, blocks, seed):
-    """Build an engine for `spec`, run the timed blocks; returns (times, engine, targs, outs, step description)."""
+def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_text, use_graph, steps, warmup, blocks, seed, eng=None, max_batch=None):
+    """Build an engine for `spec` (or take `eng`, built for the same spec), run the timed blocks; returns (times, engine, targs, outs)."""
     from uvltrack_amd import weightgen as wg
     from uvltrack_amd.engine import HipEngine
     from uvltrack_amd.shard import BoxGatherer
     flags = [flag_val] * B
-    eng = HipEngine(spec, dev, max_batch=max(B, 1))
-    for kv in args.tune:
-        k, v = kv.split("=", 1)
-        if k.strip().startswith("debug."):          # uvl_debug_set keys (A/B aids that are not launch heuristics), e.g. debug.fork_text=0
-            eng.debug_set(k.strip()[6:], int(v))
-        else:
-            eng.tune_set(k.strip(), int(v))
-    eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
+    if eng is None:
+        eng = HipEngine(spec, dev, max_batch=max(B, max_batch or 1))
+        for kv in args.tune:
+            k, v = kv.split("=", 1)
+            if k.strip().startswith("debug."):          # uvl_debug_set keys (A/B aids that are not launch heuristics), e.g. debug.fork_text=0
+                eng.debug_set(k.strip()[6:], int(v))
+            else:
+                eng.tune_set(k.strip(), int(v))
+        eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
     inp = wg.make_inputs(spec, batch=B, seed=seed + rank, flags=flags)      # every rank advances its own sequences
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     targs = (t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]))
@@ -263,11 +299,13 @@ def measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_tex
     if isinstance(env, DistEnv):                      # also with ONE rank under torch.distributed.run
         every = pick_gather_every(step_fn, torch.cuda.synchronize, env, int(getattr(args, "gather_every", 0) or 0))
         gatherer = BoxGatherer(env.world * B, dev, every=every)
-    times = timed_blocks(lambda i: step_fn(), lambda: outs["pred_boxes"].view(B, 4), gatherer, env, torch.cuda.synchronize, steps, warmup, blocks)
+    eng.local_times = []
+    times = timed_blocks(lambda i: step_fn(), lambda: outs["pred_boxes"].view(B, 4), gatherer, env, torch.cuda.synchronize, steps, warmup, blocks, local_times=eng.local_times)
     finite = bool(torch.isfinite(outs["bbox_map"]).all().item()) and bool(torch.isfinite(outs["logits"]).all().item())
     if not finite:
         raise SystemExit("bench.py: the forward pass produced non-finite outputs -- timing of a broken path is not reported")
     eng.gather_every = gatherer.every if gatherer is not None else None
+    eng.rank_ms = rank_step_times(env, step_fn, torch.cuda.synchronize)          # (a collective: every rank, outside the timed blocks)
     return times, eng, targs, outs
 
 
@@ -395,10 +433,10 @@ def main():
     times, eng, targs, outs = measure(torch, dev, env, rank, spec, B, flag_val, args, skip_text, reuse_text, use_graph,
                                       args.steps, args.warmup, args.blocks, seed=1000)
     elapsed = float(np.median(times))
+    rank_ms = eng.rank_ms
 
     if rank == 0:
-        frames = world * B * args.steps
-        fps = frames / elapsed
+        fps = throughput(world, B, args.steps, times)
         frame_ms = elapsed / args.steps * 1e3
         single_stream = (B == 1 or skip_text or reuse_text) and not use_graph
         roofline, roofline_attention, by_kernel, prof, n_launch = kernel_rooflines(eng, targs, spec, B, frame_ms, skip_text, reuse_text, single_stream, args.model)
@@ -413,6 +451,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "blocks": len(times), "block_ms": [round(x * 1e3, 3) for x in times], "statistic": "median of the blocks (each: exactly `steps` steps, max over ranks)",
+            # every rank's own ms per step (ten steps without a collective, gathered outside the timed region): `value` follows the SLOWEST rank
+            "rank_ms_per_step": rank_ms,
             "config": {"workload": "UVLTrack-%s z%d/x%d/T%d %s%s, %d sequence(s)/GPU, batch shards + RCCL all-gather of boxes" % (
                 args.model, spec.template_size, spec.search_size, spec.text_len, args.mode, " (text branch skipped)" if skip_text else (" (text branch reused from the first frame)" if reuse_text else ""), B),
                 "per_gpu_batch": B, "global_batch": B * world, "tokens_visual": spec.nv, "tokens_joint": spec.nj,
@@ -434,21 +474,33 @@ def main():
     eng.close()
     del eng, targs, outs
 
-    # ---- the regime where MFMA fractions mean something: the per-GPU load of BASELINE configs[4] (one process only) ----
+    # ---- the other BASELINE configs, one process only (the driver's record then holds all five): configs[1] = BBOX mode with the text branch skipped, configs[3] =
+    #      one UVLTrack-L sequence z256/x384, `batched` = the per-GPU load of configs[4] (8 UVLTrack-L sequences), the regime where MFMA fractions mean something.
+    #      Each: >= 30 blocks of the same number of steps, median, with its own launch count and frame-level roofline fractions.
+    def extra(model, mode, skip, Bx, eng_x, label, seed):
+        xspec = build_spec(model, 256, None)
+        xsteps = max(5, min(args.steps, 40))
+        xt, xeng, xtargs, _ = measure(torch, dev, env, rank, xspec, Bx, {"BBOX": 0, "NL": 1, "NLBBOX": 2}[mode], args, skip, False, False, xsteps, max(3, min(args.warmup, 8)),
+                                      max(30, args.blocks), seed=seed, eng=eng_x, max_batch=8 if model == "L" else 1)
+        xel = float(np.median(xt))
+        xfps = throughput(1, Bx, xsteps, xt)
+        xflops = xspec.flops_per_frame(skip_text=skip)
+        from uvltrack_amd.spec import state_dict_schema as sds
+        xwb = 2.0 * sum(int(np.prod(sh)) for n, sh in sds(xspec, False).items() if len(sh) >= 2 and "embeddings" not in n and "pos_embed" not in n and not (skip and ".bert." in n))
+        xroof, xattn, _, _, xn = kernel_rooflines(xeng, xtargs, xspec, Bx, xel / xsteps * 1e3, skip, False, Bx == 1 or skip, model)
+        blk = {"workload": label, "value": xfps, "unit": "frames/s", "ms_per_step": xel / xsteps * 1e3, "steps": xsteps, "blocks": len(xt),
+               "block_ms_min_max": [round(min(xt) * 1e3, 3), round(max(xt) * 1e3, 3)],
+               "gflop_per_frame": xflops / 1e9, "frame_model_tflops": xflops * xfps / 1e12, "frame_mfma_frac": xflops * xfps / 1e12 / PEAK_BF16_TFLOPS,
+               "frame_hbm_frac": xwb * (xfps / Bx) / 1e9 / PEAK_HBM_GBS, "launches_per_frame": xn, "roofline": xroof, "roofline_attention": xattn}
+        return blk, xeng
+
     if world == 1 and not args.no_batched and not (args.model == "L" and B == 8):
-        bspec = build_spec("L", 256, 384)
-        bsteps = max(5, min(args.steps, 40))
-        btimes, beng, btargs, bouts = measure(torch, dev, env, rank, bspec, 8, 2, args, False, False, False, bsteps, max(3, min(args.warmup, 8)), 3, seed=2000)
-        bel = float(np.median(btimes))
-        bfps = 8 * bsteps / bel
-        bflops = bspec.flops_per_frame()
-        broof, battn, _, _, bn = kernel_rooflines(beng, btargs, bspec, 8, bel / bsteps * 1e3, False, False, False, "L")
-        line["batched"] = {"workload": "UVLTrack-L z256/x384/T40 NLBBOX, 8 sequences on this GPU (per-GPU load of BASELINE configs[4])",
-                           "value": bfps, "unit": "frames/s", "ms_per_step": bel / bsteps * 1e3, "steps": bsteps, "blocks": len(btimes),
-                           "gflop_per_frame": bflops / 1e9, "frame_model_tflops": bflops * bfps / 1e12,
-                           "frame_mfma_frac": bflops * bfps / 1e12 / PEAK_BF16_TFLOPS, "launches_per_frame": bn,
-                           "roofline": broof, "roofline_attention": battn}
-        beng.close()
+        c1, e1 = extra("B", "BBOX", True, 1, None, "UVLTrack-B z256/x256 BBOX, text branch skipped, 1 sequence (BASELINE configs[1])", 3000)
+        e1.close()
+        c3, eL = extra("L", "NLBBOX", False, 1, None, "UVLTrack-L z256/x384/T40 NLBBOX, 1 sequence (BASELINE configs[3])", 4000)
+        line["configs"] = {"configs[1]": c1, "configs[3]": c3}
+        line["batched"], eL = extra("L", "NLBBOX", False, 8, eL, "UVLTrack-L z256/x384/T40 NLBBOX, 8 sequences on this GPU (per-GPU load of BASELINE configs[4])", 2000)
+        eL.close()
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -55,6 +55,11 @@ def cases():
     # workgroups) -- at this size the heuristics choose the many-sequence kernels on their own, so the un-forced default path is
     # what the reference pins here; mixed flags, one all-padding text
     c["l_z256_x384_b8"] = dict(spec=spec_l(256, 384), seed=0, in_seed=15, batch=8, flags=[2, 1, 0, 2, 2, 0, 1, 2], zero_text_rows=[3])
+    # round 6: 32 UVLTrack-B sequences = 17,696 rows, the size at which the DEFAULT path takes the text riders on the large-tile kernels, the 1152-item persistent
+    # attention walk and gemm_pipe_pair_kernel<256,1> (uvl_api.hip::text_rides: any model from 16000 visual rows).  Until now that path was pinned only to this
+    # library's own one-sequence runs (test_large_batch_matches_single_sequence_runs); batch independence is the reference's property
+    # (modality_unified_feature_extractor.py:43-77), so the reference itself pins it here.  Mixed flags, one all-padding text.
+    c["b_z256_x256_b32"] = dict(spec=spec_b(256, 256), seed=0, in_seed=16, batch=32, flags=[(2, 0, 1, 2, 2, 1, 0, 2)[i % 8] for i in range(32)], zero_text_rows=[21])
     return c
 
 

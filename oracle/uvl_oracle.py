@@ -23,6 +23,11 @@ P V, BatchNorm folded into the conv weights before their rounding, everything el
 GELU, sigmoid, normalisations) in f32.  It separates quantisation from defects: HIP-vs-emulated is gated an order of
 magnitude tighter than HIP-vs-fp32 (tests/parity_util.py).  It is NOT pinned to the reference (there is no bf16
 reference); the fp32 mode is.
+
+`emulate_bf16_mode="fold"` (round 6) is the same with the roundings of the LayerNorm-FREE one-sequence frame
+(uvltrack_amd/csrc/fold.h): a `norm -> Linear` pair (block.py:30-31 -> attn.qkv / mlp.fc1; the BertLayerNorms in front
+of query/key/value and intermediate.dense, the embedding LayerNorm in front of layer 0) is one GEMM on the UN-normalised
+rows rounded to bf16 against bf16(W gamma), y = rstd (a~ W'^T - mean colsum(W')) + (b + W beta), mean / rstd of the f32 row.
 """
 from __future__ import annotations
 
@@ -31,23 +36,27 @@ from scipy.special import erf as _erf
 
 f32 = np.float32
 _EMU = False          # bf16-emulating mode (see the module docstring)
+_FOLD = False         # ... with the LayerNorm-free frame's rounding points (norm -> Linear folded)
 QSCALE = f32(0.18033688011112042)      # log2(e) / sqrt(64): the HIP attention kernels work in the log2 domain
 
 
 class emulate_bf16:
     """Context manager: run the oracle with the HIP path's bf16 roundings."""
 
-    def __init__(self, on=True):
+    def __init__(self, on=True, fold=False):
         self.on = bool(on)
+        self.fold = bool(fold)
 
     def __enter__(self):
-        global _EMU
+        global _EMU, _FOLD
         self.prev, _EMU = _EMU, self.on
+        self.prev_fold, _FOLD = _FOLD, self.fold
         return self
 
     def __exit__(self, *exc):
-        global _EMU
+        global _EMU, _FOLD
         _EMU = self.prev
+        _FOLD = self.prev_fold
         return False
 
 
@@ -79,6 +88,22 @@ def layer_norm(x, w, b, eps):
     d = x - u
     s = (d * d).mean(-1, keepdims=True, dtype=f32)
     return (d / np.sqrt(s + f32(eps)) * w + b).astype(f32, copy=False)
+
+
+def norm_linear(x, g, b, eps, w, bias):
+    """nn.Linear applied to a LayerNorm'd row: linear(layer_norm(x, g, b, eps), w, bias) -- block.py:30-31 -> :42 / Mlp.fc1, bert_backbone.py:335-339 -> :366,
+    :376-380 -> :289-291.  In the fold-emulating mode it is the LayerNorm-free frame's single GEMM (csrc/fold.h, gemm.hip LNF): operands bf16(x) and
+    bf16(W gamma), f32 statistics of x, y = rstd (acc - mean colsum) + (bias + W beta)."""
+    if not (_EMU and _FOLD):
+        return linear(layer_norm(x, g, b, eps), w, bias)
+    u = x.mean(-1, keepdims=True, dtype=f32)
+    var = ((x * x).mean(-1, keepdims=True, dtype=f32) - u * u).clip(min=0)       # one-pass variance from (sum, sum of squares), as the partials give it
+    rstd = (f32(1.0) / np.sqrt(var + f32(eps))).astype(f32)
+    wf = bf16_round((w * g[None, :]).astype(f32))
+    cs = wf.sum(-1, dtype=f32)
+    bf = (bias + w @ b).astype(f32)
+    acc = (bf16_round(x) @ wf.T).astype(f32)
+    return (rstd * acc + ((-rstd * u) * cs + bf)).astype(f32)
 
 
 def gelu(x):
@@ -124,14 +149,17 @@ def patchify(sd, z, x):
     return np.concatenate([cls, zt, xt], axis=1).astype(f32)
 
 
-def bert_embedding(sd, ids, tmask):
+def bert_embedding(sd, ids, tmask, with_pre=False):
     """BertModel.embedding (bert_backbone.py:740-750) + BertEmbeddings.forward (:260-274), eval mode."""
     e = "backbone.bert.embeddings."
     T = ids.shape[1]
     emb = sd[e + "word_embeddings.weight"][ids] + sd[e + "position_embeddings.weight"][:T][None] \
         + sd[e + "token_type_embeddings.weight"][0][None, None]
-    emb = layer_norm(emb.astype(f32), sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], 1e-12)
+    u0 = emb.astype(f32)
+    emb = layer_norm(u0, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], 1e-12)
     bert_mask = ((f32(1.0) - tmask.astype(f32)) * f32(-10000.0))[:, None, None, :]
+    if with_pre:
+        return emb, bert_mask, (u0, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"])
     return emb, bert_mask
 
 
@@ -148,11 +176,15 @@ def cat_mask(tmask, flag, nz, nx):
     return mask, vmask
 
 
-def vit_attention(sd, pre, x, key_mask, heads):
-    """Attention.forward (block.py:47-61)."""
+def vit_attention(sd, pre, x, key_mask, heads, ln=None):
+    """Attention.forward (block.py:47-61).  ln = (gamma, beta, eps): x is the row BEFORE norm1 and the projection applies it (norm_linear)."""
     B, N, C = x.shape
     hd = C // heads
-    qkv = linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(B, N, 3, heads, hd).transpose(2, 0, 3, 1, 4)
+    if ln is not None:
+        qkv = norm_linear(x, ln[0], ln[1], ln[2], sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    else:
+        qkv = linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, heads, hd).transpose(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     if _EMU:
         o = _attention_bf16(q, k, v, None if key_mask is None else np.where(key_mask, f32(-1e10), f32(0.0)))
@@ -185,24 +217,28 @@ def _attention_bf16(q, k, v, key_add):
 def vit_block(sd, i, x, key_mask, heads):
     """Block.forward (block.py:29-32); LayerNorm eps 1e-6 (mae_vit.py:221); DropPath/LayerScale are Identity."""
     p = "backbone.vit.blocks.%d." % i
-    x = x + vit_attention(sd, p + "attn.", layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6), key_mask, heads)
-    h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
-    h = gelu(linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))     # Mlp.forward (backbones/utils.py:63-69)
+    x = x + vit_attention(sd, p + "attn.", x, key_mask, heads, ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6))
+    h = gelu(norm_linear(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))     # Mlp.forward (backbones/utils.py:63-69)
     return (x + linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])).astype(f32)
 
 
-def bert_layer(sd, i, y, bert_mask, heads):
+def bert_layer(sd, i, y, bert_mask, heads, pre=None):
     """BertLayer.forward (bert_backbone.py:390-394) = BertSelfAttention (:299-325) + BertSelfOutput (:335-339)
-    + BertIntermediate (:363-366) + BertOutput (:376-380); post-LN, eps 1e-12, eval mode."""
+    + BertIntermediate (:363-366) + BertOutput (:376-380); post-LN, eps 1e-12, eval mode.
+    pre = (u, gamma, beta) with y = LayerNorm(u): the row in front of the LayerNorm that produced y (the fold-emulating mode projects from it);
+    returns y_out, or (y_out, pre_out) when pre is given."""
     p = "backbone.bert.encoder.layer.%d." % i
     B, T, C = y.shape
     hd = C // heads
 
     def split(t):
         return t.reshape(B, T, heads, hd).transpose(0, 2, 1, 3)
-    q = split(linear(y, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"]))
-    k = split(linear(y, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"]))
-    v = split(linear(y, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"]))
+
+    def proj(name):
+        if pre is not None:
+            return norm_linear(pre[0], pre[1], pre[2], 1e-12, sd[p + "attention.self." + name + ".weight"], sd[p + "attention.self." + name + ".bias"])
+        return linear(y, sd[p + "attention.self." + name + ".weight"], sd[p + "attention.self." + name + ".bias"])
+    q, k, v = split(proj("query")), split(proj("key")), split(proj("value"))
     if _EMU:
         ctx = _attention_bf16(q, k, v, bert_mask[:, 0, 0, :]).transpose(0, 2, 1, 3).reshape(B, T, C)
     else:
@@ -211,10 +247,15 @@ def bert_layer(sd, i, y, bert_mask, heads):
         pr = softmax(s.astype(f32), -1)
         ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, T, C)
     a = linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
-    a = layer_norm(a + y, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], 1e-12)
-    h = gelu(linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+    u1 = (a + y).astype(f32)
+    g1, b1 = sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"]
+    a = layer_norm(u1, g1, b1, 1e-12)
+    h = gelu(norm_linear(u1, g1, b1, 1e-12, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
     o = linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
-    return layer_norm(o + a, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
+    u2 = (o + a).astype(f32)
+    g2, b2 = sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"]
+    out = layer_norm(u2, g2, b2, 1e-12)
+    return out if pre is None else (out, (u2, g2, b2))
 
 
 def txt_token_of(txt, tmask, mode):
@@ -240,7 +281,7 @@ def backbone_contrast(sd, img, txt, tmask, flag, nz, mode):
 def backbone_forward(sd, spec, template, search, ids, tmask, flag, taps=None):
     """ModalityUnifiedFeatureExtractor.forward (extractor.py:52-77)."""
     img = patchify(sd, template, search)
-    txt, bert_mask = bert_embedding(sd, ids, tmask)
+    txt, bert_mask, tpre = bert_embedding(sd, ids, tmask, with_pre=True)
     mask, vmask = cat_mask(tmask, flag, spec.nz, spec.nx)
     me = sd["backbone.vit.modal_embed"]
     logits = []
@@ -254,7 +295,7 @@ def backbone_forward(sd, spec, template, search, ids, tmask, flag, taps=None):
             img, txt = emb[:, :spec.nv], emb[:, spec.nv:]
         else:
             img = vit_block(sd, i, img, vmask, spec.heads)
-            txt = bert_layer(sd, i, txt, bert_mask, spec.heads)
+            txt, tpre = bert_layer(sd, i, txt, bert_mask, spec.heads, pre=tpre)
         if i in spec.cont_layers:
             logits.append(backbone_contrast(sd, img, txt, tmask, flag, spec.nz, spec.txt_token_mode))
         if taps is not None:
@@ -382,7 +423,7 @@ def head_forward(sd, spec, out, prompt, cont=None):
 def forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps=None, emulate_bf16_mode=False):
     """UVLTrack.forward_test (uvltrack.py:41-45), eval semantics."""
     if emulate_bf16_mode:
-        with emulate_bf16():
+        with emulate_bf16(fold=(emulate_bf16_mode == "fold")):
             return forward_test(sd, spec, template, search, ids, tmask, prompt, flag, taps)
     sd = {k: (np.asarray(v, dtype=f32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in sd.items()}
     out = backbone_forward(sd, spec, template.astype(f32), search.astype(f32), np.asarray(ids), np.asarray(tmask),

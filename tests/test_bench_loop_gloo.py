@@ -46,13 +46,17 @@ def _worker(rank, world, port, B, every, q):
 
         gatherer = BoxGatherer(world * B, dev, every=every)
         steps, warmup, blocks = 6, 3, 2
-        times = bench.timed_blocks(step_fn, lambda: local, gatherer, env, lambda: None, steps, warmup, blocks, on_result=on_result)
+        local_times = []
+        times = bench.timed_blocks(step_fn, lambda: local, gatherer, env, lambda: None, steps, warmup, blocks, on_result=on_result, local_times=local_times)
+        # the line's diagnostics (outside the timed blocks): every rank's own step time, and the value = all ranks' frames / the SLOWEST rank's time
+        stats = bench.rank_step_times(env, lambda: step_fn(0), lambda: None, n=5)
+        value = bench.throughput(world, B, steps, times)
         ok = len(times) == blocks and all(t >= steps * 0.002 * 0.9 for t in times)          # rank 0 reports rank 1's time too
         ok &= [i for i, _ in seen] == list(range(warmup + blocks * steps)) and all(f for _, f in seen)
         # one collective per step, or one per group of `every` steps + one per partial group at the end of a run (warm-up, each block)
         runs = [warmup] + [steps] * blocks
         ok &= gatherer.collectives == sum(-(-n // every) for n in runs)
-        q.put((rank, ok, times))
+        q.put((rank, ok, times, stats, value))
     finally:
         dist.destroy_process_group()
 
@@ -71,18 +75,31 @@ def test_bench_loop_world2_gloo(every):
     res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(r for r, _, _ in res) == [0, 1]
-    assert all(ok for _, ok, _ in res), res
-    t0, t1 = [t for _, _, t in sorted(res)]
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+    (_, _, t0, st0, v0), (_, _, t1, st1, v1) = sorted(res)
     assert t0 == t1                                # the max over ranks is what both report
+    # per-rank step times: the same list on both ranks, rank 1 (which sleeps 2 ms per step) is the slowest and at least 2 ms
+    assert st0 == st1 and st0["slowest_rank"] == 1 and len(st0["per_rank"]) == 2
+    assert st0["per_rank"][1] >= 2.0 * 0.9 and st0["per_rank"][0] < st0["per_rank"][1]
+    # value = (frames of ALL ranks) / (time of the slowest rank): 2 ranks x 3 sequences x 6 steps per block
+    import numpy as np
+    frames = 2 * 3 * 6
+    assert v0 == v1 == frames / float(np.median(t0))
+    slowest_block_s = st0["max"] * 1e-3 * 6
+    assert v0 <= frames / (2.0e-3 * 6) and v0 >= frames / slowest_block_s * 0.4      # never better than the straggler's 2 ms per step allows
 
 
 def test_bench_loop_single_process():
     sys.path.insert(0, ROOT)
     import bench
     calls = []
-    times = bench.timed_blocks(lambda i: calls.append(i), lambda: None, None, bench.NoDist(), lambda: None, 5, 2, 3)
-    assert len(times) == 3 and calls == list(range(2 + 3 * 5))
+    local = []
+    times = bench.timed_blocks(lambda i: calls.append(i), lambda: None, None, bench.NoDist(), lambda: None, 5, 2, 3, local_times=local)
+    assert len(times) == 3 and calls == list(range(2 + 3 * 5)) and len(local) == 3
+    st = bench.rank_step_times(bench.NoDist(), lambda: None, lambda: None, n=3)
+    assert st["per_rank"] and st["slowest_rank"] == 0 and st["min"] == st["max"]
+    assert bench.throughput(1, 4, 5, [2.0, 1.0, 4.0]) == 4 * 5 / 2.0
 
 
 def test_self_launcher_builds_one_rank_per_gpu(monkeypatch):

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "libuvltrack_hip.so")
 
 UVL_MAX_LAYERS = 64
 UVL_NFAM = 5
+UVL_ABI_VERSION = 3      # uvl_version(): bumped whenever a struct of include/uvltrack_hip.h changes size (3: uvl_tuning.res_pre / fin_w, the LayerNorm-free entry points)
 
 # every symbol include/uvltrack_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
@@ -104,6 +105,13 @@ def load():
             raise NativeLibraryError(msg)
         import warnings
         warnings.warn(msg)
+    elif _build.only_hash_differs(stamp):
+        import warnings
+        warnings.warn("%s was built by '%s': the tested release (%s) with another build hash -- accepted; the hand-counted waits were validated on the tested hash"
+                      % (LIB_PATH, stamp, _build.TESTED_HIPCC))
+    if lib.uvl_version() != UVL_ABI_VERSION:
+        raise NativeLibraryError("%s has ABI version %d, this binding is for %d (uvl_tuning / entry points changed): rebuild with `python -m uvltrack_amd.build --force`"
+                                 % (LIB_PATH, lib.uvl_version(), UVL_ABI_VERSION))
     lib.uvl_create.restype = vp
     lib.uvl_create.argtypes = [C.POINTER(UvlConfig)]
     lib.uvl_destroy.argtypes = [vp]

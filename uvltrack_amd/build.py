@@ -63,6 +63,13 @@ def same_toolchain(stamp: str, tested: str = None) -> bool:
     return stamp == tested or ("-" in tested and stamp.rsplit("-", 1)[0] == tested.rsplit("-", 1)[0] and stamp.startswith("HIP version: "))
 
 
+def only_hash_differs(stamp: str, tested: str = None) -> bool:
+    """same_toolchain() accepted the stamp, but its build hash is not the tested one: the suffix is a source commit, so strictly this is another source tree
+    of the same release.  Accepted (repackaged builds are common), but said out loud: callers warn."""
+    tested = TESTED_HIPCC if tested is None else tested
+    return same_toolchain(stamp, tested) and stamp != tested
+
+
 def hipcc_version(hipcc: str) -> str:
     try:
         out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
@@ -84,6 +91,9 @@ def check_toolchain(hipcc: str, verbose: bool = True) -> str:
             raise RuntimeError(msg)
         if verbose:
             sys.stderr.write(msg + "\n")
+    elif only_hash_differs(ver) and verbose:
+        sys.stderr.write("uvltrack_amd.build: hipcc '%s' is the tested release with another build hash (tested: %s); accepted -- re-run the forced-kernel "
+                         "GPU tests if results look off.\n" % (ver, TESTED_HIPCC))
     return ver
 
 

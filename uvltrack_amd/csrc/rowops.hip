@@ -111,6 +111,9 @@ hipError_t launch_layernorm_pair(const LnParams& a_in, const LnParams& b_in, hip
     if (a.D != b.D || a.D % 4 != 0 || a.D > 1024 || a.M <= 0 || b.M <= 0 || a.nsplit > LN_MAX_SLABS || b.nsplit > LN_MAX_SLABS || b.ct_x ||
         (a.ct_x && a.ct_self && (a.nsplit > 0 || a.ct_x != a.x)))
         return hipErrorInvalidValue;
+    // a direct logits job (ct_self: ln_body's CT = 2 form) beside a rider that folds slabs exists only as the rider-only-slabs kernel of the D = 768 / 1024
+    // instantiations (launch_ln_pair_variant's first branch); any other width would fall through to ln_pair_kernel<.., true, CT = 1> on a ct_self job: wrong logits
+    if (a.ct_x && a.ct_self && b.nsplit > 0 && !(a.D == 768 || a.D == 1024)) return hipErrorInvalidValue;
     const int wpb = ln_waves_per_block(a.M);
     const int ga = (a.M + wpb - 1) / wpb, gb = (b.M + wpb - 1) / wpb;
     if (a.D == 768) launch_ln_pair_variant<3, true>(a, b, ga, gb, wpb, s);

@@ -100,8 +100,11 @@ struct uvl_model {
     int fork_text = 1;                           // uvl_debug_set("fork_text", 0): multi-sequence frames run the text branch on the caller's stream (A/B)
     int fuse_contrast = 1;                       // uvl_debug_set("fuse_contrast", 0): stand-alone contrast kernels
     int prefetch_w = 1;                          // uvl_debug_set("prefetch_w", v): 0 = no next-weight requests in the GEMM launches, 1 = in frames below 2000 visual rows, 2 = always (A/B)
-    int bf16_store = 3;                          // uvl_debug_set("bf16_store", mask): which bf16 activations of many-sequence frames are stored write-through (sc1), see run_gemm
-    int text_nt = 15;                            // uvl_debug_set("text_nt", mask): which text-branch GEMMs load their weights non-temporal (1 QKV, 2 attention output, 4 intermediate, 8 output)
+    int bf16_store = 3;                          // uvl_debug_set("bf16_store", mask): which bf16 activations are stored write-through (sc1), see run_gemm.  The request is set on every visual
+                                                 // epi 0 / 2 GEMM; only gemm_dr_kernel (frames of >= 2048 rows) honours it -- gemm_epilogue_lds's bf16 / QKV stores ignore c_store
+    int text_nt = 15;                            // uvl_debug_set("text_nt", mask): which text-branch GEMMs load their weights non-temporal (1 QKV, 2 attention output, 4 intermediate, 8 output).
+                                                 // UNPAIRED text launches only (frames of 2-4 sequences): the riders of pair launches (gemm_glds_pair_kernel, gemm_lnf_pair_kernel,
+                                                 // gemm_fin_pair_kernel) always load their weight tiles non-temporal
     int rider_first = 1;                         // uvl_debug_set("rider_first", 0): the text rider's tiles of a one-sequence pair GEMM launch behind the visual tiles (the round-4 order; A/B)
     int rider_sk = 2;                            // uvl_debug_set("rider_sk", 1): the text rider's output GEMM in one K slice, in place (the round-4 form; A/B)
     int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
@@ -678,6 +681,16 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // the last full call left them.  The frame is then the single-stream visual schedule with nj rows from layer nf on.
     const int reuse = (!skip && in->reuse_text && m->nf > 0 && m->nf < m->depth) ? 1 : 0;
     if (reuse && tb) return fail(UVL_EINVAL, "uvl_forward: reuse_text is a forward_test option");
+    // a standing request for cfg 36 on the residual GEMMs (uvl_tune_set "gemm_dr" 1 / "gemm_cfg" 36 / "text_cfg" 36, uvl_debug_set "text_dr_res") needs their
+    // fragment-native weight images: made once, here, on the caller's stream (allocation + pack + one synchronize of THAT stream) -- never inside a capture
+    if ((m->tune.gemm_dr == 1 || m->tune.gemm_cfg == 36 || m->tune.text_cfg == 36 || m->text_dr_res) && (long)m->cfg.max_batch * m->nj >= 2048 && !m->vit.empty() &&
+        (!m->vit[0].pproj || !m->vit[0].pfc2 || (!m->bert.empty() && (!m->bert[0].pao || !m->bert[0].po)))) {
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cst) != hipSuccess) { (void)hipGetLastError(); cst = hipStreamCaptureStatusNone; }
+        if (cst != hipStreamCaptureStatusNone) return fail(UVL_ESTATE, "cfg 36 on the residual GEMMs was requested but their weight images are not packed yet: run one eager frame before capturing");
+        const int prc = pack_residual_images(m, s);
+        if (prc) return prc;
+    }
     const Workspace w = carve(m, B, (char*)d_ws);
     if (!d_ws || ws_bytes < w.total) return fail(UVL_EINVAL, "workspace too small: %zu < %zu", ws_bytes, w.total);
     if ((uintptr_t)d_ws % 256) return fail(UVL_EINVAL, "workspace must be 256-byte aligned");
@@ -1384,9 +1397,9 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
         {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}, {"res_pre", &uvl_tuning::res_pre}, {"fin_w", &uvl_tuning::fin_w}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) {
+            // (cfg 36 on proj / fc2 too needs their weight images: made by the next frame on ITS stream -- run_forward -- not here on the null stream, where the
+            // allocation + pack + synchronize would stall every blocking stream or break a capture in progress)
             m->tune.*(k.field) = value < 0 ? -1 : value;
-            if ((!strcmp(key, "gemm_dr") && value == 1) || ((!strcmp(key, "gemm_cfg") || !strcmp(key, "text_cfg")) && value == 36))
-                return pack_residual_images(m, nullptr);          // cfg 36 on proj / fc2 too: their weight images, once
             return UVL_OK;
         }
     if (!strcmp(key, "reset")) { uvl_tuning_init(&m->tune); return UVL_OK; }
@@ -1406,7 +1419,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fold_ln")) { m->fold_ln = value ? 1 : 0; return UVL_OK; }
-    if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return value ? pack_residual_images(m, nullptr) : UVL_OK; }
+    if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return UVL_OK; }      // (its weight images: the next frame, on its stream)
     if (!strcmp(key, "fork_text")) { m->fork_text = value ? 1 : 0; return UVL_OK; }   // 0: the text branch of multi-sequence frames runs on the caller's stream
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
 }
