@@ -264,7 +264,7 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *              up to K = 2048 -- and at every K where the launch is a single round of tiles -- the rows are requested inside the K loop, one 16-byte load per lane
  *              and phase over eight K tiles (gemm.hip::gemm_pipe128_body, PRE); 2 = at every K
  *   fin_w      tile of the finishing residual GEMMs of LayerNorm-free frames (gemm_fin.hip): 0 = 64 x 64 on two wave groups, 1 = 64 x 32 on four; default: 64 x 32 while
- *              its tiles are at most one workgroup per CU
+ *              its tiles are at most one workgroup per CU; 2 = additionally keep the split-K slab form for every layer of the conv towers (A/B)
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
     int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_dr, res_pre, fin_w;

@@ -351,7 +351,10 @@ def test_attention_spike_forces_rescale(lib, B, H, N, tile):
 
 @pytest.mark.parametrize("B,F,cin,cout,slabs", [(1, 16, 768, 256, True), (1, 16, 768, 256, False), (16, 16, 256, 128, True), (2, 24, 1024, 256, True),
                                                 (16, 24, 128, 64, False), (1, 16, 64, 32, False), (16, 16, 64, 32, True),
-                                                (8, 24, 1024, 256, True), (7, 24, 1024, 256, False)])
+                                                (8, 24, 1024, 256, True), (7, 24, 1024, 256, False),
+                                                # round 6: the layers of a one-sequence frame that run WITHOUT slabs, K quarters / halves on the wave groups of one workgroup
+                                                # (conv_fin_kernel<32>: K = 2304, <64>: K = 1152 -- 18 K tiles do not divide by four --, and UVLTrack-L's 24 x 24 map)
+                                                (1, 16, 256, 128, True), (1, 16, 128, 64, True), (1, 24, 256, 128, True), (1, 24, 128, 64, False), (2, 16, 256, 128, True)])
 def test_conv_tower_layer(lib, B, F, cin, cout, slabs):
     """One layer of the four conv towers (implicit GEMM over NHWC tokens, zero-page padding, towers as groups, BatchNorm folded)
     against F.conv2d -> BatchNorm2d(eval) -> ReLU in fp32 (heads/utils.py:126-131) at batch 1 and 16: the one-sequence split-K

@@ -222,6 +222,182 @@ __global__ __launch_bounds__(512) void gemm_fin_pair_kernel(const GemmParams pa,
     prefetch_retire(pfs);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same workgroup shape for a layer of the box head's 3x3 conv towers at one sequence (heads/utils.py:126-131 with BatchNorm folded,
+// modality_adaptive_box_head.py:28-50): implicit GEMM over NHWC tokens, towers as groups, y = relu(conv + b) as bf16.  Rounds 1-5 cut K = 9 Cin of these layers into
+// slices over workgroups (f32 slabs) and folded them with a second launch (slab_relu_kernel, 4.6 us); with the K quarters / halves on the wave groups of ONE
+// workgroup the layer is one launch and needs no slabs.  For the layers whose tiles x K fit that shape (layers 1 and 2 of the towers: K = 2304 / 1152); the first
+// layer (K = 6912: 108 K tiles) keeps its slices over 384 workgroups.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int G, int NS>
+__device__ __forceinline__ void conv_fin_body(const GemmParams& p, const int bx, char* smem_all) {
+    constexpr int WPG = 8 / G;
+    static_assert(WPG == 2 * (BN / 32) && (BN == 64 || BN == 32), "tile geometry");
+    constexpr int STAGE = (64 + BN) * 128, LPT = (64 + BN) / 8 / WPG, LPT_A = 8 / WPG, RS = 32 * 4 + 16;
+    constexpr int ITS = 32 / G / 8;
+    static_assert(G * NS * STAGE <= 160 * 1024 && 8 * 32 * RS <= G * NS * STAGE, "LDS");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave_all / WPG, wave = wave_all % WPG;
+    const int wm = wave / (BN / 32), wn = wave % (BN / 32);
+    char* smem = smem_all + grp * (NS * STAGE);
+    const int MT = (p.M + 63) >> 6, NT = p.N / BN, TG = MT * NT;
+    if (bx >= TG * p.groups) return;
+    const int g = (int)fd_div((uint32_t)bx, p.fd_gsz);                 // tower (fd_gsz = tiles per tower)
+    const int L = bx - g * TG;
+    const int nt = (int)fd_div((uint32_t)L, p.fd_mt), mt = L - nt * MT;
+    const int m0 = mt * 64, n0 = nt * BN;
+    const int kspan = p.K / G, kbase = grp * kspan, nk = kspan >> 6;
+    const int convF = p.conv_F, cin_g = p.cin_g, lda = p.lda, S = convF * convF;
+    const int goff = g == 0 ? p.a_goff[0] : g == 1 ? p.a_goff[1] : g == 2 ? p.a_goff[2] : p.a_goff[3];
+
+    const int c16 = lane & 7;
+    const int col = n0 + wn * 32 + c16 * 4;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias ? p.bias + (size_t)g * p.N + col : reinterpret_cast<const float*>(g_zero_page));
+
+    // DMA plan: instruction i of wave w fills stage rows [8 (w + WPG i), + 8): the A rows (pixels of the tile, gathered per 3x3 tap; out-of-image taps read the zero page)
+    // first, then the W rows of this tower
+    const bf16_t* src[LPT];
+    int a_i[LPT_A], a_j[LPT_A];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int r = 8 * (wave + WPG * i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        if (i < LPT_A) {
+            int gm = m0 + r;
+            gm = gm < p.M ? gm : p.M - 1;
+            const int b = gm / S, pix = gm - b * S;
+            a_i[i] = pix / convF;
+            a_j[i] = pix - a_i[i] * convF;
+            src[i] = p.A + (size_t)b * S * lda + goff + chunk * 8;
+        } else {
+            src[i] = p.W + ((size_t)g * p.N + n0 + r - 64) * p.ldw + kbase + chunk * 8;
+        }
+    }
+    const bf16_t* const zero_page = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        char* st = smem + (kt % NS) * STAGE;
+        const int k0 = kbase + kt * 64;                  // K index = tap * cin_g + channel; a 64-wide tile never straddles taps (cin_g % 64 == 0)
+        const int tap = k0 / cin_g, c0 = k0 - tap * cin_g;
+        const int tap_di = tap / 3 - 1, tap_dj = tap % 3 - 1;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const bf16_t* gp;
+            if (i < LPT_A) {
+                const int ii = a_i[i] + tap_di, jj = a_j[i] + tap_dj;
+                const bool ok = (unsigned)ii < (unsigned)convF && (unsigned)jj < (unsigned)convF;
+                gp = ok ? src[i] + (size_t)(ii * convF + jj) * lda + c0 : zero_page;
+            } else {
+                gp = src[i] + kt * 64;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)(st + (wave + WPG * i) * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(t);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt;
+        if (ahead >= NS - 2) fin_wait_vmcnt<LPT * (NS - 2)>();
+        else if (NS > 3 && ahead == 1) fin_wait_vmcnt<LPT>();
+        else fin_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const char* sA = smem + (kt % NS) * STAGE;
+        const char* sB = sA + 64 * 128;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = ks * 2 + (lane >> 5);
+            af[ks] = *reinterpret_cast<const bf16x8*>(sA + swz128(wm * 32 + (lane & 31), chunk));
+            bfr[ks] = *reinterpret_cast<const bf16x8*>(sB + swz128(wn * 32 + (lane & 31), chunk));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks], af[ks], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+    {
+        char* cw = smem_all + (grp * WPG + wave) * (32 * RS);
+        const int rl = lane & 31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(cw + rl * RS + (8 * q + 4 * (lane >> 5)) * 4) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const int r = grp * (32 / G) + it * 8 + (lane >> 3);
+        const int row = m0 + wm * 32 + r;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem_all + wave * (32 * RS) + r * RS + c16 * 16);
+#pragma unroll
+        for (int gg = 1; gg < G; ++gg) v += *reinterpret_cast<const f32x4*>(smem_all + (gg * WPG + wave) * (32 * RS) + r * RS + c16 * 16);
+        v += bias4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (row < p.M)
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + (size_t)g * p.N + col) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+
+template <bool W32>
+__global__ __launch_bounds__(512) void conv_fin_kernel(const GemmParams p) {
+    kernarg_warm<sizeof(GemmParams) + 64>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t pfs = prefetch_issue<512>(p.pf, p.pf_bytes, blockIdx.x, gridDim.x);
+    if constexpr (W32) conv_fin_body<32, 4, 3>(p, blockIdx.x, smem);
+    else conv_fin_body<64, 2, 4>(p, blockIdx.x, smem);
+    prefetch_retire(pfs);
+}
+
+// 0 = this layer does not fit the shape; 1 = 64 x 64 tiles on two wave groups; 2 = 64 x 32 on four
+int conv_fin_form(const GemmParams& p) {
+    if (p.conv_F <= 0 || p.epi != EPI_BF16 || p.act != 2 || p.cin_g % 64 != 0 || p.K != 9 * p.cin_g || p.M <= 0 || p.groups < 1 || p.groups > 4 || !p.C) return 0;
+    if (tune_get(p.tune, &uvl_tuning::fin_w, -1) == 2) return 0;                 // uvl_tune_set("fin_w", 2): the slab form everywhere (A/B)
+    const int nk = p.K / 64, MT = (p.M + 63) / 64;
+    if (nk > 48) return 0;                                                        // a long K (the first layer) is better cut over many workgroups
+    if (p.N % 32 == 0 && nk % 4 == 0 && (long)MT * (p.N / 32) * p.groups <= 256) return 2;
+    if (p.N % 64 == 0 && nk % 2 == 0 && (long)MT * (p.N / 64) * p.groups <= 256) return 1;
+    return 0;
+}
+hipError_t launch_conv_fin(const GemmParams& p_in, hipStream_t s) {
+    const int form = conv_fin_form(p_in);
+    if (!form) return hipErrorInvalidValue;
+    GemmParams p = p_in;
+    const int MT = (p.M + 63) / 64, NT = p.N / (form == 2 ? 32 : 64);
+    p.fd_mt = fastdiv_of((uint32_t)MT);
+    p.fd_gsz = fastdiv_of((uint32_t)(MT * NT));
+    const int blocks = MT * NT * p.groups;
+    if (form == 2) {
+        constexpr size_t lds = 4 * 3 * 96 * 128;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fin_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        g_last_kernel = "conv_fin_kernel<32>";
+        hipLaunchKernelGGL(conv_fin_kernel<true>, dim3(blocks), dim3(512), lds, s, p);
+    } else {
+        constexpr size_t lds = 2 * 4 * 128 * 128;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fin_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        g_last_kernel = "conv_fin_kernel<64>";
+        hipLaunchKernelGGL(conv_fin_kernel<false>, dim3(blocks), dim3(512), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
 bool gemm_fin_ok(const GemmParams& p) {
     return p.M > 0 && p.epi == EPI_F32 && p.N > 0 && p.N % 64 == 0 && p.K >= 128 && p.K % 128 == 0 && p.conv_F == 0 && p.groups <= 1 && p.splitk <= 1 && p.C != nullptr &&
            (!p.res_st || (p.res_g && p.res_b && p.N <= 1024 && p.accumulate)) && (!(p.xn || p.st_out) || p.N % 32 == 0);
@@ -230,7 +406,7 @@ bool gemm_fin_ok(const GemmParams& p) {
 // Tile width: 64 x 32 tiles on four wave groups while they are at most one workgroup per CU (uvl_tuning.fin_w: 0 = always 64 x 64, 1 = always 64 x 32)
 static bool fin_w32(const GemmParams& p) {
     const int forced = tune_get(p.tune, &uvl_tuning::fin_w, -1);
-    if (forced >= 0) return forced != 0 && (p.K / 64) % 4 == 0;
+    if (forced == 0 || forced == 1) return forced != 0 && (p.K / 64) % 4 == 0;
     return (p.K / 64) % 4 == 0 && (long)((p.M + 63) / 64) * (p.N / 32) <= 256;
 }
 template <bool W32>

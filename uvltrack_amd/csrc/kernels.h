@@ -87,6 +87,9 @@ hipError_t launch_fold_ln_linear(const float* W, const float* bias, const float*
 // x (+)= A W^T + b finished inside the launch: one eight-wave workgroup per 64 x 64 tile, the two K halves on its two wave groups (gemm_fin.hip); b = optional rider
 hipError_t launch_gemm_fin(const GemmParams& a, const GemmParams* b, hipStream_t s);
 bool gemm_fin_ok(const GemmParams& p);
+// one layer of the 3x3 conv towers (relu, bf16 out) in the same workgroup shape, no split-K slabs: conv_fin_form != 0 says whether the layer fits
+int conv_fin_form(const GemmParams& p);
+hipError_t launch_conv_fin(const GemmParams& p, hipStream_t s);
 // LayerNorm-folded consumer GEMM on the 64 x 64 tiles (EPI_BF16 / EPI_QKV); b = optional rider (plain or folded: b->st_in), ct = optional logits job
 hipError_t launch_gemm_lnf(const GemmParams& a, const GemmParams* b, const CtJob* ct, hipStream_t s);
 // fills the derived fields for a tile grid of BM x BN tiles (group_m already chosen)

@@ -608,6 +608,15 @@ static void run_conv_layer(Launcher& L, hipStream_t s, int layer, const bf16_t* 
         for (int c = 2; c <= 8 && c <= UVL_CONV_SKMAX; ++c)
             if (nk % c == 0 && nk / c >= 6 && tiles * c <= 768) sk = c;
     const char* site = conv_site[layer & 3];
+    {   // one-sequence frames: layers whose K fits run as ONE launch -- K quarters / halves on the wave groups of an eight-wave workgroup (gemm_fin.hip::conv_fin_body)
+        GemmParams q = p;
+        q.epi = 0; q.C = y; q.act = 2;
+        if (conv_fin_form(q)) {
+            L.wb_next = 2.0 * (double)q.N * q.K * 4;
+            L.run(s, site, 2.0 * q.M * q.N * q.K * 4, 2.0 * ((double)q.M * q.K + (double)q.N * q.K * 4), tramp<GemmParams, launch_conv_fin>, &q);
+            return;
+        }
+    }
     if (sk > 1) {
         p.epi = 1; p.C = slabs; p.splitk = sk; p.part_stride = (size_t)p.M * p.ldc; p.c_store = tune_get(tune, &uvl_tuning::slab_store, 2);
         RUN_GEMM(L, s, p, site);
