@@ -76,6 +76,57 @@ def test_default_path_of_a_32_sequence_frame_matches_the_reference():
     assert any(k.startswith("ln_pair_kernel") for k in kernels), sorted(kernels)
 
 
+# BASELINE.json's configs -> (model, template, search, batch, mode, skip_text), the kernels the DEFAULT path must run (prefixes), the ones it must not, launches
+_DISPATCH_CASES = {
+    "configs[1] B x1 BBOX, text skipped": (("B", 256, 256, 1, 0, True),
+        ["gemm_fin_kernel<32>", "gemm_lnf_kernel<2>", "gemm_lnf_kernel<0>", "attn_kernel<1,9,1>", "conv_fin_kernel<32>", "conv_fin_kernel<64>"],
+        ["ln_", "gemm_fin_pair", "gemm_lnf_pair", "attn_pair", "text_join", "gemm_dr", "gemm_pipe"], 69),
+    "configs[2] B x1 NLBBOX (the headline; configs[0] is the same frame on the reference's CPU path)": (("B", 256, 256, 1, 2, False),
+        ["gemm_fin_kernel<32>", "gemm_fin_pair_kernel<32,32>", "gemm_lnf_kernel<2>", "gemm_lnf_pair_kernel<2>", "gemm_lnf_pair_kernel<0>", "attn_pair_kernel<1,9,1>", "attn_kernel<1,9,1>",
+         "text_join_kernel", "conv_fin_kernel<32>", "conv_fin_kernel<64>"],
+        ["ln_", "gemm_dr", "gemm_pipe", "contrast"], 70),
+    "configs[3] L x1 NLBBOX": (("L", 256, 384, 1, 2, False),
+        ["gemm_fin_kernel<64>", "gemm_fin_pair_kernel<64,32>", "gemm_lnf_pair_kernel<2>", "gemm_lnf_kernel<0>", "attn_pair_kernel<2,4,2>", "text_join_kernel", "conv_fin_kernel"],
+        ["ln_", "gemm_dr", "gemm_pipe"], 130),
+    "configs[4] L x8 per GPU NLBBOX": (("L", 256, 384, 8, 2, False),
+        ["gemm_dr_pair_kernel<2>", "gemm_dr_pair_kernel<0>", "gemm_dr_kernel<2>", "gemm_dr_kernel<0>", "gemm_pipe_pair_kernel<128,1", "gemm_pipe128_kernel<1,1", "attn_p64_rider_kernel",
+         "attn_p64_kernel", "ln_pair_kernel", "ln_kernel"],
+        ["gemm_fin", "gemm_lnf", "text_join", "conv_fin"], None),
+}
+
+
+@pytest.mark.parametrize("case", list(_DISPATCH_CASES), ids=lambda c: c.split(" ")[0])
+def test_default_dispatch_per_baseline_config(case):
+    """One row per BASELINE.json config: which kernels the default path runs there (uvl_api.hip::kDispatch and the kernel-level choosers it points to; DESIGN.md
+    "Dispatch").  A heuristic lost in a clean-up once ran a whole round's benchmarks on the old kernels while every forced-form test stayed green; this pins the
+    kernel SET (and, for the one-sequence frames, the launch count) per workload the bench reports."""
+    from uvltrack_amd import weightgen as wg
+    from uvltrack_amd.engine import HipEngine
+    from uvltrack_amd.spec import spec_b, spec_l
+    (model, tz, xs, B, flag, skip), must, must_not, launches = _DISPATCH_CASES[case]
+    spec = spec_b(tz, xs) if model == "B" else spec_l(tz, xs)
+    _engines.clear()
+    eng = HipEngine(spec, torch.device("cuda:0"), max_batch=B)
+    try:
+        eng.load_state_dict(wg.make_state_dict(spec, 0, include_unused=False))
+        inp = wg.make_inputs(spec, batch=B, seed=5, flags=[flag] * B)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        out = eng.forward(t(inp["template"]), t(inp["search"]), t(inp["ids"]), t(inp["mask"]), t(inp["prompt"]), t(inp["flag"]), skip_text=skip, profile=True)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out["bbox_map"]).all())
+        prof = eng.profile_entries()
+        kernels = {e["kernel"] for e in prof}
+        n = sum(e["launches"] for e in prof)
+        for k in must:
+            assert any(x.startswith(k) for x in kernels), (k, sorted(kernels))
+        for k in must_not:
+            assert not any(x.startswith(k) for x in kernels), (k, sorted(kernels))
+        if launches is not None:
+            assert n == launches, (n, launches, sorted(kernels))
+    finally:
+        eng.close()
+
+
 def test_default_kernel_choice_of_a_many_sequence_frame():
     """Which kernels a frame of >= 2048 rows runs BY DEFAULT (a heuristic lost in a clean-up once ran the whole round's benchmarks on the
     old kernels while every forced-form test stayed green): QKV and fc1 on gemm_dr_kernel (cfg 36, packed weights made at

@@ -35,6 +35,27 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(UVL_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// ---- Dispatch: every frame-size rule of the scheduler, in one table (DESIGN.md, section "Dispatch", mirrors it row by row) --------------------------------
+// Rows = B x tokens of the frame.  The kernel-level choices behind these rules live with the kernels: gemm.hip::pick_plain_cfg (tile configuration by M / N / K),
+// attention.hip::pick_attn_cfg (attention form by workgroup count), gemm_fin.hip::fin_w32 / conv_fin_form (tile width of the finishing GEMMs).
+struct DispatchRules {
+    int cus;                      // 256   CUs of an MI355X: "one workgroup per CU" in the rules below
+    long fold_max_tiles;          // 256   LayerNorm-free schedule (one sequence): residual GEMMs of at most this many 64 x 64 tiles, i.e. one eight-wave workgroup per CU
+                                  //       (profiles/r06_lnfold_b1.md: 1416 -> 1552 frames/s on one UVLTrack-B sequence; tools/probes/combine2_probe.hip)
+    int splitk_cap;               // 4     split-K slices of a LayerNorm-kernel-schedule residual GEMM (UVL_SKMAX slabs in the workspace)
+    int splitk_min_ktiles;        // 6     ... a slice is at least this many K tiles (profiles/r01_gemm_sweep.md)
+    int splitk_long_half;         // 24    ... and from a grid that fits one workgroup per CU K is halved once more only into halves this long (profiles/r05_summary.md)
+    long dr_min_rows;             // 2048  frames of >= this many rows: packed weight images at finalize, gemm_dr_kernel for QKV / fc1 (profiles/r04_gemm_dr.md), riders possible
+    long rider_min_rows;          // 5000  the text branch rides in the visual launches of a many-sequence frame from here on ... (profiles/r04_text_branch.md)
+    int rider_wide_dim;           // 1024  ... for models at least this wide (UVLTrack-L: +0.7..1.9 %), or
+    long rider_any_rows;          // 16000 ... for any model from here on (UVLTrack-B x 32: +1.3..1.8 %; x 12 / 16 / 24 lose 1-1.6 % and keep the second stream)
+    long text_dr_min_rows;        // 6000  text branch on the second stream: its GEMMs on gemm_dr_kernel's tiles from here on (8 UVLTrack-B sequences lose 3.4 % below it)
+    long prefetch_max_rows;       // 2000  next-weight requests in the small-tile GEMM launches below this many visual rows ... (tools/probes/wprefetch_probe.py)
+    double prefetch_min_weights;  // 2e8   ... for models whose ViT weights (bytes) cannot stay in the 256 MB memory-side cache (UVLTrack-L x 1 +2.6..3.4 %; -B: 0)
+    long conv_sk_max_blocks;      // 768   split-K of a conv tower layer: slices while tiles x slices stay within three workgroups per CU (profiles/r01_summary.md)
+};
+static const DispatchRules kDispatch = {256, 256, 4, 6, 24, 2048, 5000, 1024, 16000, 6000, 2000, 2.0e8, 768};
+
 struct RawTensor {
     float* d = nullptr;
     std::vector<int64_t> shape;
@@ -277,7 +298,7 @@ struct Packer {
 // read-modify-write epilogue (uvl_tune_set "gemm_dr" 1) or the text branch's residual GEMMs are sent there (uvl_debug_set "text_dr_res" 1) -- made on
 // the first such request (or at finalize when the request is already standing), not for every handle.  Synchronous on `s`.
 static int pack_residual_images(uvl_model* m, hipStream_t s) {
-    if (!m->finalized || (long)m->cfg.max_batch * m->nj < 2048) return UVL_OK;
+    if (!m->finalized || (long)m->cfg.max_batch * m->nj < kDispatch.dr_min_rows) return UVL_OK;
     const int D = m->D, Fn = m->ffn;
     int err = 0;
     auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
@@ -345,7 +366,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
                     if (!P.err) P.err = fail(UVL_EHIP, "LayerNorm fold launch failed");
             }
         }
-        if ((long)m->cfg.max_batch * m->nj >= 2048) {          // many-sequence frames: second image of the weights for the direct-to-register GEMM
+        if ((long)m->cfg.max_batch * m->nj >= kDispatch.dr_min_rows) {          // many-sequence frames: second image of the weights for the direct-to-register GEMM
             auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
                 bf16_t* dst = src ? P.alloc<bf16_t>((size_t)N_ * K_) : nullptr;
                 if (dst && launch_pack_w_dr(src, dst, N_, K_, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "weight packing launch failed");
@@ -394,7 +415,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
             const float* wi32 = okf ? P.f32(b + "intermediate.dense.weight", Fn * D) : nullptr;
             if (wi32 && launch_fold_ln_linear(wi32, w.bi, w.ln1g, w.ln1b, w.fi, w.fbi, w.csi, (int)Fn, (int)D, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "LayerNorm fold launch failed");
         }
-        if ((long)m->cfg.max_batch * m->nj >= 2048) {          // the text branch of many-sequence frames runs on gemm_dr_kernel too (see run_gemm)
+        if ((long)m->cfg.max_batch * m->nj >= kDispatch.dr_min_rows) {          // the text branch of many-sequence frames runs on gemm_dr_kernel too (see run_gemm)
             auto pack = [&](const bf16_t* src, int N_, int K_) -> bf16_t* {
                 bf16_t* dst = src ? P.alloc<bf16_t>((size_t)N_ * K_) : nullptr;
                 if (dst && launch_pack_w_dr(src, dst, N_, K_, s) != hipSuccess && !P.err) P.err = fail(UVL_EHIP, "weight packing launch failed");
@@ -486,7 +507,7 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
 // Split-K factor for an `x += A W^T` GEMM that would otherwise leave most CUs idle (batch-1 shapes): each split
 // writes an f32 slab, the consuming LayerNorm / contrast kernel adds the slabs on read (deterministic, no atomics).
 static int choose_splitk(int M, int N, int K, const uvl_tuning* tune) {
-    const int cap = UVL_SKMAX;
+    const int cap = kDispatch.splitk_cap;
     const int forced = tune_get(tune, K > N ? &uvl_tuning::sk_k4 : &uvl_tuning::sk_k1, -1);   // uvl_tune_set("sk_k1" / "sk_k4")
     if (forced > 0 && (K / 64) % forced == 0 && forced <= cap) return forced;
     const long tiles = (long)((M + 63) / 64) * (N / 64);
@@ -497,7 +518,8 @@ static int choose_splitk(int M, int N, int K, const uvl_tuning* tune) {
     // sequences (216 tiles, 12 K tiles) unsplit 2042-2049 / 2019-2027, proj of one UVLTrack-L sequence (224 tiles, 16 K tiles) unsplit 459.8 / 455.6; fc2 of two
     // UVLTrack-B sequences keeps its 2 slices (2018-2037 against 1958-1981 unsplit and 1941-1945 with 4).
     int sk = 1;
-    while (sk * 2 <= cap && nk % (sk * 2) == 0 && nk / (sk * 2) >= 6 && (tiles * sk * 2 <= 256 || (tiles * sk < 256 && nk / (sk * 2) >= 24))) sk *= 2;
+    while (sk * 2 <= cap && nk % (sk * 2) == 0 && nk / (sk * 2) >= kDispatch.splitk_min_ktiles &&
+           (tiles * sk * 2 <= kDispatch.cus || (tiles * sk < kDispatch.cus && nk / (sk * 2) >= kDispatch.splitk_long_half))) sk *= 2;
     return sk;
 }
 
@@ -606,7 +628,7 @@ static void run_conv_layer(Launcher& L, hipStream_t s, int layer, const bf16_t* 
     int sk = 1;
     if (p.N % 64 == 0 && slabs)
         for (int c = 2; c <= 8 && c <= UVL_CONV_SKMAX; ++c)
-            if (nk % c == 0 && nk / c >= 6 && tiles * c <= 768) sk = c;
+            if (nk % c == 0 && nk / c >= kDispatch.splitk_min_ktiles && tiles * c <= kDispatch.conv_sk_max_blocks) sk = c;
     const char* site = conv_site[layer & 3];
     {   // one-sequence frames: layers whose K fits run as ONE launch -- K quarters / halves on the wave groups of an eight-wave workgroup (gemm_fin.hip::conv_fin_body)
         GemmParams q = p;
@@ -669,11 +691,11 @@ static bool text_rides(const uvl_model* m, int B, int skip, int reuse) {
     if (B == 1) return true;
     if (m->pair_text == 3) return false;
     const long rows = (long)B * m->nv;
-    const bool forms = rows >= 2048 && !m->bert.empty() && m->bert[0].pqkv && tune_get(&m->tune, &uvl_tuning::gemm_dr, -1) != 0 &&
+    const bool forms = rows >= kDispatch.dr_min_rows && !m->bert.empty() && m->bert[0].pqkv && tune_get(&m->tune, &uvl_tuning::gemm_dr, -1) != 0 &&
                        tune_get(&m->tune, &uvl_tuning::gemm_pipe, 1) != 0 && m->tune.text_cfg < 0;
     if (!forms) return false;
     if (m->pair_text >= 2) return true;
-    return rows >= 5000 && (m->D >= 1024 || rows >= 16000) && m->tune.gemm_cfg < 0 && m->tune.attn_cfg < 0;
+    return rows >= kDispatch.rider_min_rows && (m->D >= kDispatch.rider_wide_dim || rows >= kDispatch.rider_any_rows) && m->tune.gemm_cfg < 0 && m->tune.attn_cfg < 0;
 }
 
 static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* out, void* d_ws, size_t ws_bytes, hipStream_t s, Profiler* prof,
@@ -692,7 +714,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     if (reuse && tb) return fail(UVL_EINVAL, "uvl_forward: reuse_text is a forward_test option");
     // a standing request for cfg 36 on the residual GEMMs (uvl_tune_set "gemm_dr" 1 / "gemm_cfg" 36 / "text_cfg" 36, uvl_debug_set "text_dr_res") needs their
     // fragment-native weight images: made once, here, on the caller's stream (allocation + pack + one synchronize of THAT stream) -- never inside a capture
-    if ((m->tune.gemm_dr == 1 || m->tune.gemm_cfg == 36 || m->tune.text_cfg == 36 || m->text_dr_res) && (long)m->cfg.max_batch * m->nj >= 2048 && !m->vit.empty() &&
+    if ((m->tune.gemm_dr == 1 || m->tune.gemm_cfg == 36 || m->tune.text_cfg == 36 || m->text_dr_res) && (long)m->cfg.max_batch * m->nj >= kDispatch.dr_min_rows && !m->vit.empty() &&
         (!m->vit[0].pproj || !m->vit[0].pfc2 || (!m->bert.empty() && (!m->bert[0].pao || !m->bert[0].po)))) {
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cst) != hipSuccess) { (void)hipGetLastError(); cst = hipStreamCaptureStatusNone; }
@@ -710,7 +732,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // UVLTrack-L (909 MB of weights) x 1 426-428 -> 437-443 frames/s (+2.6..3.4 %), x 2 596 -> 620 (+4.1 %), x 4 867 -> 861 (-0.7 %); UVLTrack-B (its 170 MB
     // of ViT weights stay resident, see launch_gemm_pair) x 1 1362-1375 -> 1362-1364, x 2 0, x 4 -3 %.  The text branch's weights (riders: each byte read
     // once, by one CU) gain nothing from it (UVLTrack-L x 1 +2.6 % with them against +3.4 % without).
-    const bool pfw = m->prefetch_w == 2 || (m->prefetch_w == 1 && (long)B * nv < 2000 && (double)m->depth * 12.0 * D * D * 2.0 > 2.0e8);
+    const bool pfw = m->prefetch_w == 2 || (m->prefetch_w == 1 && (long)B * nv < kDispatch.prefetch_max_rows && (double)m->depth * 12.0 * D * D * 2.0 > kDispatch.prefetch_min_weights);
     Launcher L{prof};
     L.parts = parts;
     // eager full-frame runs fork the text branch onto the library's second stream and join with events; a partial walk
@@ -731,7 +753,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // branch), the 'cls' text token, a fusion tail (0 < nf < depth); tests cut below the first fusion layer on the LayerNorm-kernel schedule.
     const bool fold = m->fold_ln && B == 1 && (paired || skip || reuse) && !m->cfg.txt_token_mean && m->fuse_contrast && m->nf > 0 && m->nf < m->depth &&
                       m->D % 128 == 0 && (m->debug_stop_layer < 0 || m->debug_stop_layer >= m->nf) && !m->fuse_ln &&
-                      (long)((B * m->nj + 63) / 64) * (m->D / 64) <= 256 && m->tune.gemm_cfg < 0 && m->tune.text_cfg < 0 && !m->vit.empty() && m->vit[0].fqkv;
+                      (long)((B * m->nj + 63) / 64) * (m->D / 64) <= kDispatch.fold_max_tiles && m->tune.gemm_cfg < 0 && m->tune.text_cfg < 0 && !m->vit.empty() && m->vit[0].fqkv;
     // The text branch of a many-sequence frame (B x T rows: 320 at 8 sequences) overlaps the visual layers on the second stream, and what it
     // costs the frame is the CU time of its workgroups: as 64 x 64 tiles (240 workgroups of ~6 us per GEMM at ~15 % MFMA efficiency) that was
     // 8 % of the UVLTrack-L x 8 frame (1241 against 1351 frames/s without the branch).  On gemm_dr_kernel's 128 x 256 tiles the same GEMM is
@@ -739,7 +761,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // the longer text kernels reach the critical path (8 UVLTrack-B sequences -3.4 %, 4: -17 %), so only frames of >= 6000 visual rows take it.
     // The rest of the branch's cost is not CU time (profiles/r04_text_branch.md).  In-place residual epilogue (no split-K slabs).
     // uvl_tuning.text_cfg >= 0 overrides the tile configuration as before; gemm_dr = 0 switches this off.
-    const bool text_dr = !paired && (long)B * m->nv >= 6000 && m->tune.text_cfg < 0 && tune_get(&m->tune, &uvl_tuning::gemm_dr, -1) != 0 && !m->bert.empty() && m->bert[0].pqkv;
+    const bool text_dr = !paired && (long)B * m->nv >= kDispatch.text_dr_min_rows && m->tune.text_cfg < 0 && tune_get(&m->tune, &uvl_tuning::gemm_dr, -1) != 0 && !m->bert.empty() && m->bert[0].pqkv;
     const bool fork = !skip && !reuse && !prof && m->nf > 0 && parts == PART_ALL && !paired && m->fork_text;
     hipStream_t sa = fork ? m->aux : s;          // text branch stream (serialised when profiling)
     enum { R_GEMM = 0, R_ATTN = 1, R_LN = 2 };
