@@ -54,7 +54,7 @@ def main(src, tag, model="B", batch=1, wl="bench.py default workload: UVLTrack-B
     f, nf = agg(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"))
     w, nw = agg(os.path.join(src, "pmc_write", "bench_counter_collection.csv"))
     for k in sorted(stats, key=lambda k: -stats[k][2]):
-        if not re.match(r"(gemm|attn|ln_|contrast|head|im2row|bert|setup|slab|prologue)", k):
+        if not re.match(r"(gemm|attn|ln_|contrast|head|im2row|bert|setup|slab|prologue|conv_fin|text_join)", k):
             continue
         calls, avg_us, pct = stats[k]
         busy = m.get(k, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(nm.get(k, 1), 1)

@@ -1321,23 +1321,26 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
 // rider) on the 64 x 64 tiles, A = the un-normalised bf16 rows a finishing GEMM (gemm_fin.hip), the patch embedding or the prologue left, with their partial
 // statistics.  The launch may also carry the contrastive logits of the previous layer as its FIRST workgroups (one wave per search row, fold.h::ct_job_block): the
 // job used to ride on LayerNorm launches that no longer exist, its rows are complete when this launch starts and nothing of this launch depends on it.
-// Block order: [logits job | rider tiles | visual tiles]; the first two counts are multiples of 8, so every tile keeps its workgroup -> XCD relation.
+// Block order: [rider tiles | visual tiles | logits job]; the rider's count is a multiple of 8, so every tile keeps its workgroup -> XCD relation.  The job's 64
+// workgroups come LAST: dispatched first they held one of the two workgroup slots of 64 CUs while the 324 GEMM tiles were being placed, so more CUs than necessary
+// ended up with two tiles (measured: QKV launch 8.9 us with the job first).
 // ------------------------------------------------------------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_lnf_kernel(const GemmParams p, const CtJob ct, const int blocks_ct) {
     kernarg_warm<sizeof(GemmParams) + sizeof(CtJob) + 8 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < blocks_ct) { ct_job_block(ct, (int)blockIdx.x, g_zero_row); return; }
+    const int nb = (int)gridDim.x - blocks_ct;           // GEMM tiles first, the job's short workgroups behind them (see the note above)
+    if ((int)blockIdx.x >= nb) { ct_job_block(ct, (int)blockIdx.x - nb, g_zero_row); return; }
     const uint32_t pfs = prefetch_issue<256>(p.pf, p.pf_bytes, blockIdx.x, gridDim.x);
-    gemm_glds_body<64, 64, 2, 2, EPI, 4, false, false, 64, 0, 0, true>(p, (int)blockIdx.x - blocks_ct, 0, 0, smem);
+    gemm_glds_body<64, 64, 2, 2, EPI, 4, false, false, 64, 0, 0, true>(p, (int)blockIdx.x, 0, 0, smem);
     prefetch_retire(pfs);
 }
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_lnf_pair_kernel(const GemmParams pa, const GemmParams pb, const CtJob ct, const int blocks_ct, const int blocks_b) {
     kernarg_warm<2 * sizeof(GemmParams) + sizeof(CtJob) + 8 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bid = (int)blockIdx.x - blocks_ct;
-    if (bid < 0) { ct_job_block(ct, (int)blockIdx.x, g_zero_row); return; }
+    const int bid = (int)blockIdx.x, nb = (int)gridDim.x - blocks_ct;
+    if (bid >= nb) { ct_job_block(ct, bid - nb, g_zero_row); return; }
     const uint32_t pfs = prefetch_issue<256>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
     if (bid < blocks_b) gemm_glds_body<64, 64, 2, 2, EPI, 4, false, true, 64, 0, 0, true>(pb, bid, 0, 0, smem);       // the rider first: its weight tiles come from HBM (non-temporal)
     else gemm_glds_body<64, 64, 2, 2, EPI, 4, false, false, 64, 0, 0, true>(pa, bid - blocks_b, 0, 0, smem);
