@@ -195,30 +195,31 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
     }
 }
 
-// W32: the 64 x 32 tile on four wave groups (else 64 x 64 on two)
-template <bool NTW, bool W32>
+// BN = 32: the 64 x 32 tile on four wave groups; 64: 64 x 64 on two (the template arguments are the tile widths, so that profilers print the names the library reports)
+template <bool NTW, int BN>
 __device__ __forceinline__ void gemm_fin_tile(const GemmParams& p, const int bx, char* smem) {
-    if constexpr (W32) gemm_fin_body<NTW, 32, 4, 3>(p, bx, smem);
+    static_assert(BN == 32 || BN == 64, "tile width");
+    if constexpr (BN == 32) gemm_fin_body<NTW, 32, 4, 3>(p, bx, smem);
     else gemm_fin_body<NTW, 64, 2, 4>(p, bx, smem);
 }
 
-template <bool W32>
+template <int BN>
 __global__ __launch_bounds__(512) void gemm_fin_kernel(const GemmParams p) {
     kernarg_warm<sizeof(GemmParams) + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t pfs = prefetch_issue<512>(p.pf, p.pf_bytes, blockIdx.x, gridDim.x);
-    gemm_fin_tile<false, W32>(p, blockIdx.x, smem);
+    gemm_fin_tile<false, BN>(p, blockIdx.x, smem);
     prefetch_retire(pfs);
 }
 
 // The same with the text branch's GEMM of the same kind as a second problem (the rider: its workgroups first, its weight tiles non-temporal -- see gemm_glds_pair_kernel)
-template <bool W32A, bool W32B>
+template <int BNA, int BNB>
 __global__ __launch_bounds__(512) void gemm_fin_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
     kernarg_warm<2 * sizeof(GemmParams) + 8 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t pfs = prefetch_issue<512>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
-    if ((int)blockIdx.x < blocks_b) gemm_fin_tile<true, W32B>(pb, blockIdx.x, smem);
-    else gemm_fin_tile<false, W32A>(pa, (int)blockIdx.x - blocks_b, smem);
+    if ((int)blockIdx.x < blocks_b) gemm_fin_tile<true, BNB>(pb, blockIdx.x, smem);
+    else gemm_fin_tile<false, BNA>(pa, (int)blockIdx.x - blocks_b, smem);
     prefetch_retire(pfs);
 }
 
@@ -346,12 +347,12 @@ __device__ __forceinline__ void conv_fin_body(const GemmParams& p, const int bx,
     }
 }
 
-template <bool W32>
+template <int BN>
 __global__ __launch_bounds__(512) void conv_fin_kernel(const GemmParams p) {
     kernarg_warm<sizeof(GemmParams) + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t pfs = prefetch_issue<512>(p.pf, p.pf_bytes, blockIdx.x, gridDim.x);
-    if constexpr (W32) conv_fin_body<32, 4, 3>(p, blockIdx.x, smem);
+    if constexpr (BN == 32) conv_fin_body<32, 4, 3>(p, blockIdx.x, smem);
     else conv_fin_body<64, 2, 4>(p, blockIdx.x, smem);
     prefetch_retire(pfs);
 }
@@ -378,22 +379,22 @@ hipError_t launch_conv_fin(const GemmParams& p_in, hipStream_t s) {
         constexpr size_t lds = 4 * 3 * 96 * 128;
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fin_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fin_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
         g_last_kernel = "conv_fin_kernel<32>";
-        hipLaunchKernelGGL(conv_fin_kernel<true>, dim3(blocks), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(conv_fin_kernel<32>, dim3(blocks), dim3(512), lds, s, p);
     } else {
         constexpr size_t lds = 2 * 4 * 128 * 128;
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fin_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fin_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
         g_last_kernel = "conv_fin_kernel<64>";
-        hipLaunchKernelGGL(conv_fin_kernel<false>, dim3(blocks), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(conv_fin_kernel<64>, dim3(blocks), dim3(512), lds, s, p);
     }
     return hipGetLastError();
 }
@@ -412,7 +413,7 @@ static bool fin_w32(const GemmParams& p) {
 template <bool W32>
 static hipError_t launch_fin1(const GemmParams& a, int ba, hipStream_t s) {
     constexpr size_t lds = W32 ? 4 * 3 * 96 * 128 : 2 * 4 * 128 * 128;
-    auto kern = gemm_fin_kernel<W32>;
+    auto kern = gemm_fin_kernel<W32 ? 32 : 64>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -426,7 +427,7 @@ static hipError_t launch_fin1(const GemmParams& a, int ba, hipStream_t s) {
 template <bool W32A, bool W32B>
 static hipError_t launch_fin2(const GemmParams& a, const GemmParams& b, int ba, int bb, hipStream_t s) {
     constexpr size_t lds = (W32A || W32B) ? 4 * 3 * 96 * 128 : 2 * 4 * 128 * 128;
-    auto kern = gemm_fin_pair_kernel<W32A, W32B>;
+    auto kern = gemm_fin_pair_kernel<W32A ? 32 : 64, W32B ? 32 : 64>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
