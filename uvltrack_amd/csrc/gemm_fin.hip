@@ -188,8 +188,17 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
         s1 = oct_sum(s1);
         s2 = oct_sum(s2);
         if (inb[it]) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + xrow[it] * p.ldc + col) = v;
-            if (p.xn) *reinterpret_cast<uint2*>(p.xn + nrow[it] * p.N + col) = uint2{lo, hi};
+            float* xp = reinterpret_cast<float*>(p.C) + xrow[it] * p.ldc + col;
+            if (p.c_store == 2) {          // write-through (sc1): the next launch reads these rows on other XCDs; nothing of them waits dirty in this L2 for the end-of-kernel write-back
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xp), "v"(v) : "memory");
+                if (p.xn) {
+                    const uint2 pk = uint2{lo, hi};
+                    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p.xn + nrow[it] * p.N + col), "v"(pk) : "memory");
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(xp) = v;
+                if (p.xn) *reinterpret_cast<uint2*>(p.xn + nrow[it] * p.N + col) = uint2{lo, hi};
+            }
             if (p.st_out && c16 == 0) *reinterpret_cast<float2*>(p.st_out + (nrow[it] * np + ((n0 >> 5) + wn)) * 2) = float2{s1, s2};
         }
     }

@@ -1042,7 +1042,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         };
         auto run_fin = [&](const char* what, GemmParams& a, GemmParams* b) {
             a.tune = &m->tune;
-            if (b) b->tune = &m->tune;
+            a.c_store = tune_get(&m->tune, &uvl_tuning::res_store, 0);
+            if (b) { b->tune = &m->tune; b->c_store = a.c_store; }
             FinCtx c{a, b ? *b : a, b != nullptr};
             double fl = 0, by = 0, wb = 0;
             cost(a, fl, by, wb);
