@@ -224,7 +224,8 @@ int uvl_profile_entry(const uvl_model_t* m, int i, char* name, char* kernel, int
 int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
 
 /* Test hooks.  key "stop_layer": value >= 0 makes the next forwards leave the layer loop after that ViT layer
- * (the head still runs on that state) so parity tests can localise an error to a layer; -1 restores normal runs.
+ * (the head still runs on that state) so parity tests can localise an error to a layer; -2 runs NO layer (the outputs `search` / `template` / `vis_token` / `text` are then
+ * the patch embedding + position table + [cls] row and the BERT embedding: the input side alone); -1 restores normal runs.
  * "pair_text" (default 1): where the text branch rides in the visual launches instead of running on a second stream -- 0 never,
  * 1 one-sequence frames and the many-sequence frames it measured ahead on (UVLTrack-L from 5000 visual rows, any model from
  * 16000), 2 wherever the pair kernels exist (>= 2048 rows), 3 one-sequence frames only.  "fuse_contrast" (default 1): 0 selects
@@ -332,12 +333,12 @@ int uvl_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, f
 /* ---- the LayerNorm-free forms one- / two-sequence frames run (uvl_debug_set "fold_ln", default 1) ---------------------------------------------
  * A `norm -> Linear` pair (block.py:30-31 -> attn.qkv / mlp.fc1; BertLayerNorm -> query/key/value / intermediate.dense, bert_backbone.py:335-339,366,376-380)
  * runs as ONE GEMM on the UN-normalised rows rounded to bf16:  y = rstd (a~ W'^T - mean colsum(W')) + b'  with W' = bf16(W gamma), b' = b + W beta, mean / rstd
- * of the f32 rows a, a~ = bf16(a).  The rows' statistics travel as per-32-column partials  stats[(row * K/32 + j) * 2 + {0,1}] = (sum, sum of squares) of
+ * of the f32 rows a, a~ = bf16(a).  The rows' statistics travel as per-32-column partials  stats[((j / 2) * M + row) * 4 + (j % 2) * 2 + {0,1}] (j < K/32: planes of column-block PAIRS, all M rows each) = (sum, sum of squares) of
  * the f32 values of columns [32 j, 32 j + 32) (before their rounding to bf16), written by whoever writes the bf16 row.
  * uvl_fold_ln_linear: d_w [N,K] f32, d_bias [N] (or NULL), gamma / beta [K] -> d_w_folded bf16 [N,K], d_bias_folded [N], d_colsum [N] (row sums of the ROUNDED W').
  * uvl_linear_fin:  x (+)= a W^T + b finished inside the launch (block.py:29-32 residual adds; no split-K slabs): one eight-wave workgroup per 64 x 64 tile, its two
  *   wave groups on the two K halves.  d_a [M,K] bf16, d_w [N,K] bf16, d_x [M,N] f32 in/out (accumulate != 0 adds), d_xn [M,N] bf16 = bf16(x) and d_stats
- *   [M, N/32, 2] = its partials (both optional).  d_res_stats != NULL: post-LayerNorm residual (bert_backbone.py:335-339) -- d_x holds PRE-norm rows u, d_res_stats
+ *   [N/64, M, 2, 2] = its partials (both optional).  d_res_stats != NULL: post-LayerNorm residual (bert_backbone.py:335-339) -- d_x holds PRE-norm rows u, d_res_stats
  *   the partials of u, and the residual added is LayerNorm(u; gamma, beta, res_eps); d_res_copy (optional) receives those normalised rows.  N % 64 == 0, K % 128 == 0.
  * uvl_linear_lnf / uvl_qkv_project_lnf: the consumer GEMMs (epilogues of uvl_linear / uvl_qkv_project), d_a = bf16 rows + d_stats.  K % 128 == 0, K <= 1024. */
 int uvl_fold_ln_linear(const float* d_w, const float* d_bias, const float* d_gamma, const float* d_beta, void* d_w_folded, float* d_bias_folded, float* d_colsum,

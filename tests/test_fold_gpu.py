@@ -36,10 +36,10 @@ def _chk(rc, lib):
 
 
 def _partials(rows):
-    """[M, D] f32 -> [M, D/32, 2] (sum, sum of squares) per 32 columns, the layout fold.h describes."""
+    """[M, D] f32 -> [D/64, M, 2, 2]: (sum, sum of squares) per 32 columns, planes of column-block pairs (fold.h::st_off)."""
     M, D = rows.shape
-    r = rows.float().reshape(M, D // 32, 32)
-    return torch.stack([r.sum(-1), (r * r).sum(-1)], dim=-1).contiguous()
+    r = rows.float().reshape(M, D // 64, 2, 32)
+    return torch.stack([r.sum(-1), (r * r).sum(-1)], dim=-1).permute(1, 0, 2, 3).contiguous()
 
 
 def _rows_with_mean_and_outliers(M, D, seed):
@@ -68,7 +68,7 @@ def test_linear_fin(lib, M, N, K, acc, fw):
     x0 = _rand((M, N), 4) if acc else torch.full((M, N), float("nan"), device="cuda")
     x = x0.clone()
     xn = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-    st = torch.full((M, N // 32, 2), float("nan"), device="cuda")
+    st = torch.full((N // 64, M, 2, 2), float("nan"), device="cuda")
     _chk(lib.uvl_linear_fin(_p(a), _p(w), _p(b), _p(x), _p(xn), _p(st), M, N, K, acc, None, None, None, C.c_float(0.0), None, tune, _stream()), lib)
     torch.cuda.synchronize()
     ref = a.float() @ w.float().t() + b + (x0 if acc else 0.0)
@@ -96,7 +96,7 @@ def test_linear_fin_post_layernorm_residual(lib, M, N, K, fw):
     st_u = _partials(u)
     x = u.clone()
     xn = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-    st = torch.empty((M, N // 32, 2), device="cuda")
+    st = torch.empty((N // 64, M, 2, 2), device="cuda")
     copy = torch.full((M, N), float("nan"), device="cuda")
     _chk(lib.uvl_linear_fin(_p(a), _p(w), _p(b), _p(x), _p(xn), _p(st), M, N, K, 1, _p(st_u), _p(g), _p(be), C.c_float(1e-12), _p(copy), _fin_tune(fw), _stream()), lib)
     torch.cuda.synchronize()

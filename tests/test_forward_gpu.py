@@ -265,6 +265,34 @@ def test_layer_localised_error_is_explained_by_bf16_quantisation(name):
     assert ok, "\n" + "\n".join("%-16s %s" % kv for kv in rep.items())
 
 
+@pytest.mark.parametrize("name", ["tiny_mixed", "b_z256_x256", "l_z256_x384"])
+def test_input_side_alone_matches_the_oracle_taps(name):
+    """Patch embedding (im2row + GEMM + position table, mae_vit.py:92-100,203-215), the [cls] row and the BERT embedding (bert_backbone.py:260-274) localised:
+    uvl_debug_set("stop_layer", -2) runs no layer, so the head's output copies are the residual stream as the input-side kernels left it (prologue_kernel, gemm.patch);
+    compared with the oracle's `embed_img` / `embed_txt` taps (fp32, pinned to the reference) at bf16-operand tolerance for the patch GEMM and f32 tolerance for the embedding.
+    Batched (setup + bert_embed + im2row kernels) and one sequence (the single prologue launch)."""
+    from oracle import uvl_oracle as O
+    meta, spec, _ = load_case(name)
+    inp = rebuild_inputs(meta, spec)
+    sd = rebuild_weights(meta, spec, include_unused=False)
+    taps = {}
+    O.forward_test(sd, spec, inp["template"], inp["search"], inp["ids"], inp["mask"], inp["prompt"], inp["flag"], taps)
+    eng = _engine(meta, spec)
+    _native_check(eng.lib.uvl_debug_set(eng.handle, b"stop_layer", -2))
+    try:
+        for sl in (slice(None), slice(0, 1)):
+            o = _run(eng, {k: v[sl] for k, v in inp.items()})
+            img = np.concatenate([o["vis_token"], o["template"], o["search"]], axis=1)
+            want_img, want_txt = taps["embed_img"][sl], taps["embed_txt"][sl]
+            assert img.shape == want_img.shape and o["text"].shape == want_txt.shape
+            amax = float(np.abs(want_img).max())
+            assert np.isfinite(img).all() and float(np.abs(img - want_img).max()) <= 1e-2 * amax, (float(np.abs(img - want_img).max()), amax)
+            np.testing.assert_array_equal(img[:, 0], want_img[:, 0])                      # the [cls] row is a copy
+            assert float(np.abs(o["text"] - want_txt).max()) <= 2e-5 * max(1.0, float(np.abs(want_txt).max()))
+    finally:
+        eng.lib.uvl_debug_set(eng.handle, b"stop_layer", -1)
+
+
 _fold_emu_cache = {}
 
 

@@ -12,6 +12,10 @@
 
 namespace uvl {
 
+// Offset (floats) of partial pair j of row `row` in an array of `rows` rows: plane PAIRS -- [j / 2][row][j % 2][sum, sum of squares] -- so that a consumer lane reads the
+// partials (2 i, 2 i + 1) of its row as ONE 16-byte load and the 32 lanes of a half wave (consecutive rows) read 512 contiguous bytes
+__host__ __device__ __forceinline__ size_t st_off(int j, size_t row, size_t rows) { return ((size_t)(j >> 1) * rows + row) * 4 + (size_t)(j & 1) * 2; }
+
 // sum over the 8 lanes of an aligned octet (lanes 8j .. 8j+7), every lane of the octet gets it: xor 1, xor 2 as quad permutes, then the mirror of the half row
 __device__ __forceinline__ float oct_sum(float v) {
 #if __HIP_DEVICE_COMPILE__
@@ -58,12 +62,12 @@ __device__ __forceinline__ void ct_job_block(const CtJob& j, const int blk, cons
     const bool tln = j.txt_g != nullptr && !j.skip_text;
     if (tln) {
         const int np = D >> 5, c16 = lane & 7;
-        const float* sp = j.txt_st + (size_t)b * j.txt_st_bs * np * 2;
+        const size_t srow = (size_t)b * j.txt_st_bs;
         float2 rs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int jj = c16 + 8 * k;
-            rs[k] = jj < np ? *reinterpret_cast<const float2*>(sp + jj * 2) : make_float2(0.f, 0.f);
+            rs[k] = jj < np ? *reinterpret_cast<const float2*>(j.txt_st + st_off(jj, srow, (size_t)j.txt_st_rows)) : make_float2(0.f, 0.f);
         }
         float s1 = (rs[0].x + rs[1].x) + (rs[2].x + rs[3].x), s2 = (rs[0].y + rs[1].y) + (rs[2].y + rs[3].y);
         s1 = oct_sum(s1);

@@ -253,19 +253,28 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     GLDS_STAMP(1);
     f32x4 bias_v[TN][4];
     gemm_bias_preload<TN>(p, n0 + wn * WN, lane, g, sk, bias_v);     // older than every DMA: retired by the first tile wait
-    f32x4 lnf_cs[LNF ? 4 : 1], lnf_st[LNF ? 8 : 1];
+    f32x4 lnf_cs[LNF ? 4 : 1];
+    f32x4 lnf_st[LNF ? 8 : 1];
+    const float* lnf_sp[LNF ? 8 : 1];
     if constexpr (LNF) {
         static_assert(TM * TN == 1 && !CONV && !PROD, "LayerNorm-folded form: the 64 x 64 tile");
         const float* cp = p.colsum + n0 + wn * WN;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lnf_cs[q] = *reinterpret_cast<const f32x4*>(cp + 8 * q + 4 * (lane >> 5));
-        // lane l owns row l & 31 of the wave's block; its half (l >> 5) of the row's np partial pairs = np floats = np / 4 loads of 16 bytes (np = K / 32 <= 32)
-        const int np = p.K >> 5, n4 = np >> 2;
+        for (int q = 0; q < 4; ++q)
+#ifdef LNF_ABL_NOCS
+            lnf_cs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+            lnf_cs[q] = *reinterpret_cast<const f32x4*>(cp + 8 * q + 4 * (lane >> 5));
+#endif
+        // lane l owns row l & 31 of the wave's block and sums its half (l >> 5) of the row's np partial pairs: np / 4 loads of 16 bytes = two pairs each (fold.h::st_off:
+        // plane pairs), the 32 lanes of a half reading 32 consecutive rows = 512 contiguous bytes per instruction (np = K / 32 <= 32, np % 4 == 0).  They are REQUESTED
+        // behind the prologue's LDS-DMA (below): in front of it they delayed the first tiles of every workgroup (+1..2.7 us per launch on UVLTrack-L's 672-896 workgroups)
+        const int np = p.K >> 5, nq = np >> 2;
         int row = m0 + wm * WM + (lane & 31);
         row = row < p.M ? row : p.M - 1;
-        const float* sp = p.st_in + ((size_t)row * np + (size_t)(lane >> 5) * (np >> 1)) * 2;
+        const float* sp = p.st_in + st_off((lane >> 5) * (np >> 1), (size_t)row, (size_t)p.M);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lnf_st[i] = *reinterpret_cast<const f32x4*>(i < n4 ? sp + 4 * i : reinterpret_cast<const float*>(g_zero_page));
+        for (int i = 0; i < 8; ++i) lnf_sp[i] = i < nq ? sp + (size_t)i * p.M * 4 : reinterpret_cast<const float*>(g_zero_page);
     }
 
     f32x16 acc[TM][TN];
@@ -281,6 +290,19 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
 #pragma unroll
         for (int t = 0; t < NS - 1; ++t)
             if (t < nk) issue(t, true, PRE != 2);          // PRE == 2: the weight halves are in LDS already (the grid barrier drained them)
+    }
+    if constexpr (LNF) {
+        // the rows' partial statistics: eight 16-byte loads per lane, younger than the prologue's tiles and older than every tile requested inside the loop -- the loop's
+        // counted waits for tiles 0 .. NS - 2 allow for them (inline asm: hipcc neither moves them across the LDS-DMA nor waits for them; the last tile's vmcnt(0) does)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#ifdef LNF_ABL_NOSTATS
+            lnf_st[i] = f32x4{1.0f, 2.0f, 1.0f, 2.0f};
+#else
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnf_st[i]) : "v"(lnf_sp[i]) : "memory");
+#endif
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (PROD && producer) {
         // producer waves: wait for the own pieces of tile kt, meet the consumers, request tile kt + NS - 1 into the stage they left
@@ -306,6 +328,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
             if (PRE == 2 && kt == 0 && ahead >= NS - 2) wait_vmcnt<LPT_A * (NS - 2)>();
             else if (PRE == 2 && kt == 1 && ahead >= NS - 2) wait_vmcnt<LPT_A * (NS - 3) + LPT>();
             else if (PRE == 2 && kt < NS - 2) wait_vmcnt<0>();
+            else if (LNF && kt <= NS - 2 && ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2) + 8>();        // (+ the eight statistics loads behind the prologue's tiles)
+            else if (LNF && kt <= NS - 2 && NS > 3 && ahead == 1) wait_vmcnt<LPT + 8>();
             else if (ahead >= NS - 2) wait_vmcnt<LPT * (NS - 2)>();
             else if (NS > 5 && ahead == 3) wait_vmcnt<LPT * 3>();
             else if (NS > 4 && ahead == 2) wait_vmcnt<LPT * 2>();

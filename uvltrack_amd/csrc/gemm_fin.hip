@@ -49,7 +49,7 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
     const int m0 = mt * 64, n0 = nt * BN;
     const int kspan = p.K / G, kbase = grp * kspan, nk = kspan >> 6;
 
-    // ---- what the finishing step of this wave needs and the K loop does not produce: requested now, older than every LDS-DMA, retired by the first tile wait ----
+    // ---- what the finishing step of this wave needs and the K loop does not produce (addresses now; the loads go out behind the prologue's tiles, see below) ----
     // wave (grp, wave) finishes rows grp * (32 / G) + it * 8 + (lane >> 3) of block `wave`: 16 bytes (4 columns) per lane, 8 lanes = one 128-byte line
     const int c16 = lane & 7;
     const int col = n0 + wn * 32 + c16 * 4;
@@ -59,7 +59,8 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
     size_t xrow[ITS], nrow[ITS];
     int grow[ITS];
     f32x4 ov[ITS], tv[ITS];
-    float2 rs[ITS][4];
+    f32x2 rs[ITS][4];
+    const float *ov_p[ITS], *tv_p[ITS], *rs_p[ITS][4];
     const bool recon = p.res_st != nullptr;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
@@ -70,20 +71,19 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
         grow[it] = rc;
         xrow[it] = (size_t)b * p.obs + p.oro + rem;
         nrow[it] = (size_t)b * p.xn_bs + p.xn_ro + rem;
-        const float* xp = p.accumulate ? reinterpret_cast<const float*>(p.C) + xrow[it] * p.ldc + col : zero;
-        ov[it] = *reinterpret_cast<const f32x4*>(xp);
-        const float* tp = p.addtab ? p.addtab + (size_t)(p.addtab_split ? (rem >= p.addtab_split ? 1 : 0) : rem) * p.N + col : zero;
-        tv[it] = *reinterpret_cast<const f32x4*>(tp);
+        ov_p[it] = p.accumulate ? reinterpret_cast<const float*>(p.C) + xrow[it] * p.ldc + col : zero;
+        tv_p[it] = p.addtab ? p.addtab + (size_t)(p.addtab_split ? (rem >= p.addtab_split ? 1 : 0) : rem) * p.N + col : zero;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = c16 + 8 * k;
-            const float* sp = (recon && j < np) ? p.res_st + (nrow[it] * np + j) * 2 : zero;
-            rs[it][k] = *reinterpret_cast<const float2*>(sp);
+            rs_p[it][k] = (recon && j < np) ? p.res_st + st_off(j, nrow[it], (size_t)p.st_rows) : zero;
         }
     }
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias ? p.bias + col : zero);
-    const f32x4 rg4 = *reinterpret_cast<const f32x4*>(recon ? p.res_g + col : zero);
-    const f32x4 rb4 = *reinterpret_cast<const f32x4*>(recon ? p.res_b + col : zero);
+    const float* bias_p = p.bias ? p.bias + col : zero;
+    const float* rg_p = recon ? p.res_g + col : zero;
+    const float* rb_p = recon ? p.res_b + col : zero;
+    f32x4 bias4, rg4, rb4;
+    constexpr int NLATE = ITS * 6 + 3;               // loads per lane requested behind the prologue's LDS-DMA (see below)
 
     // ---- K loop of this wave group: gemm_glds_body's loop for one 32 x 32 block per wave (fragment reads first, the LDS-DMA of the next free stage under their
     //      round trip, four MFMAs); instruction i of wave w fills stage rows [8 (w + WPG i), + 8): A rows first, then W rows ----
@@ -126,9 +126,26 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) issue(t);
+    // what the finishing step needs and the K loop does not produce (residual rows, table term, the residual's partials, bias, the residual LayerNorm's gamma / beta):
+    // requested BEHIND the prologue's tiles -- in front of them they delayed the first tile of every workgroup -- and older than every tile requested inside the loop; the
+    // counted waits for tiles 0 .. NS - 2 allow for these NLATE loads (inline asm: hipcc neither moves them across the LDS-DMA nor waits for them; the last tile's vmcnt(0) does)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ov[it]) : "v"(ov_p[it]) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tv[it]) : "v"(tv_p[it]) : "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rs[it][k]) : "v"(rs_p[it][k]) : "memory");
+    }
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias4) : "v"(bias_p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rg4) : "v"(rg_p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb4) : "v"(rb_p) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt;
-        if (ahead >= NS - 2) fin_wait_vmcnt<LPT * (NS - 2)>();
+        if (kt <= NS - 2 && ahead >= NS - 2) fin_wait_vmcnt<LPT * (NS - 2) + NLATE>();
+        else if (kt <= NS - 2 && NS > 3 && ahead == 1) fin_wait_vmcnt<LPT + NLATE>();
+        else if (ahead >= NS - 2) fin_wait_vmcnt<LPT * (NS - 2)>();
         else if (NS > 3 && ahead == 1) fin_wait_vmcnt<LPT>();
         else fin_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -172,7 +189,7 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
         f32x4 res = ov[it];
         if (recon) {
             // the stored row is pre-norm: the residual is its LayerNorm (statistics from the row's partials, all np of them across the octet)
-            float s1 = (rs[it][0].x + rs[it][1].x) + (rs[it][2].x + rs[it][3].x), s2 = (rs[it][0].y + rs[it][1].y) + (rs[it][2].y + rs[it][3].y);
+            float s1 = (rs[it][0][0] + rs[it][1][0]) + (rs[it][2][0] + rs[it][3][0]), s2 = (rs[it][0][1] + rs[it][1][1]) + (rs[it][2][1] + rs[it][3][1]);
             s1 = oct_sum(s1);
             s2 = oct_sum(s2);
             float mean, rstd;
@@ -199,7 +216,7 @@ __device__ __forceinline__ void gemm_fin_body(const GemmParams& p, const int bx,
                 *reinterpret_cast<f32x4*>(xp) = v;
                 if (p.xn) *reinterpret_cast<uint2*>(p.xn + nrow[it] * p.N + col) = uint2{lo, hi};
             }
-            if (p.st_out && c16 == 0) *reinterpret_cast<float2*>(p.st_out + (nrow[it] * np + ((n0 >> 5) + wn)) * 2) = float2{s1, s2};
+            if (p.st_out && c16 == 0) *reinterpret_cast<float2*>(p.st_out + st_off((n0 >> 5) + wn, nrow[it], (size_t)p.st_rows)) = float2{s1, s2};
         }
     }
 }
@@ -410,7 +427,7 @@ hipError_t launch_conv_fin(const GemmParams& p_in, hipStream_t s) {
 
 bool gemm_fin_ok(const GemmParams& p) {
     return p.M > 0 && p.epi == EPI_F32 && p.N > 0 && p.N % 64 == 0 && p.K >= 128 && p.K % 128 == 0 && p.conv_F == 0 && p.groups <= 1 && p.splitk <= 1 && p.C != nullptr &&
-           (!p.res_st || (p.res_g && p.res_b && p.N <= 1024 && p.accumulate)) && (!(p.xn || p.st_out) || p.N % 32 == 0);
+           (!p.res_st || (p.res_g && p.res_b && p.N <= 1024 && p.accumulate)) && (!(p.xn || p.st_out) || p.N % 32 == 0) && (!(p.st_out || p.res_st) || p.st_rows > 0);
 }
 
 // Tile width: 64 x 32 tiles on four wave groups while they are at most one workgroup per CU (uvl_tuning.fin_w: 0 = always 64 x 64, 1 = always 64 x 32)

@@ -47,17 +47,18 @@ struct GemmParams {
     int kspan = 0;                               // K / splitk
     int rider_first = 1;                         // pair launches of one-sequence frames (gemm_glds_pair_kernel): this problem, as the RIDER, takes the first block indices
     // ---- LayerNorm-free frames (round 6; gemm_fin.hip and the LNF forms of gemm.hip) -------------------------------------------------------------------
-    // Row statistics travel as PARTIALS: st[(row * np + j) * 2 + {0, 1}] = (sum, sum of squares) of the f32 values of columns [32 j, 32 j + 32) of
-    // a row (taken before the row is rounded to bf16), np = D / 32.  Whoever writes a bf16 row that a LayerNorm-folded GEMM will read leaves them; that GEMM adds them up (mean / rstd per row).
+    // Row statistics travel as PARTIALS: st[fold.h::st_off(j, row, rows) + {0, 1}] = [j / 2][row][j % 2][.] = (sum, sum of squares) of the f32 values of columns [32 j, 32 j + 32) of
+    // a row (taken before the row is rounded to bf16), j < np = D / 32, `rows` = the row count of the array (plane j holds all rows: the lanes of a consumer wave,
+    // one row each, then read CONSECUTIVE addresses -- row-major partials made every statistics load touch 64 lines and cost the UVLTrack-L QKV / fc1 launches +2.7 us).  Whoever writes a bf16 row that a LayerNorm-folded GEMM will read leaves them; that GEMM adds them up (mean / rstd per row).
     // Producer side (launch_gemm_fin: x (+)= A W^T + b finished in the launch, no slabs):
     bf16_t* xn = nullptr; int xn_bs = 0, xn_ro = 0;   // bf16 copy of the finished rows: GEMM row (b, t) -> xn row b * xn_bs + xn_ro + t, [., N]
-    float* st_out = nullptr;                     // partials of those rows, indexed like xn
+    float* st_out = nullptr; int st_rows = 0;    // partials of those rows, row index like xn, st_rows = rows per plane (= M of the GEMM that will read them)
     // post-LN residual (bert_backbone.py:335-339,376-380): the residual operand is LayerNorm(row of C) -- C holds the PRE-norm rows u; res_st = partials of
     // u indexed like xn, res_g / res_b / res_eps the LayerNorm; res_copy (optional, [M, N] compact) receives the normalised rows (the text snapshot)
     const float* res_st = nullptr; const float *res_g = nullptr, *res_b = nullptr; float res_eps = 0.f; float* res_copy = nullptr;
     // Consumer side (launch_gemm_lnf: y = act(LayerNorm(a) W^T + b) on A = bf16(a) UN-normalised): W = bf16(W gamma), bias = b + W beta, colsum[n] = sum_k W[n, k]
     // (of the rounded weight), st_in = partials of A's rows (compact index m): y = rstd (acc - mean colsum) + bias
-    const float* st_in = nullptr; const float* colsum = nullptr; float ln_eps = 0.f;
+    const float* st_in = nullptr; const float* colsum = nullptr; float ln_eps = 0.f;      // (st_in: planes of M rows)
 };
 // The contrastive logits of one layer (extractor.py:85-93) as extra workgroups of a GEMM launch (LayerNorm-free frames: the job has no LayerNorm launch to ride on):
 // one wave per search row; the rows are complete in x when the hosting launch starts.
@@ -66,7 +67,7 @@ struct CtJob {
     int nz = 0, nv = 0, nx = 0, skip_text = 0;
     const float* txt = nullptr; int txt_bs = 0;                // text token rows: sample b at txt + b * txt_bs * D (null: row nv of x)
     const float *txt_g = nullptr, *txt_b = nullptr; float txt_eps = 0.f;   // non-null: the text row is PRE-norm, the job normalises it (bert_backbone.py:376-380)
-    const float* txt_st = nullptr; int txt_st_bs = 0;          // ... with the partial statistics of its bf16 copy: sample b's row at txt_st + b * txt_st_bs * (D/32) * 2
+    const float* txt_st = nullptr; int txt_st_bs = 0, txt_st_rows = 0;   // ... with the row's partial statistics: row b * txt_st_bs of planes of txt_st_rows rows
     const float *sub_vis = nullptr, *sub_txt = nullptr;        // the next fusion layer's modal embedding, already added to x by the fc2 epilogue: taken off again
     const int64_t* flag = nullptr; const float* logit_scale = nullptr; float* logits = nullptr; int slot = 0, ncont = 0;
 };
@@ -78,7 +79,7 @@ struct TextJoinParams {
     const float *gamma = nullptr, *beta = nullptr; float eps = 1e-12f;
     float* snap = nullptr;                                     // optional [B*T, D]: the normalised rows
     const float* add = nullptr;                                // optional [D] vector added after the snapshot (modal_embed[1])
-    bf16_t* xn = nullptr; int xn_bs = 0, xn_ro = 0; float* st = nullptr;
+    bf16_t* xn = nullptr; int xn_bs = 0, xn_ro = 0; float* st = nullptr; int st_rows = 0;
     int B = 0, T = 0, D = 0;
 };
 hipError_t launch_text_join(const TextJoinParams& p, hipStream_t s);
@@ -183,8 +184,8 @@ struct PrologueParams {
     // LayerNorm-free frames (fold.h): the [cls] row also as bf16 + partials (row b * cls_xn_bs of cls_xn / cls_st: the first QKV GEMM reads it un-normalised);
     // embed_raw: the BERT embedding row is left PRE-norm (f32 row, bf16 copy in tn, partials in embed_st [B*T, D/32, 2]) -- its LayerNorm (emb_g / emb_b, eps 1e-12)
     // is folded into the first QKV GEMM and applied to the residual by the first attention.output GEMM
-    bf16_t* cls_xn = nullptr; int cls_xn_bs = 0; float* cls_st = nullptr;
-    int embed_raw = 0; float* embed_st = nullptr;
+    bf16_t* cls_xn = nullptr; int cls_xn_bs = 0; float* cls_st = nullptr; int cls_st_rows = 0;
+    int embed_raw = 0; float* embed_st = nullptr;            // (embed_st: planes of B * T rows)
 };
 hipError_t launch_prologue(const PrologueParams& p, hipStream_t s);
 

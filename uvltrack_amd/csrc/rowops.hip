@@ -226,7 +226,7 @@ __device__ __forceinline__ void bert_embed_body(const int64_t* __restrict__ ids,
             if (ok[i]) {
                 *reinterpret_cast<float4*>(xr + c) = v[i];
                 *reinterpret_cast<uint2*>(y + (size_t)m * D + c) = uint2{lo, hi};
-                if ((lane & 7) == 0) *reinterpret_cast<float2*>(raw_st + ((size_t)m * (D >> 5) + (c >> 5)) * 2) = float2{s1, s2};
+                if ((lane & 7) == 0) *reinterpret_cast<float2*>(raw_st + st_off(c >> 5, (size_t)m, (size_t)B * T)) = float2{s1, s2};
             }
         }
         return;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void setup_body(const uint8_t* __restrict__ tmask, co
                                            const float* __restrict__ cls_token, float* __restrict__ x,
                                            float* __restrict__ key_add, float* __restrict__ bert_add,
                                            int nz, int nv, int nj, int npad, int T, int D, int skip_text, int what, int b,
-                                           bf16_t* __restrict__ cls_xn = nullptr, int cls_xn_bs = 0, float* __restrict__ cls_st = nullptr) {
+                                           bf16_t* __restrict__ cls_xn = nullptr, int cls_xn_bs = 0, float* __restrict__ cls_st = nullptr, int cls_st_rows = 0) {
     const int fl = (int)sload_u32(flag + b);                          // low word of the int64 flag
     // the text mask is read unconditionally at a clamped index (no branch around the load, no wait per key group)
     const uint8_t* tm = skip_text ? reinterpret_cast<const uint8_t*>(g_zero_row) : tmask + (size_t)b * T;
@@ -322,7 +322,7 @@ __device__ __forceinline__ void setup_body(const uint8_t* __restrict__ tmask, co
         s2 = oct_sum(s2);
         if (ok) {
             *reinterpret_cast<uint2*>(cls_xn + (size_t)b * cls_xn_bs * D + c) = uint2{lo, hi};
-            if ((threadIdx.x & 7) == 0) *reinterpret_cast<float2*>(cls_st + ((size_t)b * cls_xn_bs * (D >> 5) + (c >> 5)) * 2) = float2{s1, s2};
+            if ((threadIdx.x & 7) == 0) *reinterpret_cast<float2*>(cls_st + st_off(c >> 5, (size_t)b * cls_xn_bs, (size_t)cls_st_rows)) = float2{s1, s2};
         }
     }
 }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const PrologueParams p) {
     kernarg_warm<sizeof(PrologueParams)>();
     const int bx = blockIdx.x;
     if (bx < p.n_setup) {
-        setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, p.skip_text, p.setup_what, bx, p.cls_xn, p.cls_xn_bs, p.cls_st);
+        setup_body(p.text_mask, p.flag, p.cls_token, p.x, p.key_add, p.bert_add, p.nz, p.nv, p.nj, p.npad, p.T, p.D, p.skip_text, p.setup_what, bx, p.cls_xn, p.cls_xn_bs, p.cls_st, p.cls_st_rows);
     } else if (bx < p.n_setup + p.n_embed) {
         bert_embed_body<NV>(p.ids, p.word, p.pos, p.type0, p.emb_g, p.emb_b, p.x, p.nj, p.nv, p.tn, p.B, p.T, p.D, p.vocab, bx - p.n_setup, p.embed_raw ? p.embed_st : nullptr);
     } else {
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(256) void text_join_kernel(const TextJoinParams p) 
             *reinterpret_cast<float4*>(xr + c) = v[i];
             const size_t nrow = (size_t)b * p.xn_bs + p.xn_ro + t;
             if (p.xn) *reinterpret_cast<uint2*>(p.xn + nrow * D + c) = uint2{lo, hi};
-            if (p.st && (lane & 7) == 0) *reinterpret_cast<float2*>(p.st + (nrow * (D >> 5) + (c >> 5)) * 2) = float2{s1, s2};
+            if (p.st && (lane & 7) == 0) *reinterpret_cast<float2*>(p.st + st_off(c >> 5, nrow, (size_t)p.st_rows)) = float2{s1, s2};
         }
     }
 }

@@ -752,7 +752,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     // normalises the text rows where they join the visual rows.  96 -> 72 launches for one UVLTrack-B sequence.  Needs the single-stream frame (riders, or no text
     // branch), the 'cls' text token, a fusion tail (0 < nf < depth); tests cut below the first fusion layer on the LayerNorm-kernel schedule.
     const bool fold = m->fold_ln && B == 1 && (paired || skip || reuse) && !m->cfg.txt_token_mean && m->fuse_contrast && m->nf > 0 && m->nf < m->depth &&
-                      m->D % 128 == 0 && (m->debug_stop_layer < 0 || m->debug_stop_layer >= m->nf) && !m->fuse_ln &&
+                      m->D % 128 == 0 && (m->debug_stop_layer == -1 || m->debug_stop_layer >= m->nf) && !m->fuse_ln &&
                       (long)((B * m->nj + 63) / 64) * (m->D / 64) <= kDispatch.fold_max_tiles && m->tune.gemm_cfg < 0 && m->tune.text_cfg < 0 && !m->vit.empty() && m->vit[0].fqkv;
     // The text branch of a many-sequence frame (B x T rows: 320 at 8 sequences) overlaps the visual layers on the second stream, and what it
     // costs the frame is the CU time of its workgroups: as 64 x 64 tiles (240 workgroups of ~6 us per GEMM at ~15 % MFMA efficiency) that was
@@ -904,7 +904,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         pro.tn = w.Tn; pro.vocab = m->cfg.vocab;
         pro.z = in->d_template; pro.ximg = in->d_search; pro.patches = w.P; pro.Hz = m->cfg.template_size; pro.Hx = m->cfg.search_size;
         if (fold) {         // the [cls] row as layer 0's QKV GEMM reads it; the embedding rows stay pre-norm (their LayerNorm is folded into the first query/key/value GEMM)
-            pro.cls_xn = w.Xn; pro.cls_xn_bs = nv; pro.cls_st = w.St;
+            pro.cls_xn = w.Xn; pro.cls_xn_bs = nv; pro.cls_st = w.St; pro.cls_st_rows = B * nv;
             pro.embed_raw = paired ? 1 : 0; pro.embed_st = w.StT0;
         }
         L.run(s, "prologue", 0, 0, tramp<PrologueParams, launch_prologue>, &pro);
@@ -952,7 +952,8 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         }, &bc);
         L.cur = PART_V1;
     }
-    const int last_bert = (skip || reuse) ? -1 : ((m->debug_stop_layer >= 0 && m->debug_stop_layer < m->nf - 1) ? m->debug_stop_layer : m->nf - 1);
+    // (stop_layer -2: no layer at all -- the residual stream after the patch embedding / the BERT embedding goes straight to the head's output copies: tests localise the input side with it)
+    const int last_bert = (skip || reuse) ? -1 : (m->debug_stop_layer == -2 ? -1 : (m->debug_stop_layer >= 0 && m->debug_stop_layer < m->nf - 1) ? m->debug_stop_layer : m->nf - 1);
     int text_err = 0;
     // one BERT layer (BertLayer.forward, bert_backbone.py:390-394); launched interleaved with the visual layers so both
     // hardware queues are fed in step (the host enqueues ~3.5 us per launch)
@@ -1017,7 +1018,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         p.rpb = nz + nx; p.obs = nj; p.oro = 1; p.addtab = m->pos_tab; p.tune = &m->tune;
         if (pfw && m->depth > 0) { p.pf = fold ? m->vit[0].fqkv : m->vit[0].wqkv; p.pf_bytes = (uint32_t)((size_t)3 * D * D * 2); }
         if (fold) {         // finished in the launch, + the bf16 rows and partial statistics layer 0's QKV GEMM reads (its norm1 is folded into that GEMM)
-            p.xn = w.Xn; p.xn_bs = nv; p.xn_ro = 1; p.st_out = w.St;
+            p.xn = w.Xn; p.xn_bs = nv; p.xn_ro = 1; p.st_out = w.St; p.st_rows = B * nv;
             L.wb_next = 2.0 * (double)p.N * p.K;
             L.run(s, "gemm.patch", 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K) + 6.0 * p.M * p.N,
                   [](void* c, hipStream_t q) { return launch_gemm_fin(*(const GemmParams*)c, nullptr, q); }, &p);
@@ -1083,7 +1084,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 tj.alt = reuse ? w.TxtSnap + (size_t)(m->nf - 1) * Mt * D : nullptr;
                 tj.gamma = m->bert[m->nf - 1].ln2g; tj.beta = m->bert[m->nf - 1].ln2b; tj.eps = 1e-12f;
                 tj.snap = reuse ? nullptr : w.TxtSnap + (size_t)(m->nf - 1) * Mt * D;
-                tj.add = m->modal + D; tj.xn = w.Xn; tj.xn_bs = nj; tj.xn_ro = nv; tj.st = w.St;
+                tj.add = m->modal + D; tj.xn = w.Xn; tj.xn_bs = nj; tj.xn_ro = nv; tj.st = w.St; tj.st_rows = B * nj;
                 L.run(s, "layernorm", 0, (double)Mt * D * 14, tramp<TextJoinParams, launch_text_join>, &tj);
             }
             const BertLayerW* bw = rider ? &m->bert[i] : nullptr;
@@ -1117,12 +1118,12 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
             {   // x += attn.proj(o) (block.py:29-30,44), finished in the launch; rider: u1 = LayerNorm_prev(u) + attention.output.dense(o) (bert_backbone.py:335-339)
                 GemmParams p;
                 p.A = w.O; p.lda = D; p.W = vw.wproj; p.ldw = D; p.bias = vw.bproj; p.M = M; p.N = D; p.K = D; p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1;
-                p.rpb = N; p.obs = nj; p.oro = 0; p.xn = w.Xn; p.xn_bs = N; p.xn_ro = 0; p.st_out = w.St;
+                p.rpb = N; p.obs = nj; p.oro = 0; p.xn = w.Xn; p.xn_bs = N; p.xn_ro = 0; p.st_out = w.St; p.st_rows = M;
                 if (pfw) { p.pf = vw.ffc1; p.pf_bytes = (uint32_t)((size_t)Fn * D * 2); }
                 GemmParams t;
                 if (rider) {
                     t.A = w.To; t.lda = D; t.W = bw->wao; t.ldw = D; t.bias = bw->bao; t.M = Mt; t.N = D; t.K = D; t.epi = 1; t.C = w.X; t.ldc = D; t.accumulate = 1;
-                    t.rpb = T; t.obs = nj; t.oro = nv; t.xn = w.Tn; t.xn_bs = T; t.xn_ro = 0; t.st_out = w.StT1;
+                    t.rpb = T; t.obs = nj; t.oro = nv; t.xn = w.Tn; t.xn_bs = T; t.xn_ro = 0; t.st_out = w.StT1; t.st_rows = Mt;
                     // the residual is the LayerNorm in front of this layer applied to the stored pre-norm rows: the embedding LayerNorm (layer 0) or output.LayerNorm of layer i - 1
                     t.res_st = w.StT0; t.res_g = i == 0 ? m->emb_g : m->bert[i - 1].ln2g; t.res_b = i == 0 ? m->emb_b : m->bert[i - 1].ln2b; t.res_eps = 1e-12f;
                     if (i > 0 && is_cont_layer(i - 1) && out->d_logits) t.res_copy = w.TxtSnap + (size_t)(i - 1) * Mt * D;      // layer i - 1's text rows, for frames that reuse the branch
@@ -1146,7 +1147,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 GemmParams p;
                 p.A = w.Hb; p.lda = Fn; p.W = vw.wfc2; p.ldw = Fn; p.bias = vw.bfc2; p.M = M; p.N = D; p.K = Fn; p.epi = 1; p.C = w.X; p.ldc = D; p.accumulate = 1;
                 p.rpb = N; p.obs = nj; p.oro = 0;
-                if (!last) { p.xn = w.Xn; p.xn_bs = Nn; p.xn_ro = 0; p.st_out = w.St; }
+                if (!last) { p.xn = w.Xn; p.xn_bs = Nn; p.xn_ro = 0; p.st_out = w.St; p.st_rows = B * Nn; }
                 if (next_joint) { p.addtab = m->modal; p.addtab_split = nv; }
                 if (pfw) {
                     p.pf = (i + 1 < m->depth && !last) ? (const void*)m->vit[i + 1].fqkv : (const void*)m->conv[0].w;
@@ -1155,7 +1156,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 GemmParams t;
                 if (rider) {
                     t.A = w.Th; t.lda = Fn; t.W = bw->wo; t.ldw = Fn; t.bias = bw->bo; t.M = Mt; t.N = D; t.K = Fn; t.epi = 1; t.C = w.X; t.ldc = D; t.accumulate = 1;
-                    t.rpb = T; t.obs = nj; t.oro = nv; t.xn = w.Tn; t.xn_bs = T; t.xn_ro = 0; t.st_out = w.StT0;
+                    t.rpb = T; t.obs = nj; t.oro = nv; t.xn = w.Tn; t.xn_bs = T; t.xn_ro = 0; t.st_out = w.StT0; t.st_rows = Mt;
                     t.res_st = w.StT1; t.res_g = bw->ln1g; t.res_b = bw->ln1b; t.res_eps = 1e-12f;
                 }
                 run_fin("gemm.fc2", p, rider ? &t : nullptr);
@@ -1172,7 +1173,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                         if (i == m->nf - 1 || reuse) { ctj.txt = w.TxtSnap + (size_t)i * Mt * D; ctj.txt_bs = T; }       // normalised rows: the text join's / an earlier frame's snapshot
                         else {                 // the pre-norm rows the output GEMM has just left, normalised by the job (the same bits the snapshot will hold)
                             ctj.txt = w.X + (size_t)nv * D; ctj.txt_bs = nj; ctj.txt_g = m->bert[i].ln2g; ctj.txt_b = m->bert[i].ln2b; ctj.txt_eps = 1e-12f;
-                            ctj.txt_st = w.StT0; ctj.txt_st_bs = T;
+                            ctj.txt_st = w.StT0; ctj.txt_st_bs = T; ctj.txt_st_rows = Mt;
                         }
                     }
                     ctj.flag = in->d_flag; ctj.logit_scale = m->logit_scale_bb; ctj.logits = out->d_logits; ctj.slot = cont_slot; ctj.ncont = m->cfg.n_cont;
@@ -1192,6 +1193,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
         if (have_ct) return fail(UVL_ESTATE, "internal: logits job left unlaunched");
     } else
     for (int i = 0; i < m->depth; ++i) {
+        if (m->debug_stop_layer == -2) break;
         const bool joint = i >= m->nf;
         const int N = (joint && !skip) ? nj : nv;
         const int M = B * N;
@@ -1753,7 +1755,7 @@ extern "C" int uvl_linear_fin(const void* d_a, const void* d_w, const float* d_b
     GemmParams p;
     p.tune = tune;
     p.A = (const bf16_t*)d_a; p.lda = K; p.W = (const bf16_t*)d_w; p.ldw = K; p.bias = d_bias; p.M = M; p.N = N; p.K = K; p.epi = 1; p.C = d_x; p.ldc = N; p.accumulate = accumulate ? 1 : 0;
-    p.xn = (bf16_t*)d_xn; p.xn_bs = 0; p.xn_ro = 0; p.st_out = d_stats;
+    p.xn = (bf16_t*)d_xn; p.xn_bs = 0; p.xn_ro = 0; p.st_out = d_stats; p.st_rows = M;
     p.res_st = d_res_stats; p.res_g = d_res_gamma; p.res_b = d_res_beta; p.res_eps = res_eps; p.res_copy = d_res_copy;
     if (!gemm_fin_ok(p)) return fail(UVL_EINVAL, "uvl_linear_fin: need N %% 64 == 0, K %% 128 == 0 (and gamma / beta / accumulate with d_res_stats)");
     HIPCHK(launch_gemm_fin(p, nullptr, (hipStream_t)stream));
