@@ -37,6 +37,7 @@ from scipy.special import erf as _erf
 f32 = np.float32
 _EMU = False          # bf16-emulating mode (see the module docstring)
 _FOLD = False         # ... with the LayerNorm-free frame's rounding points (norm -> Linear folded)
+HEAD_ROUND = {"act": True, "w": True, "from_layer": 0}   # experiments only (tools/head_precision_experiment.py): which operands of the tower layers >= from_layer the emulation rounds
 QSCALE = f32(0.18033688011112042)      # log2(e) / sqrt(64): the HIP attention kernels work in the log2 domain
 
 
@@ -325,9 +326,13 @@ def conv3x3_bn_relu(sd, pre, x):
             cols[:, :, :, :, kh, kw] = xp[:, :, kh:kh + H, kw:kw + W].transpose(0, 2, 3, 1)
     if _EMU:     # BatchNorm folded into the weights before they are rounded (rowops.hip::fold_conv_bn_kernel), bf16 activations
         scale = (sd[pre + "1.weight"] / np.sqrt(sd[pre + "1.running_var"] + f32(1e-5))).astype(f32)
-        wf = bf16_round(w * scale[:, None, None, None])
+        layer = int(pre.rstrip(".").rsplit(".", 1)[1])
+        rnd = layer >= HEAD_ROUND["from_layer"]
+        wf = (w * scale[:, None, None, None]).astype(f32)
+        if rnd and HEAD_ROUND["w"]:
+            wf = bf16_round(wf)
         bf = ((b - sd[pre + "1.running_mean"]) * scale + sd[pre + "1.bias"]).astype(f32)
-        y = bf16_round(cols).reshape(B * H * W, C * 9) @ wf.reshape(w.shape[0], -1).T + bf
+        y = (bf16_round(cols) if (rnd and HEAD_ROUND["act"]) else cols).reshape(B * H * W, C * 9) @ wf.reshape(w.shape[0], -1).T + bf
         return np.maximum(y, f32(0.0)).astype(f32).reshape(B, H, W, -1).transpose(0, 3, 1, 2)
     y = cols.reshape(B * H * W, C * 9) @ w.reshape(w.shape[0], -1).T + b
     y = (y - sd[pre + "1.running_mean"]) / np.sqrt(sd[pre + "1.running_var"] + f32(1e-5)) * sd[pre + "1.weight"] + sd[pre + "1.bias"]
