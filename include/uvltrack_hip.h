@@ -266,9 +266,11 @@ int uvl_debug_set(uvl_model_t* m, const char* key, int value);
  *              and phase over eight K tiles (gemm.hip::gemm_pipe128_body, PRE); 2 = at every K
  *   fin_w      tile of the finishing residual GEMMs of LayerNorm-free frames (gemm_fin.hip): 0 = 64 x 64 on two wave groups, 1 = 64 x 32 on four; default: 64 x 32 while
  *              its tiles are at most one workgroup per CU; 2 = additionally keep the split-K slab form for every layer of the conv towers (A/B)
+ *   lnf_w      tile of the LayerNorm-folded QKV / fc1 GEMMs of LayerNorm-free frames (gemm.hip LNF): 0 = 64 x 64 / four stages, 1 = 64 x 128 / two stages, 2 = 64 x 128 / three stages;
+ *              default: 64 x 128 where the grid would exceed two 64 x 64 tiles per CU (one UVLTrack-L sequence)
  * uvl_tuning_init fills a struct with -1.  Keys of uvl_tune_set are the field names. */
 typedef struct uvl_tuning {
-    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_dr, res_pre, fin_w;
+    int32_t gemm_cfg, gemm_gm, gemm_prod, gemm_big, gemm_kxcd, attn_cfg, sk_k1, sk_k4, gemm_pipe, ring1, text_cfg, res_store, slab_store, attn_wgs, gemm_dr, res_pre, fin_w, lnf_w;
 } uvl_tuning;
 void uvl_tuning_init(uvl_tuning* t);
 int uvl_tune_set(uvl_model_t* m, const char* key, int value);
@@ -346,9 +348,9 @@ int uvl_fold_ln_linear(const float* d_w, const float* d_bias, const float* d_gam
 int uvl_linear_fin(const void* d_a, const void* d_w, const float* d_bias, float* d_x, void* d_xn, float* d_stats, int M, int N, int K, int accumulate,
                    const float* d_res_stats, const float* d_res_gamma, const float* d_res_beta, float res_eps, float* d_res_copy, const uvl_tuning* tune, void* stream);
 int uvl_linear_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps, void* d_y,
-                   int M, int N, int K, int act, void* stream);
+                   int M, int N, int K, int act, const uvl_tuning* tune, void* stream);
 int uvl_qkv_project_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps,
-                        void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream);
+                        void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune, void* stream);
 
 /* f32 -> bf16 (round to nearest even) helper for tests. */
 int uvl_f32_to_bf16(const float* d_in, void* d_out, size_t n, void* stream);

@@ -108,8 +108,9 @@ def test_linear_fin_post_layernorm_residual(lib, M, N, K, fw):
     assert torch.equal(xn, x.bfloat16())
 
 
+@pytest.mark.parametrize("form", [None, 0, 1, 2], ids=["auto", "64x64", "64x128/2", "64x128/3"])
 @pytest.mark.parametrize("M,N,K,act", [(553, 3072, 768, 1), (553, 2304, 768, 0), (40, 3072, 768, 1), (873, 4096, 1024, 1), (29, 512, 128, 1), (1106, 3072, 768, 1), (65, 64, 256, 0)])
-def test_linear_lnf_matches_layernorm_then_linear(lib, M, N, K, act):
+def test_linear_lnf_matches_layernorm_then_linear(lib, M, N, K, act, form):
     """norm -> Linear (-> GELU) as ONE GEMM on the un-normalised bf16 rows, against LayerNorm(fp32) -> Linear in fp32, and no worse than ~1.5x the
     LayerNorm-kernel path (uvl_layernorm -> uvl_linear) on rows with a non-zero mean and 20x outlier channels."""
     x = _rows_with_mean_and_outliers(M, K, 21)
@@ -133,7 +134,9 @@ def test_linear_lnf_matches_layernorm_then_linear(lib, M, N, K, act):
     xb = x.bfloat16()
     st = _partials(x)
     y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_linear_lnf(_p(xb), _p(st), _p(wf), _p(bf), _p(cs), C.c_float(eps), _p(y), M, N, K, act, _stream()), lib)
+    from uvltrack_amd import _native
+    tune = _native.UvlTuning(lnf_w=form).ref() if form is not None else None      # tile form of the folded GEMM (64 x 128 needs N % 128 == 0, else 64 x 64)
+    _chk(lib.uvl_linear_lnf(_p(xb), _p(st), _p(wf), _p(bf), _p(cs), C.c_float(eps), _p(y), M, N, K, act, tune, _stream()), lib)
     # the LayerNorm-kernel path on the same operands
     xn = torch.empty((M, K), dtype=torch.bfloat16, device="cuda")
     _chk(lib.uvl_layernorm(_p(x), _p(g), _p(be), C.c_float(eps), _p(xn), None, M, K, _stream()), lib)
@@ -150,8 +153,9 @@ def test_linear_lnf_matches_layernorm_then_linear(lib, M, N, K, act):
     assert bool((err <= 2e-2 * ref.abs() + 8e-2).all()), "max err %g" % float(err.max())
 
 
+@pytest.mark.parametrize("form", [None, 0, 1, 2], ids=["auto", "64x64", "64x128/2", "64x128/3"])
 @pytest.mark.parametrize("B,H,N", [(1, 12, 553), (1, 16, 873), (1, 2, 29), (2, 12, 553)])
-def test_qkv_project_lnf(lib, B, H, N):
+def test_qkv_project_lnf(lib, B, H, N, form):
     D = H * 64
     Npad = (N + 63) // 64 * 64
     x = _rows_with_mean_and_outliers(B * N, D, 31)
@@ -169,7 +173,9 @@ def test_qkv_project_lnf(lib, B, H, N):
     q = torch.full((B, H, Npad, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     k = torch.full_like(q, float("nan"))
     vt = torch.full((B, H, 64, Npad), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _chk(lib.uvl_qkv_project_lnf(_p(xb), _p(st), _p(wf), _p(bf), _p(cs), C.c_float(1e-6), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(qs), _stream()), lib)
+    from uvltrack_amd import _native
+    tune = _native.UvlTuning(lnf_w=form).ref() if form is not None else None
+    _chk(lib.uvl_qkv_project_lnf(_p(xb), _p(st), _p(wf), _p(bf), _p(cs), C.c_float(1e-6), _p(q), _p(k), _p(vt), B, N, Npad, D, C.c_float(qs), tune, _stream()), lib)
     torch.cuda.synchronize()
     qkv = (torch.nn.functional.layer_norm(x, (D,), g, be, 1e-6) @ w.t() + b).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     for got, ref in ((q[:, :, :N], qkv[0] * qs), (k[:, :, :N], qkv[1]), (vt[:, :, :, :N].transpose(2, 3), qkv[2])):

@@ -38,5 +38,5 @@ for (M, N, K) in [(553, 3072, 768), (553, 2304, 768), (873, 4096, 1024), (873, 3
     stt = torch.stack([r.sum(-1), (r * r).sum(-1)], -1).permute(1, 0, 2, 3).contiguous()
     y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     t_plain = bench(lambda: lib.uvl_linear(p(xb), p(w), p(b), p(y), M, N, K, 1, 0, 0, None, st()))
-    t_lnf = bench(lambda: lib.uvl_linear_lnf(p(xb), p(stt), p(w), p(b), p(cs), C.c_float(1e-6), p(y), M, N, K, 1, st()))
+    t_lnf = bench(lambda: lib.uvl_linear_lnf(p(xb), p(stt), p(w), p(b), p(cs), C.c_float(1e-6), p(y), M, N, K, 1, None, st()))
     print("M %4d N %4d K %4d   plain %.2f us   lnf %.2f us   (%+.2f)" % (M, N, K, t_plain, t_lnf, t_lnf - t_plain), flush=True)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libuvltrack_hip.so")
 
 UVL_MAX_LAYERS = 64
 UVL_NFAM = 5
-UVL_ABI_VERSION = 3      # uvl_version(): bumped whenever a struct of include/uvltrack_hip.h changes size (3: uvl_tuning.res_pre / fin_w, the LayerNorm-free entry points)
+UVL_ABI_VERSION = 4      # uvl_version(): bumped whenever a struct of include/uvltrack_hip.h changes size (3: uvl_tuning.res_pre / fin_w, the LayerNorm-free entry points)
 
 # every symbol include/uvltrack_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
@@ -57,7 +57,7 @@ class UvlCropGeometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("crop_sz", "x1", "y1", "x1_pad", "x2_pad", "y1_pad", "y2_pad")] + [("resize_factor", C.c_float)]
 
 
-TUNING_FIELDS = ("gemm_cfg", "gemm_gm", "gemm_prod", "gemm_big", "gemm_kxcd", "attn_cfg", "sk_k1", "sk_k4", "gemm_pipe", "ring1", "text_cfg", "res_store", "slab_store", "attn_wgs", "gemm_dr", "res_pre", "fin_w")
+TUNING_FIELDS = ("gemm_cfg", "gemm_gm", "gemm_prod", "gemm_big", "gemm_kxcd", "attn_cfg", "sk_k1", "sk_k4", "gemm_pipe", "ring1", "text_cfg", "res_store", "slab_store", "attn_wgs", "gemm_dr", "res_pre", "fin_w", "lnf_w")
 
 
 class UvlTuning(C.Structure):
@@ -159,8 +159,8 @@ def load():
     lib.uvl_f32_to_bf16.argtypes = [vp, vp, C.c_size_t, vp]
     lib.uvl_fold_ln_linear.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.uvl_linear_fin.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, C.c_float, vp, tp, vp]
-    lib.uvl_linear_lnf.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, vp]
-    lib.uvl_qkv_project_lnf.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
+    lib.uvl_linear_lnf.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, tp, vp]
+    lib.uvl_qkv_project_lnf.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, C.c_float, tp, vp]
     _lib = lib
     return lib
 

@@ -253,18 +253,20 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
     GLDS_STAMP(1);
     f32x4 bias_v[TN][4];
     gemm_bias_preload<TN>(p, n0 + wn * WN, lane, g, sk, bias_v);     // older than every DMA: retired by the first tile wait
-    f32x4 lnf_cs[LNF ? 4 : 1];
+    f32x4 lnf_cs[LNF ? TN : 1][4];
     f32x4 lnf_st[LNF ? 8 : 1];
     const float* lnf_sp[LNF ? 8 : 1];
     if constexpr (LNF) {
-        static_assert(TM * TN == 1 && !CONV && !PROD, "LayerNorm-folded form: the 64 x 64 tile");
+        static_assert(TM == 1 && !CONV && !PROD, "LayerNorm-folded form: one 32-row block per wave (64-row tiles)");
         const float* cp = p.colsum + n0 + wn * WN;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
 #ifdef LNF_ABL_NOCS
-            lnf_cs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                lnf_cs[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #else
-            lnf_cs[q] = *reinterpret_cast<const f32x4*>(cp + 8 * q + 4 * (lane >> 5));
+                lnf_cs[j][q] = *reinterpret_cast<const f32x4*>(cp + j * 32 + 8 * q + 4 * (lane >> 5));
 #endif
         // lane l owns row l & 31 of the wave's block and sums its half (l >> 5) of the row's np partial pairs: np / 4 loads of 16 bytes = two pairs each (fold.h::st_off:
         // plane pairs), the 32 lanes of a half reading 32 consecutive rows = 512 contiguous bytes per instruction (np = K / 32 <= 32, np % 4 == 0).  They are REQUESTED
@@ -405,12 +407,14 @@ __device__ __forceinline__ void gemm_glds_body(const GemmParams& p, const int bx
         st_finish(s1, s2, p.K, p.ln_eps, mean, rstd);
         const float nrm = -rstd * mean;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0][4 * q + e] = rstd * acc[0][0][4 * q + e] + (nrm * lnf_cs[q][e] + bias_v[0][q][e]);
-                bias_v[0][q][e] = 0.f;
-            }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][j][4 * q + e] = rstd * acc[0][j][4 * q + e] + (nrm * lnf_cs[j][q][e] + bias_v[j][q][e]);
+                    bias_v[j][q][e] = 0.f;
+                }
     }
     gemm_epilogue_lds<TM, TN, WM, WN, EPI, NW>(p, acc, smem, m0, n0, wm, wn, lane, wave, g, sk, bias_v);
     GLDS_STAMP(6);
@@ -1349,17 +1353,19 @@ hipError_t launch_gemm_pair(const GemmParams& a, const GemmParams& b, hipStream_
 // workgroups come LAST: dispatched first they held one of the two workgroup slots of 64 CUs while the 324 GEMM tiles were being placed, so more CUs than necessary
 // ended up with two tiles (measured: QKV launch 8.9 us with the job first).
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
+// BN / NS: the visual problem's tile width and ring depth -- 64 x 64 with four stages (two workgroups per CU), or 64 x 128 (a wave = 32 x 64) for grids of more than two 64 x 64 tiles per CU
+// (one UVLTrack-L sequence: 672 / 896 tiles): half the workgroups, every A stage feeds twice the MFMAs.  The rider keeps 64 x 64.
+template <int EPI, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_lnf_kernel(const GemmParams p, const CtJob ct, const int blocks_ct) {
     kernarg_warm<sizeof(GemmParams) + sizeof(CtJob) + 8 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nb = (int)gridDim.x - blocks_ct;           // GEMM tiles first, the job's short workgroups behind them (see the note above)
     if ((int)blockIdx.x >= nb) { ct_job_block(ct, (int)blockIdx.x - nb, g_zero_row); return; }
     const uint32_t pfs = prefetch_issue<256>(p.pf, p.pf_bytes, blockIdx.x, gridDim.x);
-    gemm_glds_body<64, 64, 2, 2, EPI, 4, false, false, 64, 0, 0, true>(p, (int)blockIdx.x, 0, 0, smem);
+    gemm_glds_body<64, BN, 2, 2, EPI, NS, false, false, 64, 0, 0, true>(p, (int)blockIdx.x, 0, 0, smem);
     prefetch_retire(pfs);
 }
-template <int EPI>
+template <int EPI, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_lnf_pair_kernel(const GemmParams pa, const GemmParams pb, const CtJob ct, const int blocks_ct, const int blocks_b) {
     kernarg_warm<2 * sizeof(GemmParams) + sizeof(CtJob) + 8 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1367,7 +1373,7 @@ __global__ __launch_bounds__(256) void gemm_lnf_pair_kernel(const GemmParams pa,
     if (bid >= nb) { ct_job_block(ct, bid - nb, g_zero_row); return; }
     const uint32_t pfs = prefetch_issue<256>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
     if (bid < blocks_b) gemm_glds_body<64, 64, 2, 2, EPI, 4, false, true, 64, 0, 0, true>(pb, bid, 0, 0, smem);       // the rider first: its weight tiles come from HBM (non-temporal)
-    else gemm_glds_body<64, 64, 2, 2, EPI, 4, false, false, 64, 0, 0, true>(pa, bid - blocks_b, 0, 0, smem);
+    else gemm_glds_body<64, BN, 2, 2, EPI, NS, false, false, 64, 0, 0, true>(pa, bid - blocks_b, 0, 0, smem);
     prefetch_retire(pfs);
 }
 
@@ -1375,52 +1381,68 @@ static bool lnf_ok(const GemmParams& p) {
     return p.M > 0 && p.conv_F == 0 && p.groups <= 1 && p.N % 64 == 0 && p.K % 128 == 0 && p.K <= 1024 && p.splitk <= 1 && p.st_in && p.colsum &&
            (p.epi == EPI_BF16 || p.epi == EPI_QKV) && (p.M + 63) / 64 < 64;
 }
-template <int EPI>
+// 0: 64 x 64 tiles, four stages; 1: 64 x 128, two stages (48 KB: three workgroups per CU); 2: 64 x 128, three stages (72 KB: two per CU).  uvl_tuning.lnf_w overrides.
+static int lnf_form(const GemmParams& p) {
+    const int forced = tune_get(p.tune, &uvl_tuning::lnf_w, -1);
+    if (p.N % 128 != 0) return 0;
+    if (forced >= 0 && forced <= 2) return forced;
+    return (long)((p.M + 63) / 64) * (p.N / 64) > 512 ? 1 : 0;
+}
+template <int EPI, int BN, int NS>
 static hipError_t launch_lnf_epi(const GemmParams& a_in, const GemmParams* b_in, const CtJob* ct, hipStream_t s) {
-    auto prep = [](GemmParams& p) {
+    auto prep = [](GemmParams& p, int bn) {
         const int MT = (p.M + 63) / 64;
         p.group_m = MT;                       // N-major runs per XCD (few M tiles: the M tiles of a weight panel share an L2)
-        gemm_derive(p, 64, 64);
-        return 8 * ((MT * (p.N / 64) + 7) / 8);
+        gemm_derive(p, 64, bn);
+        return 8 * ((MT * (p.N / bn) + 7) / 8);
     };
     GemmParams a = a_in;
-    const int ba = prep(a);
+    const int ba = prep(a, BN);
     CtJob job = ct ? *ct : CtJob();
     const int bc = ct ? 8 * ((((job.B * job.nx + 3) / 4) + 7) / 8) : 0;
-    constexpr size_t lds = 4 * (size_t)(64 + 64) * 128;
+    constexpr size_t lds_a = (size_t)NS * (64 + BN) * 128, lds_r = 4 * (size_t)(64 + 64) * 128;
     if (!b_in) {
-        auto kern = gemm_lnf_kernel<EPI>;
+        auto kern = gemm_lnf_kernel<EPI, BN, NS>;
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-        static char name[40];
-        if (!name[0]) snprintf(name, sizeof(name), "gemm_lnf_kernel<%d>", EPI);
+        static char name[48];
+        if (!name[0]) snprintf(name, sizeof(name), "gemm_lnf_kernel<%d,%d,%d>", EPI, BN, NS);
         g_last_kernel = name;
-        hipLaunchKernelGGL(kern, dim3(bc + ba), dim3(256), lds, s, a, job, bc);
+        hipLaunchKernelGGL(kern, dim3(ba + bc), dim3(256), lds_a, s, a, job, bc);
         return hipGetLastError();
     }
     GemmParams b = *b_in;
-    const int bb = prep(b);
-    auto kern = gemm_lnf_pair_kernel<EPI>;
+    const int bb = prep(b, 64);
+    constexpr size_t lds = lds_a > lds_r ? lds_a : lds_r;
+    auto kern = gemm_lnf_pair_kernel<EPI, BN, NS>;
     static bool attr_done2 = false;
     if (!attr_done2) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done2 = true;
     }
-    static char name2[40];
-    if (!name2[0]) snprintf(name2, sizeof(name2), "gemm_lnf_pair_kernel<%d>", EPI);
+    static char name2[48];
+    if (!name2[0]) snprintf(name2, sizeof(name2), "gemm_lnf_pair_kernel<%d,%d,%d>", EPI, BN, NS);
     g_last_kernel = name2;
-    hipLaunchKernelGGL(kern, dim3(bc + bb + ba), dim3(256), lds, s, a, b, job, bc, bb);
+    hipLaunchKernelGGL(kern, dim3(bb + ba + bc), dim3(256), lds, s, a, b, job, bc, bb);
     return hipGetLastError();
 }
 hipError_t launch_gemm_lnf(const GemmParams& a, const GemmParams* b, const CtJob* ct, hipStream_t s) {
     if (!lnf_ok(a) || (b && (!lnf_ok(*b) || b->epi != a.epi))) return hipErrorInvalidValue;
     if (ct && (!ct->x || !ct->logits || !ct->flag || !ct->logit_scale || ct->D % 4 != 0 || ct->D > 1024 || ct->nx <= 0)) return hipErrorInvalidValue;
-    return a.epi == EPI_QKV ? launch_lnf_epi<EPI_QKV>(a, b, ct, s) : launch_lnf_epi<EPI_BF16>(a, b, ct, s);
+    const int form = lnf_form(a);
+    if (a.epi == EPI_QKV) {
+        if (form == 1) return launch_lnf_epi<EPI_QKV, 128, 2>(a, b, ct, s);
+        if (form == 2) return launch_lnf_epi<EPI_QKV, 128, 3>(a, b, ct, s);
+        return launch_lnf_epi<EPI_QKV, 64, 4>(a, b, ct, s);
+    }
+    if (form == 1) return launch_lnf_epi<EPI_BF16, 128, 2>(a, b, ct, s);
+    if (form == 2) return launch_lnf_epi<EPI_BF16, 128, 3>(a, b, ct, s);
+    return launch_lnf_epi<EPI_BF16, 64, 4>(a, b, ct, s);
 }
 
 #ifdef GLDS_TRACE

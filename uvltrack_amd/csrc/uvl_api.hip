@@ -155,7 +155,7 @@ extern "C" void uvl_tuning_init(uvl_tuning* t) {
     for (size_t i = 0; i < sizeof(uvl_tuning) / sizeof(int32_t); ++i) f[i] = -1;
 }
 extern "C" const char* uvl_last_error(void) { return g_err; }
-extern "C" int uvl_version(void) { return 3; }
+extern "C" int uvl_version(void) { return 4; }
 #ifndef UVL_BUILD_TOOLCHAIN
 #define UVL_BUILD_TOOLCHAIN "unknown"
 #endif
@@ -1428,7 +1428,7 @@ extern "C" int uvl_tune_set(uvl_model_t* m, const char* key, int value) {
     static const struct { const char* key; int32_t uvl_tuning::*field; } keys[] = {
         {"gemm_cfg", &uvl_tuning::gemm_cfg}, {"gemm_gm", &uvl_tuning::gemm_gm}, {"gemm_prod", &uvl_tuning::gemm_prod},
         {"gemm_big", &uvl_tuning::gemm_big}, {"gemm_kxcd", &uvl_tuning::gemm_kxcd}, {"attn_cfg", &uvl_tuning::attn_cfg},
-        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}, {"res_pre", &uvl_tuning::res_pre}, {"fin_w", &uvl_tuning::fin_w}};
+        {"sk_k1", &uvl_tuning::sk_k1}, {"sk_k4", &uvl_tuning::sk_k4}, {"gemm_pipe", &uvl_tuning::gemm_pipe}, {"ring1", &uvl_tuning::ring1}, {"text_cfg", &uvl_tuning::text_cfg}, {"res_store", &uvl_tuning::res_store}, {"slab_store", &uvl_tuning::slab_store}, {"attn_wgs", &uvl_tuning::attn_wgs}, {"gemm_dr", &uvl_tuning::gemm_dr}, {"res_pre", &uvl_tuning::res_pre}, {"fin_w", &uvl_tuning::fin_w}, {"lnf_w", &uvl_tuning::lnf_w}};
     for (const auto& k : keys)
         if (!strcmp(key, k.key)) {
             // (cfg 36 on proj / fc2 too needs their weight images: made by the next frame on ITS stream -- run_forward -- not here on the null stream, where the
@@ -1762,18 +1762,20 @@ extern "C" int uvl_linear_fin(const void* d_a, const void* d_w, const float* d_b
     return UVL_OK;
 }
 extern "C" int uvl_linear_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps, void* d_y,
-                              int M, int N, int K, int act, void* stream) {
+                              int M, int N, int K, int act, const uvl_tuning* tune, void* stream) {
     if (!d_a || !d_stats || !d_w_folded || !d_bias_folded || !d_colsum || !d_y) return fail(UVL_EINVAL, "uvl_linear_lnf: null pointer");
     GemmParams p;
+    p.tune = tune;
     p.A = (const bf16_t*)d_a; p.lda = K; p.W = (const bf16_t*)d_w_folded; p.ldw = K; p.bias = d_bias_folded; p.colsum = d_colsum; p.st_in = d_stats; p.ln_eps = eps;
     p.M = M; p.N = N; p.K = K; p.epi = 0; p.C = d_y; p.ldc = N; p.act = act;
     if (launch_gemm_lnf(p, nullptr, nullptr, (hipStream_t)stream) != hipSuccess) return fail(UVL_EINVAL, "uvl_linear_lnf: need N %% 64 == 0, K %% 128 == 0, K <= 1024 (or the launch failed: %s)", hipGetErrorString(hipGetLastError()));
     return UVL_OK;
 }
 extern "C" int uvl_qkv_project_lnf(const void* d_a, const float* d_stats, const void* d_w_folded, const float* d_bias_folded, const float* d_colsum, float eps,
-                                   void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, void* stream) {
+                                   void* d_q, void* d_k, void* d_vt, int B, int N, int Npad, int D, float q_scale, const uvl_tuning* tune, void* stream) {
     if (!d_a || !d_stats || !d_w_folded || !d_bias_folded || !d_colsum || !d_q || !d_k || !d_vt || D % 64 != 0) return fail(UVL_EINVAL, "uvl_qkv_project_lnf: bad argument");
     GemmParams p;
+    p.tune = tune;
     p.A = (const bf16_t*)d_a; p.lda = D; p.W = (const bf16_t*)d_w_folded; p.ldw = D; p.bias = d_bias_folded; p.colsum = d_colsum; p.st_in = d_stats; p.ln_eps = eps;
     p.M = B * N; p.N = 3 * D; p.K = D; p.epi = 2; p.rpb = N; p.q = (bf16_t*)d_q; p.k = (bf16_t*)d_k; p.vt = (bf16_t*)d_vt; p.H = D / 64; p.Npad = Npad; p.D = D; p.q_scale = q_scale;
     if (launch_gemm_lnf(p, nullptr, nullptr, (hipStream_t)stream) != hipSuccess) return fail(UVL_EINVAL, "uvl_qkv_project_lnf: need D %% 128 == 0, D <= 1024 (or the launch failed: %s)", hipGetErrorString(hipGetLastError()));
