@@ -1386,7 +1386,9 @@ static int lnf_form(const GemmParams& p) {
     const int forced = tune_get(p.tune, &uvl_tuning::lnf_w, -1);
     if (p.N % 128 != 0) return 0;
     if (forced >= 0 && forced <= 2) return forced;
-    return (long)((p.M + 63) / 64) * (p.N / 64) > 512 ? 1 : 0;
+    const long tiles = (long)((p.M + 63) / 64) * (p.N / 64);
+    if (forced >= 100) return tiles > forced ? 1 : 0;          // (tools: the tile-count threshold itself)
+    return tiles > 512 ? 1 : 0;
 }
 template <int EPI, int BN, int NS>
 static hipError_t launch_lnf_epi(const GemmParams& a_in, const GemmParams* b_in, const CtJob* ct, hipStream_t s) {
