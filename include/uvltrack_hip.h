@@ -240,7 +240,8 @@ int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
  * one-sequence pair GEMM launch behind the visual tiles.  "text_nt" (default 15): which text-branch GEMMs of frames of up to four sequences load their
  * weights non-temporal -- bit 0 QKV, 1 attention output, 2 intermediate, 3 output (0: none; two UVLTrack-B sequences lose 3.5 % with it, one is level).
  * "bf16_store" (default 3): which bf16 activations of frames of >= 2048 rows are stored write-through -- bit 0 the fc1 output, 1 the q / k rows of QKV, 2 LayerNorm's
- * rows (0: plain stores, the round-4 form: 8 UVLTrack-L sequences lose 2.2 %). */
+ * rows (0: plain stores, the round-4 form: 8 UVLTrack-L sequences lose 2.2 %).  "head_fin" (default 1): 0 keeps the towers' last 3x3 layer and the head tail as two
+ * launches where the one-launch form applies (16 x 16 search features, HEAD_DIM 256: see uvl_head_end). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
 /* Overrides of the launch heuristics, for tools and tests (not part of the product path).  There is NO process-global tuning
@@ -294,6 +295,16 @@ int uvl_linear(const void* d_x, const void* d_w, const float* d_bias, void* d_y,
 int uvl_pack_weight(const void* d_w, void* d_w_packed, int N, int K, void* stream);
 int uvl_linear_pk(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y,
                   int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune, void* stream);
+
+/* The end of ModalityAdaptiveBoxHead.forward (modality_adaptive_box_head.py:71-94) from the towers' third 3x3 layer onwards: the last conv3x3 + BatchNorm(eval) + ReLU
+ * of the four towers (heads/utils.py:126-131; C/4 -> C/8 channels), their 1x1 convs, the sigmoids, the size-map select by flag and convert2bbox (:108-119) incl. the
+ * argmax -- as the frame runs it.  d_g3: bf16 [batch * feat^2][4 * cin] (tower-major channels), d_w_packed / d_bias_folded: uvl_fold_conv_bn's outputs for cout = cin / 2,
+ * d_w1 [7][cin / 2] / d_b1 [7]: the 1x1 weights in the order cls | offset x, y | bbox w, h | bbox_grounding w, h; d_coord: box_head.coodinate [2][feat^2].
+ * form 0: the layer as a conv launch + the tail kernel (any geometry; d_scratch: bf16 [batch * feat^2][4 * cin / 2]); form 1: ONE launch, one workgroup per sample
+ * (16 x 16 features, cin = 64: UVL_EINVAL otherwise; d_scratch: 4 * 32 * 9 * 64 bf16, receives the weights in fragment order).  Outputs may be null except bbox_map. */
+int uvl_head_end(const void* d_g3, int batch, int feat, int cin, const void* d_w_packed, const float* d_bias_folded, const float* d_w1, const float* d_b1,
+                 const float* d_cont_score, int cont_channels, const int64_t* d_flag, const float* d_coord, int offset_sigmoid, int joint_cls, int form, void* d_scratch,
+                 float* d_cls_score, float* d_cls_score_test, float* d_bbox_map, float* d_pred_boxes, int64_t* d_argmax, void* stream);
 
 /* Fused multi-head self-attention core of Attention.forward (block.py:50-58) and BertSelfAttention
  * (bert_backbone.py:311-324): softmax(q k^T / sqrt(64) + key_add) v.

@@ -79,15 +79,15 @@ def test_default_path_of_a_32_sequence_frame_matches_the_reference():
 # BASELINE.json's configs -> (model, template, search, batch, mode, skip_text), the kernels the DEFAULT path must run (prefixes), the ones it must not, launches
 _DISPATCH_CASES = {
     "configs[1] B x1 BBOX, text skipped": (("B", 256, 256, 1, 0, True),
-        ["gemm_fin_kernel<32>", "gemm_lnf_kernel<2,64,4>", "gemm_lnf_kernel<0,64,4>", "attn_kernel<1,9,1>", "conv_fin_kernel<32>", "conv_fin_kernel<64>"],
-        ["ln_", "gemm_fin_pair", "gemm_lnf_pair", "attn_pair", "text_join", "gemm_dr", "gemm_pipe"], 69),
+        ["gemm_fin_kernel<32>", "gemm_lnf_kernel<2,64,4>", "gemm_lnf_kernel<0,64,4>", "attn_kernel<1,9,1>", "conv_fin_kernel<32>", "conv_fin_kernel<64>", "head_fin_kernel"],
+        ["ln_", "gemm_fin_pair", "gemm_lnf_pair", "attn_pair", "text_join", "gemm_dr", "gemm_pipe", "head_tail"], 68),
     "configs[2] B x1 NLBBOX (the headline; configs[0] is the same frame on the reference's CPU path)": (("B", 256, 256, 1, 2, False),
         ["gemm_fin_kernel<32>", "gemm_fin_pair_kernel<32,32>", "gemm_lnf_kernel<2,64,4>", "gemm_lnf_pair_kernel<2,64,4>", "gemm_lnf_pair_kernel<0,64,4>", "attn_pair_kernel<1,9,1>", "attn_kernel<1,9,1>",
-         "text_join_kernel", "conv_fin_kernel<32>", "conv_fin_kernel<64>"],
-        ["ln_", "gemm_dr", "gemm_pipe", "contrast"], 70),
+         "text_join_kernel", "conv_fin_kernel<32>", "conv_fin_kernel<64>", "head_fin_kernel"],
+        ["ln_", "gemm_dr", "gemm_pipe", "contrast", "head_tail"], 69),
     "configs[3] L x1 NLBBOX": (("L", 256, 384, 1, 2, False),
-        ["gemm_fin_kernel<64>", "gemm_fin_pair_kernel<64,32>", "gemm_lnf_pair_kernel<2,128,2>", "gemm_lnf_kernel<0,128,2>", "attn_pair_kernel<2,4,2>", "text_join_kernel", "conv_fin_kernel"],
-        ["ln_", "gemm_dr", "gemm_pipe"], 130),
+        ["gemm_fin_kernel<64>", "gemm_fin_pair_kernel<64,32>", "gemm_lnf_pair_kernel<2,128,2>", "gemm_lnf_kernel<0,128,2>", "attn_pair_kernel<2,4,2>", "text_join_kernel", "conv_fin_kernel", "head_tail"],
+        ["ln_", "gemm_dr", "gemm_pipe", "head_fin"], 130),
     "configs[4] L x8 per GPU NLBBOX": (("L", 256, 384, 8, 2, False),
         ["gemm_dr_pair_kernel<2>", "gemm_dr_pair_kernel<0>", "gemm_dr_kernel<2>", "gemm_dr_kernel<0>", "gemm_pipe_pair_kernel<128,1", "gemm_pipe128_kernel<1,1", "attn_p64_rider_kernel",
          "attn_p64_kernel", "ln_pair_kernel", "ln_kernel"],

@@ -392,6 +392,97 @@ def test_conv_tower_layer(lib, B, F, cin, cout, slabs):
     assert bool((err <= 2e-2 * ref.abs() + 2e-2).all()), "conv tower max err %g" % float(err.max())
 
 
+@pytest.mark.parametrize("B,F,cin,form,cont_ch,offset_sigmoid,joint_cls", [
+    (1, 16, 64, 1, 3, 1, 0), (1, 16, 64, 0, 3, 1, 0), (3, 16, 64, 1, 2, 0, 1), (3, 16, 64, 0, 2, 0, 1), (40, 16, 64, 1, 3, 1, 1),
+    (2, 24, 64, 0, 3, 1, 0), (2, 8, 128, 0, 2, 1, 0)])
+def test_head_end(lib, B, F, cin, form, cont_ch, offset_sigmoid, joint_cls):
+    """The end of the box head from the towers' third layer onwards (last conv3x3 + BN + ReLU, the 1x1 convs, sigmoids, size select by flag, convert2bbox + argmax:
+    modality_adaptive_box_head.py:71-94,108-119) against fp32 torch, as ONE launch (form 1: head_fin_kernel, one workgroup per sample) and as the conv launch +
+    head_tail_kernel (form 0), for flags 0 / 1 / 2, two and three cont_score channels, both offset modes."""
+    S, cout = F * F, cin // 2
+    x = torch.relu(_rand((B, S, 4 * cin), 131, 1.0)).bfloat16()
+    wpk = torch.empty((4, cout, 9 * cin), dtype=torch.bfloat16, device="cuda")
+    bpk = torch.empty((4 * cout,), device="cuda")
+    rows = [1, 2, 2, 2]
+    w1 = torch.cat([_rand((rows[g], cout), 140 + g, 2.0 / math.sqrt(cout)) for g in range(4)]).contiguous()
+    b1 = torch.cat([_rand((7,), 150, 0.3), torch.zeros(1, device="cuda")])
+    maps = []
+    for g in range(4):
+        w = _rand((cout, cin, 3, 3), 40 + g, 1.5 / math.sqrt(9 * cin))
+        b = _rand((cout,), 50 + g, 0.1)
+        bn_w = _rand((cout,), 60 + g, 0.2) + 1.0
+        bn_b = _rand((cout,), 70 + g, 0.1)
+        mu = _rand((cout,), 80 + g, 0.1)
+        var = _rand((cout,), 90 + g, 0.1).abs() + 0.5
+        _chk(lib.uvl_fold_conv_bn(_p(w), _p(b), _p(bn_w), _p(bn_b), _p(mu), _p(var), C.c_void_p(wpk[g].data_ptr()), C.c_void_p(bpk[g * cout:].data_ptr()), cout, cin, _stream()), lib)
+        xg = x[:, :, g * cin:(g + 1) * cin].float().reshape(B, F, F, cin).permute(0, 3, 1, 2)
+        y = torch.nn.functional.conv2d(xg, w, b, padding=1)
+        y = torch.relu(torch.nn.functional.batch_norm(y, mu, var, bn_w, bn_b, training=False, eps=1e-5))
+        k0 = sum(rows[:g])
+        maps.append(torch.nn.functional.conv2d(y, w1[k0:k0 + rows[g], :, None, None], b1[k0:k0 + rows[g]]).reshape(B, rows[g], S))
+    cont = _rand((B, S, cont_ch), 160, 1.0).contiguous()
+    flag = (torch.arange(B, device="cuda") % 3).to(torch.int64)
+    jj, ii = torch.meshgrid(torch.arange(F, device="cuda").float(), torch.arange(F, device="cuda").float(), indexing="xy")
+    coord = torch.stack([jj.reshape(-1), ii.reshape(-1)]) + (0.0 if offset_sigmoid else 0.5)
+    cls_ref = torch.sigmoid(maps[0][:, 0])
+    off = torch.sigmoid(maps[1]) if offset_sigmoid else maps[1]
+    size = torch.where((flag == 1)[:, None, None], torch.sigmoid(maps[3]), torch.sigmoid(maps[2]))
+    box_ref = torch.cat([(coord[None] + off) / F, size], 1).transpose(1, 2)
+    score_ref = cls_ref * cont.softmax(-1)[..., 0]
+    scratch = torch.empty((max(B * S * 4 * cout, 4 * 32 * 9 * 64),), dtype=torch.bfloat16, device="cuda")
+    cls = torch.full((B, S), float("nan"), device="cuda")
+    cls_test = torch.full((B, S), float("nan"), device="cuda")
+    bbox = torch.full((B, S, 4), float("nan"), device="cuda")
+    pred = torch.full((B, 4), float("nan"), device="cuda")
+    arg = torch.full((B,), -1, dtype=torch.int64, device="cuda")
+    _chk(lib.uvl_head_end(_p(x), B, F, cin, _p(wpk), _p(bpk), _p(w1), _p(b1), _p(cont), cont_ch, _p(flag), _p(coord.contiguous()), offset_sigmoid, joint_cls, form,
+                          _p(scratch), _p(cls), _p(cls_test), _p(bbox), _p(pred), _p(arg), _stream()), lib)
+    torch.cuda.synchronize()
+    assert float((cls_test - cls_ref).abs().max()) < 6e-3
+    assert float((cls - (score_ref if joint_cls else cls_ref)).abs().max()) < 6e-3
+    assert float((bbox - box_ref).abs().max()) < (6e-3 if offset_sigmoid else 3e-2 / F * 4)
+    bi = torch.arange(B, device="cuda")
+    assert bool((arg >= 0).all()) and bool((arg < S).all())
+    assert bool((score_ref[bi, arg] >= score_ref.max(-1).values - 6e-3).all())          # the winner, up to positions that tie within the precision
+    assert torch.equal(pred, bbox[bi, arg])
+
+
+def test_head_end_forms_agree_and_a_nan_map_selects_position_zero(lib):
+    """Both forms on the same inputs: the same maps within bf16 accumulation-order noise and the same winner; an all-NaN score map (NaN cont_score) gives argmax 0
+    and pred_boxes = bbox_map[0] in both (torch.argmax would return the first NaN: position 0 as well)."""
+    B, F, cin, cout = 5, 16, 64, 32
+    S = F * F
+    x = torch.relu(_rand((B, S, 4 * cin), 231, 1.0)).bfloat16()
+    wpk = _rand((4, cout, 9 * cin), 232, 1.5 / math.sqrt(9 * cin)).bfloat16()
+    bpk = _rand((4 * cout,), 233, 0.1)
+    w1 = _rand((7, cout), 234, 2.0 / math.sqrt(cout))
+    b1 = _rand((8,), 235, 0.3)
+    cont = _rand((B, S, 3), 236, 1.0)
+    cont[2] = float("nan")
+    flag = (torch.arange(B, device="cuda") % 3).to(torch.int64)
+    coord = _rand((2, S), 237, 1.0).abs()
+    outs = []
+    for form in (0, 1):
+        scratch = torch.empty((B * S * 4 * cout,), dtype=torch.bfloat16, device="cuda")
+        cls_test = torch.empty((B, S), device="cuda")
+        bbox = torch.empty((B, S, 4), device="cuda")
+        pred = torch.empty((B, 4), device="cuda")
+        arg = torch.full((B,), -1, dtype=torch.int64, device="cuda")
+        _chk(lib.uvl_head_end(_p(x), B, F, cin, _p(wpk), _p(bpk), _p(w1), _p(b1), _p(cont), 3, _p(flag), _p(coord), 1, 1, form, _p(scratch), None, _p(cls_test), _p(bbox), _p(pred),
+                              _p(arg), _stream()), lib)
+        torch.cuda.synchronize()
+        outs.append((cls_test, bbox, pred, arg))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-3 and float((outs[0][1] - outs[1][1]).abs().max()) < 2e-3
+    for cls_test, bbox, pred, arg in outs:
+        assert int(arg[2]) == 0 and torch.equal(pred[2], bbox[2, 0])
+    keep = [0, 1, 3, 4]
+    score = outs[0][0] * cont.softmax(-1)[..., 0]
+    gap = score[keep].topk(2, -1).values
+    clear = (gap[:, 0] - gap[:, 1]) > 4e-3                       # samples whose winner is not a near-tie
+    assert bool((outs[0][3][keep][clear] == outs[1][3][keep][clear]).all())
+    assert float((outs[0][2][keep] - outs[1][2][keep])[clear].abs().max() if bool(clear.any()) else 0.0) < 2e-3
+
+
 def test_anno2mask_matches_oracle(lib):
     """uvl_anno2mask against the numpy restatement of the tracker's anno2mask (tracker:183-194), bit-exact, incl. boxes whose
     centre cell is the only one set and boxes touching the border."""

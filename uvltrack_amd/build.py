@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libuvltrack_hip.so")
-SOURCES = ["gemm.hip", "gemm_fin.hip", "gemm_dr.hip", "attention.hip", "rowops.hip", "prompter.hip", "preprocess.hip", "uvl_api.hip"]
+SOURCES = ["gemm.hip", "gemm_fin.hip", "gemm_dr.hip", "attention.hip", "rowops.hip", "head_fin.hip", "prompter.hip", "preprocess.hip", "uvl_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1",      # accumulators stay in VGPRs (unified file on gfx950): no v_accvgpr moves around the softmax
          # a*b+c fuses where the SOURCE expression says so, not wherever the optimiser finds a multiply next to an add: the same

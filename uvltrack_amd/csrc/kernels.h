@@ -239,6 +239,16 @@ struct HeadTailParams {
 };
 hipError_t launch_head_tail(const HeadTailParams& p, hipStream_t s);
 
+// The last 3x3 tower layer + the tail as one launch, one workgroup per sample (head_fin.hip): 16 x 16 search features, 4 x 64 -> 4 x 32 channels
+struct HeadFinParams {
+    HeadTailParams t;                                        // g4 / ld unused; c8 = 32
+    const bf16_t* g3 = nullptr; int g3_ld = 0;               // [B*S, 4*64] bf16: the output of tower layer 2
+    const bf16_t* wf = nullptr; const float* bias3 = nullptr;   // layer 3's weights in fragment order (launch_head_fin_pack), bias [4*32]
+};
+bool head_fin_ok(const HeadFinParams& p);
+hipError_t launch_head_fin(const HeadFinParams& p, hipStream_t s);
+hipError_t launch_head_fin_pack(const bf16_t* w, bf16_t* wf, hipStream_t s);
+
 // The prompter (DistributionBasedCrossAttention, heads/utils.py:23-99): token sums before the MLP, and the flag switch.
 struct PrompterParams {
     const float *tem = nullptr, *ctx = nullptr, *vis = nullptr, *txt = nullptr;     // [B,nz,D], [B,S,D], [B,1,D], [B,1,D] f32

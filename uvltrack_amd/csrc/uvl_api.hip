@@ -53,8 +53,9 @@ struct DispatchRules {
     long prefetch_max_rows;       // 2000  next-weight requests in the small-tile GEMM launches below this many visual rows ... (tools/probes/wprefetch_probe.py)
     double prefetch_min_weights;  // 2e8   ... for models whose ViT weights (bytes) cannot stay in the 256 MB memory-side cache (UVLTrack-L x 1 +2.6..3.4 %; -B: 0)
     long conv_sk_max_blocks;      // 768   split-K of a conv tower layer: slices while tiles x slices stay within three workgroups per CU (profiles/r01_summary.md)
+    int head_fin_max_batch;       // 1<<30 last tower layer + head tail as one launch, one workgroup per sample, at 16 x 16 search features / HEAD_DIM 256 (head_fin.hip; profiles/r06_head_fin.md)
 };
-static const DispatchRules kDispatch = {256, 256, 4, 6, 24, 2048, 5000, 1024, 16000, 6000, 2000, 2.0e8, 768};
+static const DispatchRules kDispatch = {256, 256, 4, 6, 24, 2048, 5000, 1024, 16000, 6000, 2000, 2.0e8, 768, 1 << 30};
 
 struct RawTensor {
     float* d = nullptr;
@@ -129,6 +130,8 @@ struct uvl_model {
     int rider_first = 1;                         // uvl_debug_set("rider_first", 0): the text rider's tiles of a one-sequence pair GEMM launch behind the visual tiles (the round-4 order; A/B)
     int rider_sk = 2;                            // uvl_debug_set("rider_sk", 1): the text rider's output GEMM in one K slice, in place (the round-4 form; A/B)
     int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
+    bf16_t* head_wf = nullptr;                   // tower layer 3's weights in head_fin_kernel's fragment order (finalize; null when the geometry does not fit)
+    int head_fin = 1;                            // uvl_debug_set("head_fin", 0): tower layer 3 and head_tail as two launches (rounds 1-5; A/B)
     int fold_ln = 1;                             // uvl_debug_set("fold_ln", 0): one-sequence frames keep their LayerNorm launches and split-K slabs (the round-1..5 schedule; A/B)
     int fuse_ln = 0;                             // uvl_debug_set("fuse_ln", 1): one-sequence frames launch LayerNorm + its consumer GEMM as ONE kernel behind a
                                                  // grid barrier (96 -> 72 launches; measured 3-4 % SLOWER than the two launches, so off: profiles/r03_summary.md)
@@ -445,6 +448,10 @@ extern "C" int uvl_finalize_weights(uvl_model_t* m, void* stream) {
             if (w && b && g && be && mu && var && cw.w && cw.b)
                 launch_fold_conv_bn(w, b, g, be, mu, var, cw.w + (size_t)t * co * 9 * ci, cw.b + (size_t)t * co, co, ci, s);
         }
+    }
+    if (m->F == 16 && m->C == 256) {             // the geometry head_fin_kernel is written for (head_fin.hip)
+        m->head_wf = P.alloc<bf16_t>((size_t)4 * 32 * 9 * 64);
+        if (m->head_wf && m->conv[3].w && launch_head_fin_pack(m->conv[3].w, m->head_wf, s) != hipSuccess) return fail(UVL_EHIP, "head weight packing failed");
     }
     const int c8 = m->C / 8;
     m->w1 = P.alloc<float>(7 * c8);
@@ -1359,20 +1366,31 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
     const bf16_t* cin[4] = {w.G0, w.G1, w.G2, w.G3};
     bf16_t* cout[4] = {w.G1, w.G2, w.G3, w.G4};
     const int in_ld[4] = {g0_ld, 4 * C, 2 * C, C};
-    for (int l = 0; l < 4; ++l) {
+    HeadFinParams hf;
+    {
+        HeadTailParams& p = hf.t;
+        p.g4 = w.G4; p.ld = C / 2; p.c8 = C / 8; p.w1 = m->w1; p.b1 = m->b1; p.cont = cont; p.cont_ch = (m->cfg.softmax_one && !tb) ? 3 : 2;
+        p.flag = in->d_flag; p.coord = m->coord; p.B = B; p.S = S; p.F = m->F; p.offset_sigmoid = m->cfg.offset_sigmoid; p.joint_cls = m->cfg.joint_cls;
+        p.o_cls = out->d_cls_score; p.o_cls_test = out->d_cls_score_test; p.o_bbox_map = bbox; p.o_pred = out->d_pred_boxes; p.o_argmax = out->d_argmax;
+        hf.g3 = w.G3; hf.g3_ld = C; hf.wf = m->head_wf; hf.bias3 = m->conv[3].b;
+    }
+    // the last tower layer + the tail as ONE launch where the geometry fits (head_fin.hip): any batch -- one workgroup per sample
+    const bool fin_head = m->head_fin && head_fin_ok(hf) && B <= kDispatch.head_fin_max_batch;
+    for (int l = 0; l < (fin_head ? 3 : 4); ++l) {
         const ConvLayerW& cw = m->conv[l];
         int goff[4];
         for (int g = 0; g < 4; ++g) goff[g] = (l == 0) ? ((g == 0 && m->cfg.cls_tokenize) ? D : 0) : g * cw.cin;
         const ConvLayerW* nx = (pfw && l + 1 < 4) ? &m->conv[l + 1] : nullptr;
+        const void* nxw = nx ? (const void*)((fin_head && l == 2) ? m->head_wf : nx->w) : nullptr;
         run_conv_layer(L, s, l, cin[l], in_ld[l], goff, cw.w, cw.b, B, m->F, cw.cin, cw.cout, cout[l], w.ConvPart, &m->tune,
-                       nx ? nx->w : nullptr, nx ? (size_t)4 * nx->cout * 9 * nx->cin * 2 : 0);
+                       nxw, nx ? (size_t)4 * nx->cout * 9 * nx->cin * 2 : 0);
     }
-    {
-        HeadTailParams p;
-        p.g4 = w.G4; p.ld = C / 2; p.c8 = C / 8; p.w1 = m->w1; p.b1 = m->b1; p.cont = cont; p.cont_ch = (m->cfg.softmax_one && !tb) ? 3 : 2;
-        p.flag = in->d_flag; p.coord = m->coord; p.B = B; p.S = S; p.F = m->F; p.offset_sigmoid = m->cfg.offset_sigmoid; p.joint_cls = m->cfg.joint_cls;
-        p.o_cls = out->d_cls_score; p.o_cls_test = out->d_cls_score_test; p.o_bbox_map = bbox; p.o_pred = out->d_pred_boxes; p.o_argmax = out->d_argmax;
-        L.run(s, "head_tail", 0, 0, tramp<HeadTailParams, launch_head_tail>, &p);
+    if (fin_head) {
+        const double fl = 2.0 * B * S * 4.0 * (C / 8) * 9.0 * (C / 4);
+        L.wb_next = 2.0 * 4.0 * (C / 8) * 9.0 * (C / 4);
+        L.run(s, "head_fin", fl, 2.0 * ((double)B * S * C + 4.0 * (C / 8) * 9.0 * (C / 4)), tramp<HeadFinParams, launch_head_fin>, &hf);
+    } else {
+        L.run(s, "head_tail", 0, 0, tramp<HeadTailParams, launch_head_tail>, &hf.t);
     }
     return L.err;
 }
@@ -1453,6 +1471,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "fuse_contrast")) { m->fuse_contrast = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fold_ln")) { m->fold_ln = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "head_fin")) { m->head_fin = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return UVL_OK; }      // (its weight images: the next frame, on its stream)
     if (!strcmp(key, "fork_text")) { m->fork_text = value ? 1 : 0; return UVL_OK; }   // 0: the text branch of multi-sequence frames runs on the caller's stream
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
@@ -1715,6 +1734,37 @@ extern "C" int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_
     run_conv_layer(L, (hipStream_t)stream, 0, (const bf16_t*)d_x, x_ld, goff, (const bf16_t*)d_w_packed, d_bias_folded, batch, feat, cin, cout,
                    (bf16_t*)d_y, d_slabs, tune);
     return L.err;
+}
+
+extern "C" int uvl_head_end(const void* d_g3, int batch, int feat, int cin, const void* d_w_packed, const float* d_bias_folded, const float* d_w1, const float* d_b1,
+                            const float* d_cont_score, int cont_channels, const int64_t* d_flag, const float* d_coord, int offset_sigmoid, int joint_cls, int form, void* d_scratch,
+                            float* d_cls_score, float* d_cls_score_test, float* d_bbox_map, float* d_pred_boxes, int64_t* d_argmax, void* stream) {
+    if (!d_g3 || !d_w_packed || !d_bias_folded || !d_w1 || !d_b1 || !d_cont_score || !d_flag || !d_coord || !d_scratch || batch <= 0 || feat <= 0)
+        return fail(UVL_EINVAL, "uvl_head_end: bad argument");
+    if (cin % 64 != 0 || cont_channels < 1 || cont_channels > 3) return fail(UVL_EINVAL, "uvl_head_end: need cin %% 64 == 0 and 1..3 cont_score channels");
+    hipStream_t s = (hipStream_t)stream;
+    const int cout = cin / 2;
+    HeadFinParams hf;
+    HeadTailParams& p = hf.t;
+    p.g4 = (const bf16_t*)d_scratch; p.ld = 4 * cout; p.c8 = cout; p.w1 = d_w1; p.b1 = d_b1; p.cont = d_cont_score; p.cont_ch = cont_channels;
+    p.flag = d_flag; p.coord = d_coord; p.B = batch; p.S = feat * feat; p.F = feat; p.offset_sigmoid = offset_sigmoid ? 1 : 0; p.joint_cls = joint_cls ? 1 : 0;
+    p.o_cls = d_cls_score; p.o_cls_test = d_cls_score_test; p.o_bbox_map = d_bbox_map; p.o_pred = d_pred_boxes; p.o_argmax = d_argmax;
+    hf.g3 = (const bf16_t*)d_g3; hf.g3_ld = 4 * cin; hf.wf = (const bf16_t*)d_scratch; hf.bias3 = d_bias_folded;
+    if (form == 1) {
+        if (!head_fin_ok(hf)) return fail(UVL_EINVAL, "uvl_head_end: the one-launch form is written for 16 x 16 features and 4 x 64 -> 4 x 32 channels");
+        HIPCHK(launch_head_fin_pack((const bf16_t*)d_w_packed, (bf16_t*)d_scratch, s));
+        HIPCHK(launch_head_fin(hf, s));
+        return UVL_OK;
+    }
+    Launcher L{nullptr};
+    int goff[4] = {0, cin, 2 * cin, 3 * cin};
+    uvl_tuning tune;
+    uvl_tuning_init(&tune);
+    tune.fin_w = 2;                                          // (the plain launch: this entry's form 0 is the two-launch path of every geometry)
+    run_conv_layer(L, s, 3, (const bf16_t*)d_g3, 4 * cin, goff, (const bf16_t*)d_w_packed, d_bias_folded, batch, feat, cin, cout, (bf16_t*)d_scratch, nullptr, &tune);
+    if (L.err) return L.err;
+    HIPCHK(launch_head_tail(p, s));
+    return UVL_OK;
 }
 
 extern "C" int uvl_attention(const void* d_q, const void* d_k, const void* d_vt, const float* d_key_add, void* d_o, int B, int H, int N, int Npad, int q_prescaled,
