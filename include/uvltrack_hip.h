@@ -241,7 +241,8 @@ int uvl_profile_entry_weight_bytes(const uvl_model_t* m, int i, double* bytes);
  * weights non-temporal -- bit 0 QKV, 1 attention output, 2 intermediate, 3 output (0: none; two UVLTrack-B sequences lose 3.5 % with it, one is level).
  * "bf16_store" (default 3): which bf16 activations of frames of >= 2048 rows are stored write-through -- bit 0 the fc1 output, 1 the q / k rows of QKV, 2 LayerNorm's
  * rows (0: plain stores, the round-4 form: 8 UVLTrack-L sequences lose 2.2 %).  "head_fin" (default 1): 0 keeps the towers' last 3x3 layer and the head tail as two
- * launches where the one-launch form applies (16 x 16 search features, HEAD_DIM 256: see uvl_head_end). */
+ * launches where the one-launch form applies (16 x 16 search features, HEAD_DIM 256: see uvl_head_end).  "rider_pf" (default 0): n > 0 lets the text riders of BERT layers < n
+ * of a one-sequence frame request the next rider's weight into the L2 of the XCD that will read it (measured level: profiles/NOTES.md). */
 int uvl_debug_set(uvl_model_t* m, const char* key, int value);
 
 /* Overrides of the launch heuristics, for tools and tests (not part of the product path).  There is NO process-global tuning

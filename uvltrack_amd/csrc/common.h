@@ -266,4 +266,22 @@ __device__ __forceinline__ uint32_t prefetch_issue(const void* ptr, uint32_t byt
     }
     return sink;
 }
+// The same for a RIDER's next weight (the text branch's GEMM that rides in the next launch: its bytes come from HBM, nobody has read them this frame), XCD-matched:
+// the rider's `tiles` one-row-of-tiles panels (`lp` 128-byte lines each, contiguous in the weight) are consumed in 8 contiguous runs, run x by the workgroups with
+// blockIdx % 8 == x of THAT launch (gemm_glds_body / gemm_fin_body tile order) -- so the workgroups with blockIdx % 8 == x of THIS launch request run x: the lines
+// arrive in the L2 of the XCD that will read them (every XCD has its own L2; a request from another XCD only reaches the memory-side cache).
+template <int THREADS>
+__device__ __forceinline__ uint32_t prefetch_issue_xcd(uint32_t sink, const void* ptr, uint32_t tiles, uint32_t lp, uint32_t wg, uint32_t nwg) {
+    if (ptr) {
+        const uint32_t x = wg & 7, j = wg >> 3, nx = (nwg - x + 7) >> 3;
+        const uint32_t base = tiles >> 3, rem = tiles & 7;
+        const uint32_t first = (x * base + (x < rem ? x : rem)) * lp, count = (base + (x < rem ? 1u : 0u)) * lp;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t q = (j + k * nx) * THREADS + threadIdx.x;
+            if (q < count) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(reinterpret_cast<const char*>(ptr) + (size_t)(first + q) * 128) : "memory");
+        }
+    }
+    return sink;
+}
 __device__ __forceinline__ void prefetch_retire(uint32_t sink) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory"); }

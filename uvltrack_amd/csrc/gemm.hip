@@ -1371,7 +1371,8 @@ __global__ __launch_bounds__(256) void gemm_lnf_pair_kernel(const GemmParams pa,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = (int)blockIdx.x, nb = (int)gridDim.x - blocks_ct;
     if (bid >= nb) { ct_job_block(ct, bid - nb, g_zero_row); return; }
-    const uint32_t pfs = prefetch_issue<256>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
+    uint32_t pfs = prefetch_issue<256>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
+    pfs = prefetch_issue_xcd<256>(pfs, pb.pf2, pb.pf2_tiles, pb.pf2_lp, blockIdx.x, nb);
     if (bid < blocks_b) gemm_glds_body<64, 64, 2, 2, EPI, 4, false, true, 64, 0, 0, true>(pb, bid, 0, 0, smem);       // the rider first: its weight tiles come from HBM (non-temporal)
     else gemm_glds_body<64, BN, 2, 2, EPI, NS, false, false, 64, 0, 0, true>(pa, bid - blocks_b, 0, 0, smem);
     prefetch_retire(pfs);

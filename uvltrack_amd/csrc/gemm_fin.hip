@@ -243,7 +243,8 @@ template <int BNA, int BNB>
 __global__ __launch_bounds__(512) void gemm_fin_pair_kernel(const GemmParams pa, const GemmParams pb, const int blocks_b) {
     kernarg_warm<2 * sizeof(GemmParams) + 8 + 64>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t pfs = prefetch_issue<512>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
+    uint32_t pfs = prefetch_issue<512>(pa.pf, pa.pf_bytes, blockIdx.x, gridDim.x);
+    pfs = prefetch_issue_xcd<512>(pfs, pb.pf2, pb.pf2_tiles, pb.pf2_lp, blockIdx.x, gridDim.x);
     if ((int)blockIdx.x < blocks_b) gemm_fin_tile<true, BNB>(pb, blockIdx.x, smem);
     else gemm_fin_tile<false, BNA>(pa, (int)blockIdx.x - blocks_b, smem);
     prefetch_retire(pfs);
@@ -388,7 +389,7 @@ int conv_fin_form(const GemmParams& p) {
     if (p.conv_F <= 0 || p.epi != EPI_BF16 || p.act != 2 || p.cin_g % 64 != 0 || p.K != 9 * p.cin_g || p.M <= 0 || p.groups < 1 || p.groups > 4 || !p.C) return 0;
     if (tune_get(p.tune, &uvl_tuning::fin_w, -1) == 2) return 0;                 // uvl_tune_set("fin_w", 2): the slab form everywhere (A/B)
     const int nk = p.K / 64, MT = (p.M + 63) / 64;
-    if (nk > 48) return 0;                                                        // a long K (the first layer) is better cut over many workgroups
+    if (nk > 48 && tune_get(p.tune, &uvl_tuning::fin_w, -1) != 3) return 0;      // a long K (the first layer) is better cut over many workgroups (fin_w 3: A/B of that)
     if (p.N % 32 == 0 && nk % 4 == 0 && (long)MT * (p.N / 32) * p.groups <= 256) return 2;
     if (p.N % 64 == 0 && nk % 2 == 0 && (long)MT * (p.N / 64) * p.groups <= 256) return 1;
     return 0;

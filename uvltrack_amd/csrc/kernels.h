@@ -37,6 +37,7 @@ struct GemmParams {
     const uvl_tuning* tune = nullptr;            // host side only: overrides of the launch heuristics (null = heuristics)
     int c_store = 0;                             // EPI_F32 stores: 0 plain, 1 non-temporal, 2 write-through (sc1); A/B knob uvl_tuning.res_store
     const void* pf = nullptr; uint32_t pf_bytes = 0;   // optional: bytes the launch requests for the NEXT launch (its weight), see common.h::prefetch_issue
+    const void* pf2 = nullptr; uint32_t pf2_tiles = 0, pf2_lp = 0;   // a rider's params: the NEXT rider's weight, requested XCD-matched (common.h::prefetch_issue_xcd)
                                                  // (the 64 x 64-tile kernels of small frames; the large-tile kernels ignore it)
     int group_m = 0;                             // set by the launcher: 0 = each XCD owns whole N panels (weights stream once; small M),
                                                  // g > 0 = grouped order, g M-tiles x all N-tiles per group, contiguous runs per XCD (large M)

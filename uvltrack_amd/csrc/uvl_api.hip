@@ -131,6 +131,8 @@ struct uvl_model {
     int rider_sk = 2;                            // uvl_debug_set("rider_sk", 1): the text rider's output GEMM in one K slice, in place (the round-4 form; A/B)
     int fold_modal = 1;                          // uvl_debug_set("fold_modal", 0): the fusion layers' modal embedding always added by their LayerNorm-1 (A/B)
     bf16_t* head_wf = nullptr;                   // tower layer 3's weights in head_fin_kernel's fragment order (finalize; null when the geometry does not fit)
+    int rider_pf = 0;                            // uvl_debug_set("rider_pf", n): the riders of BERT layers < n request the NEXT rider's weight XCD-matched (common.h::prefetch_issue_xcd).  Off: the
+                                                 // pair launches gain 1.1 us each, but the requests allocate the BERT weights in the memory-side cache and the ViT weights of the later blocks leave it (profiles/NOTES.md, round 6)
     int head_fin = 1;                            // uvl_debug_set("head_fin", 0): tower layer 3 and head_tail as two launches (rounds 1-5; A/B)
     int fold_ln = 1;                             // uvl_debug_set("fold_ln", 0): one-sequence frames keep their LayerNorm launches and split-K slabs (the round-1..5 schedule; A/B)
     int fuse_ln = 0;                             // uvl_debug_set("fuse_ln", 1): one-sequence frames launch LayerNorm + its consumer GEMM as ONE kernel behind a
@@ -1104,6 +1106,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 if (rider) {
                     t.A = w.Tn; t.lda = D; t.W = bw->fqkv; t.ldw = D; t.bias = bw->fbqkv; t.colsum = bw->csqkv; t.st_in = w.StT0; t.ln_eps = 1e-12f; t.M = Mt; t.N = 3 * D; t.K = D;
                     t.epi = 2; t.rpb = T; t.q = w.Tq; t.k = w.Tk; t.vt = w.Tvt; t.H = H; t.Npad = 64; t.D = D; t.q_scale = UVL_QSCALE;
+                    if (i < m->rider_pf) { t.pf2 = bw->wao; t.pf2_tiles = D / 32; t.pf2_lp = D / 2; }        // attention.output.dense: 32-row panels of K = D
                 }
                 run_lnf("gemm.qkv", p, rider ? &t : nullptr, have_ct ? &ctj : nullptr);
                 have_ct = false;
@@ -1134,6 +1137,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                     // the residual is the LayerNorm in front of this layer applied to the stored pre-norm rows: the embedding LayerNorm (layer 0) or output.LayerNorm of layer i - 1
                     t.res_st = w.StT0; t.res_g = i == 0 ? m->emb_g : m->bert[i - 1].ln2g; t.res_b = i == 0 ? m->emb_b : m->bert[i - 1].ln2b; t.res_eps = 1e-12f;
                     if (i > 0 && is_cont_layer(i - 1) && out->d_logits) t.res_copy = w.TxtSnap + (size_t)(i - 1) * Mt * D;      // layer i - 1's text rows, for frames that reuse the branch
+                    if (i < m->rider_pf) { t.pf2 = bw->fi; t.pf2_tiles = Fn / 64; t.pf2_lp = D; }             // intermediate.dense: 64-row panels of K = D
                 }
                 run_fin("gemm.proj", p, rider ? &t : nullptr);
             }
@@ -1146,6 +1150,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                 if (rider) {
                     t.A = w.Tn; t.lda = D; t.W = bw->fi; t.ldw = D; t.bias = bw->fbi; t.colsum = bw->csi; t.st_in = w.StT1; t.ln_eps = 1e-12f; t.M = Mt; t.N = Fn; t.K = D;
                     t.epi = 0; t.C = w.Th; t.ldc = Fn; t.act = 1;
+                    if (i < m->rider_pf) { t.pf2 = bw->wo; t.pf2_tiles = D / 32; t.pf2_lp = Fn / 2; }         // output.dense: 32-row panels of K = 4 D
                 }
                 run_lnf("gemm.fc1", p, rider ? &t : nullptr, nullptr);
             }
@@ -1165,6 +1170,7 @@ static int run_forward(uvl_model* m, const uvl_inputs* in, const uvl_outputs* ou
                     t.A = w.Th; t.lda = Fn; t.W = bw->wo; t.ldw = Fn; t.bias = bw->bo; t.M = Mt; t.N = D; t.K = Fn; t.epi = 1; t.C = w.X; t.ldc = D; t.accumulate = 1;
                     t.rpb = T; t.obs = nj; t.oro = nv; t.xn = w.Tn; t.xn_bs = T; t.xn_ro = 0; t.st_out = w.StT0; t.st_rows = Mt;
                     t.res_st = w.StT1; t.res_g = bw->ln1g; t.res_b = bw->ln1b; t.res_eps = 1e-12f;
+                    if (i + 1 < m->rider_pf && i + 1 <= tl) { t.pf2 = m->bert[i + 1].fqkv; t.pf2_tiles = 3 * D / 64; t.pf2_lp = D; }      // the next layer's query / key / value
                 }
                 run_fin("gemm.fc2", p, rider ? &t : nullptr);
             }
@@ -1472,6 +1478,7 @@ extern "C" int uvl_debug_set(uvl_model_t* m, const char* key, int value) {
     if (!strcmp(key, "fuse_ln")) { m->fuse_ln = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "fold_ln")) { m->fold_ln = value ? 1 : 0; return UVL_OK; }
     if (!strcmp(key, "head_fin")) { m->head_fin = value ? 1 : 0; return UVL_OK; }
+    if (!strcmp(key, "rider_pf")) { m->rider_pf = value < 0 ? 0 : value; return UVL_OK; }
     if (!strcmp(key, "text_dr_res")) { m->text_dr_res = value ? 1 : 0; return UVL_OK; }      // (its weight images: the next frame, on its stream)
     if (!strcmp(key, "fork_text")) { m->fork_text = value ? 1 : 0; return UVL_OK; }   // 0: the text branch of multi-sequence frames runs on the caller's stream
     return fail(UVL_ENOTFOUND, "unknown debug key '%s'", key);
