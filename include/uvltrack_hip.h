@@ -297,6 +297,14 @@ int uvl_pack_weight(const void* d_w, void* d_w_packed, int N, int K, void* strea
 int uvl_linear_pk(const void* d_x, const void* d_w, const void* d_w_packed, const float* d_bias, void* d_y,
                   int M, int N, int K, int act, int out_f32, int accumulate, const uvl_tuning* tune, void* stream);
 
+/* ModalityUnifiedFeatureExtractor.contractive_learning (extractor.py:79-93) of one layer, as the frame runs it: logits[b, slot, s] = exp(logit_scale) *
+ * normalize(x[b, 1 + nz + s]) . normalize(token), token = [x[b, 0], text token, mean of the two logits][flag[b]]; the text token is row `text_row` of the sample
+ * ('cls') or the masked mean of rows text_row .. + text_len (mean_mode; d_text_mask [batch, text_len]); skip_text: visual logits only.  d_x: f32 [batch,
+ * rows_per_sample, dim]; d_logits: f32 [batch, n_cont, nx].  form 0 = contrast_kernel (LayerNorm-kernel schedule), 1 = the job that rides in the QKV launches of a
+ * LayerNorm-free frame, launched alone ('cls' token only).  Exported for the parity tests. */
+int uvl_contrast_logits(const float* d_x, int batch, int rows_per_sample, int dim, int nz, int nx, int text_row, int text_len, const uint8_t* d_text_mask,
+                        int mean_mode, int skip_text, const int64_t* d_flag, const float* d_logit_scale, float* d_logits, int slot, int n_cont, int form, void* stream);
+
 /* The end of ModalityAdaptiveBoxHead.forward (modality_adaptive_box_head.py:71-94) from the towers' third 3x3 layer onwards: the last conv3x3 + BatchNorm(eval) + ReLU
  * of the four towers (heads/utils.py:126-131; C/4 -> C/8 channels), their 1x1 convs, the sigmoids, the size-map select by flag and convert2bbox (:108-119) incl. the
  * argmax -- as the frame runs it.  d_g3: bf16 [batch * feat^2][4 * cin] (tower-major channels), d_w_packed / d_bias_folded: uvl_fold_conv_bn's outputs for cout = cin / 2,

@@ -483,6 +483,33 @@ def test_head_end_forms_agree_and_a_nan_map_selects_position_zero(lib):
     assert float((outs[0][2][keep] - outs[1][2][keep])[clear].abs().max() if bool(clear.any()) else 0.0) < 2e-3
 
 
+@pytest.mark.parametrize("B,D,nz,nx,T,mode,form,skip", [(3, 768, 64, 256, 40, "cls", 0, 0), (3, 768, 64, 256, 40, "cls", 1, 0), (5, 1024, 64, 576, 40, "cls", 1, 0),
+                                                     (4, 768, 64, 256, 40, "mean", 0, 0), (2, 256, 4, 16, 8, "cls", 1, 1), (2, 256, 4, 16, 8, "mean", 0, 1), (7, 64, 1, 7, 5, "cls", 1, 0)])
+def test_contrast_logits_match_the_oracle(lib, B, D, nz, nx, T, mode, form, skip):
+    """The contrastive logits of a layer (extractor.py:79-93) at kernel level, both implementations (contrast_kernel; the job of the LayerNorm-free frames'
+    QKV launches) against the numpy oracle: flags 0 / 1 / 2, 'cls' and 'mean' text tokens incl. a sentence of one token, text skipped, UVLTrack-B and -L widths."""
+    import numpy as np
+    from oracle import uvl_oracle as O
+    rows = 1 + nz + nx + T
+    x = _rand((B, rows, D), 300 + D, 1.0)
+    x[:, 1 + nz:1 + nz + nx] += 0.5 * x[:, :1]                   # some alignment with the vis token: logits not all near zero
+    mask = torch.zeros((B, T), dtype=torch.uint8, device="cuda")
+    for b in range(B):
+        mask[b, :max(1, (b * 7) % T)] = 1
+    flag = (torch.arange(B, device="cuda") % 3).to(torch.int64) * (0 if skip else 1)       # (the frame skips the text branch only when every flag is 0)
+    scale = torch.tensor([math.log(14.3)], device="cuda")
+    logits = torch.full((B, 2, nx), float("nan"), device="cuda")
+    _chk(lib.uvl_contrast_logits(_p(x), B, rows, D, nz, nx, 1 + nz + nx, T, _p(mask), 1 if mode == "mean" else 0, skip, _p(flag), _p(scale), _p(logits), 1, 2, form, _stream()), lib)
+    torch.cuda.synchronize()
+    xn = x.cpu().numpy()
+    img, txt = xn[:, :1 + nz + nx], xn[:, 1 + nz + nx:]
+    fl = flag.cpu().numpy()
+    ref = O.backbone_contrast({"backbone.logit_scale": scale.cpu().numpy()}, img, txt, mask.cpu().numpy().astype(bool), fl, nz, mode)[..., 0]
+    got = logits.cpu().numpy()
+    assert np.isnan(got[:, 0]).all()                               # the other slot is not touched
+    np.testing.assert_allclose(got[:, 1], ref, rtol=1e-4, atol=1e-4)
+
+
 def test_anno2mask_matches_oracle(lib):
     """uvl_anno2mask against the numpy restatement of the tracker's anno2mask (tracker:183-194), bit-exact, incl. boxes whose
     centre cell is the only one set and boxes touching the border."""

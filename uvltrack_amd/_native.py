@@ -21,7 +21,7 @@ EXPORTS = [
     "uvl_workspace_bytes", "uvl_forward_test", "uvl_forward_prompt", "uvl_forward", "uvl_anno2mask", "uvl_decode", "uvl_crop_geometry_of", "uvl_sample_target", "uvl_sample_target_window", "uvl_sample_target_staged", "uvl_grounding_resize", "uvl_normalize_u8", "uvl_graph_capture", "uvl_graph_launch", "uvl_graph_release",
     "uvl_forward_test_profiled", "uvl_profile_count", "uvl_profile_entry", "uvl_profile_entry_weight_bytes", "uvl_debug_set", "uvl_tune_set", "uvl_tuning_init", "uvl_linear_splitk",
     "uvl_linear", "uvl_linear_pk", "uvl_pack_weight", "uvl_attention", "uvl_qkv_project", "uvl_qkv_project_pk", "uvl_layernorm", "uvl_f32_to_bf16", "uvl_fold_conv_bn", "uvl_conv_tower_layer",
-    "uvl_fold_ln_linear", "uvl_linear_fin", "uvl_linear_lnf", "uvl_qkv_project_lnf", "uvl_head_end",
+    "uvl_fold_ln_linear", "uvl_linear_fin", "uvl_linear_lnf", "uvl_qkv_project_lnf", "uvl_head_end", "uvl_contrast_logits",
 ]
 
 
@@ -161,6 +161,7 @@ def load():
     lib.uvl_linear_fin.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, C.c_float, vp, tp, vp]
     lib.uvl_linear_lnf.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, tp, vp]
     lib.uvl_qkv_project_lnf.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, C.c_float, tp, vp]
+    lib.uvl_contrast_logits.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]
     lib.uvl_head_end.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib

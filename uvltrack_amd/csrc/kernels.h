@@ -213,6 +213,7 @@ struct ContrastParams {
     const float* txt_snap = nullptr;             // [B,T,D] text rows of this layer (pre-fusion layers) or null = read x
 };
 hipError_t launch_contrast(const ContrastParams& p, hipStream_t s);
+hipError_t launch_ct_job(const CtJob& j, hipStream_t s);
 
 // Head prologue: copy residual rows to the output dict, emit the bf16 NHWC conv input and cont_score (head:140-148).
 struct HeadPrepParams {

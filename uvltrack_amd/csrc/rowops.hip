@@ -506,6 +506,14 @@ hipError_t launch_contrast(const ContrastParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// The logits job of a LayerNorm-free frame (fold.h::ct_job_block, normally the last workgroups of a QKV launch) as a launch of its own: the parity tests' handle on it
+__global__ __launch_bounds__(256) void ct_job_kernel(const CtJob j) { ct_job_block(j, blockIdx.x, g_zero_row); }
+hipError_t launch_ct_job(const CtJob& j, hipStream_t s) {
+    if (j.D % 4 != 0 || j.D > 1024 || j.B <= 0 || j.nx <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ct_job_kernel, dim3((j.B * j.nx + 3) / 4), dim3(256), 0, s, j);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Head prologue.  grid (ceil(nj/4), B): one wave per residual row.
 //   * copies the row into the output dict entry it belongs to (extractor.py:66-76)

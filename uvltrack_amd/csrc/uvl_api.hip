@@ -1743,6 +1743,28 @@ extern "C" int uvl_conv_tower_layer(const void* d_x, int batch, int feat, int x_
     return L.err;
 }
 
+extern "C" int uvl_contrast_logits(const float* d_x, int batch, int rows_per_sample, int dim, int nz, int nx, int text_row, int text_len, const uint8_t* d_text_mask,
+                                   int mean_mode, int skip_text, const int64_t* d_flag, const float* d_logit_scale, float* d_logits, int slot, int n_cont, int form, void* stream) {
+    if (!d_x || !d_flag || !d_logit_scale || !d_logits || batch <= 0 || nx <= 0 || nz < 0 || dim % 4 != 0 || dim > 1024 || slot < 0 || slot >= n_cont)
+        return fail(UVL_EINVAL, "uvl_contrast_logits: bad argument");
+    if (1 + nz + nx > rows_per_sample || (!skip_text && text_row + (mean_mode ? text_len : 1) > rows_per_sample)) return fail(UVL_EINVAL, "uvl_contrast_logits: rows out of range");
+    if (form == 1) {
+        if (mean_mode) return fail(UVL_EINVAL, "uvl_contrast_logits: the LayerNorm-free frame's job takes the 'cls' text token only");
+        CtJob j;
+        j.x = d_x; j.xbs = rows_per_sample; j.D = dim; j.B = batch; j.nz = nz; j.nv = text_row; j.nx = nx; j.skip_text = skip_text ? 1 : 0;
+        j.flag = d_flag; j.logit_scale = d_logit_scale; j.logits = d_logits; j.slot = slot; j.ncont = n_cont;
+        HIPCHK(launch_ct_job(j, (hipStream_t)stream));
+        return UVL_OK;
+    }
+    if (mean_mode && !d_text_mask) return fail(UVL_EINVAL, "uvl_contrast_logits: the 'mean' text token needs the text mask");
+    ContrastParams p;
+    p.x = d_x; p.nj = rows_per_sample; p.nz = nz; p.nx = nx; p.nv = text_row; p.D = dim; p.T = text_len; p.B = batch;
+    p.text_mask = d_text_mask; p.flag = d_flag; p.logit_scale = d_logit_scale; p.mean_mode = mean_mode ? 1 : 0; p.skip_text = skip_text ? 1 : 0;
+    p.logits = d_logits; p.slot = slot; p.n_cont = n_cont;
+    HIPCHK(launch_contrast(p, (hipStream_t)stream));
+    return UVL_OK;
+}
+
 extern "C" int uvl_head_end(const void* d_g3, int batch, int feat, int cin, const void* d_w_packed, const float* d_bias_folded, const float* d_w1, const float* d_b1,
                             const float* d_cont_score, int cont_channels, const int64_t* d_flag, const float* d_coord, int offset_sigmoid, int joint_cls, int form, void* d_scratch,
                             float* d_cls_score, float* d_cls_score_test, float* d_bbox_map, float* d_pred_boxes, int64_t* d_argmax, void* stream) {
