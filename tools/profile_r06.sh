@@ -11,6 +11,7 @@ timeout 300 python tools/ab_tune.py debug.fold_ln 0 1 --mode BBOX --skip-text > 
 timeout 300 python tools/ab_tune.py debug.fold_ln 0 1 --model L --template-size 256 --search-size 384 > gpurun_out/${TAG}_ab_fold_L.txt 2>&1
 timeout 300 python tools/ab_tune.py fin_w 0 1 > gpurun_out/${TAG}_ab_finw.txt 2>&1
 timeout 300 python tools/ab_tune.py fin_w 2 -1 > gpurun_out/${TAG}_ab_convfin.txt 2>&1
+timeout 300 python tools/ab_tune.py debug.head_fin 0 1 > gpurun_out/${TAG}_ab_headfin.txt 2>&1
 timeout 900 bash tools/profile_bench.sh gpurun_out/$TAG > gpurun_out/$TAG.log 2>&1
 BENCH="python bench.py --steps 100 --warmup 20 --blocks 3 --no-cpu-baseline --no-batched --tune debug.fold_ln=0"
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_old/stats -o bench --output-format csv -- $BENCH > gpurun_out/${TAG}_old/bench_stats_run.json 2> gpurun_out/${TAG}_old/stats.log
