@@ -561,6 +561,35 @@ def test_repeated_frames_are_bit_identical(name, batch):
             assert torch.equal(cur[k], ref[k]), k
 
 
+@pytest.mark.parametrize("name", ["b_z256_x256", "l_z256_x384"])
+def test_off_default_forms_of_the_one_sequence_frame_change_no_bit_or_only_the_head(name):
+    """The tools' switches of round 6 on a one-sequence frame: "rider_pf" (the riders request the next rider's weight, XCD-matched: requests only -- every output bit
+    for bit) and "head_fin" 0 (tower layer 3 + head_tail as two launches: the backbone outputs bit for bit, the head maps within the accumulation-order noise
+    of the last layer).  Restores the defaults."""
+    meta, spec, _ = load_case(name)
+    inp = {k: v[:1] for k, v in rebuild_inputs(meta, spec).items()}
+    eng = _engine(meta, spec)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inp.items()}
+    keys = ("bbox_map", "cls_score_test", "cont_score", "logits", "search", "text", "pred_boxes")
+    run = lambda: {k: v.clone() for k, v in eng.forward(t["template"], t["search"], t["ids"], t["mask"], t["prompt"], t["flag"]).items() if k in keys}
+    ref = run()
+    try:
+        eng.debug_set("rider_pf", 64)
+        got = run()
+        for k in keys:
+            assert torch.equal(got[k], ref[k]), k
+        eng.debug_set("rider_pf", 0)
+        eng.debug_set("head_fin", 0)
+        got = run()
+        for k in ("cont_score", "logits", "search", "text"):
+            assert torch.equal(got[k], ref[k]), k
+        for k in ("bbox_map", "cls_score_test"):
+            assert float((got[k] - ref[k]).abs().max()) < 2e-3, k
+    finally:
+        eng.debug_set("rider_pf", 0)
+        eng.debug_set("head_fin", 1)
+
+
 @pytest.mark.parametrize("name", ["b_z256_x256", "l_z256_x384", "tiny_mixed"])
 def test_fused_layernorm_gemm_launch_is_bit_identical(name):
     """uvl_debug_set("fuse_ln", 1): one-sequence frames run LayerNorm + the GEMM that consumes it (LN-1 -> QKV, LN-2 -> fc1, with the
